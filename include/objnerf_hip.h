@@ -1,0 +1,253 @@
+/* objnerf_hip.h -- C ABI of libobjnerf_hip.so: the MI355X (gfx950) replacement for the
+ * volume-rendering hot path of zju3dv/object_nerf.
+ *
+ * The reference has NO native interface for this path (it is pure PyTorch); each entry point
+ * below names the reference Python code it replaces (paths relative to the reference root).
+ * The binding a maintainer adds on the reference side is a ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name starts with `h_`;
+ *   - `stream` is a hipStream_t passed as void*; calls only ENQUEUE work on it, never synchronise,
+ *     never allocate: the caller owns every buffer including workspaces;
+ *   - return 0 on success, negative on error; objnerf_last_error() gives the message of the last
+ *     failing call made by the calling thread;
+ *   - all arithmetic is fp32 with the reference's operation order wherever it is observable
+ *     (DESIGN.md "numerics contract").
+ */
+#ifndef OBJNERF_HIP_H
+#define OBJNERF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBJNERF_ABI_VERSION 1
+
+int objnerf_abi_version(void);
+const char* objnerf_last_error(void);
+
+/* ---- sparse voxel grid: state of models/embedding_helper.py::EmbeddingVoxel (77-200) ---- */
+typedef struct {
+  const int32_t* idx_map;   /* (X,Y,Z) row-major; >=0 row of `table`, <0 empty (voxel_idx_map, 187-200) */
+  const float* table;       /* (n_rows, 24) embedding_space_ftr.weight (81) */
+  int32_t shape[3];         /* voxel_shape (111-122) */
+  float offset[3];          /* voxel_offset = -bounds[0] (108) */
+  float voxel_size;         /* voxel_size / scale_factor (102-103) */
+  int32_t n_rows;
+} objnerf_voxel_grid;
+
+/* ---- packed MLP weights of one models/nerf_model.py::ObjectNeRF ---- */
+/* sizes (in floats) of the weight stream and the aux (bias + heads) block */
+int64_t objnerf_blob_floats(int use_voxel);
+int64_t objnerf_aux_floats(void);
+/* number of parameter tensors the packer consumes, and their canonical order:
+ *   2*i = weight, 2*i+1 = bias of
+ *   xyz_encoding_{1..8}.0, xyz_encoding_final, dir_encoding.0, sigma, rgb.0,
+ *   instance_encoding_{1..4}.0, instance_encoding_final.0, inst_dir_encoding.0,
+ *   instance_sigma, inst_rgb.0                      (names: nerf_model.py:41-58, 77-95) */
+int objnerf_num_param_ptrs(void);
+/* expected element count of parameter tensor `ptr_id` (for validation by the caller) */
+int64_t objnerf_param_numel(int use_voxel, int ptr_id);
+/* host: fill the two gather maps (uint32 per packed float) that describe the permutation
+ * from the reference's (out,in) row-major nn.Linear tensors to the MFMA operand stream */
+int objnerf_pack_index(int use_voxel, uint32_t* h_blob_idx, uint32_t* h_aux_idx);
+/* device: blob[i] = param[idx>>24][idx & 0xFFFFFF] (0 where idx == 0xFFFFFFFF).
+ * h_param_ptrs: HOST array of objnerf_num_param_ptrs() DEVICE pointers. */
+int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx,
+                         const float* const* h_param_ptrs, float* blob, float* aux, void* stream);
+
+/* ---- stage entry points ---- */
+
+/* coarse depths: models/rendering.py:260-277.  z_steps = torch.linspace(0,1,S) (S floats, device).
+ * perturb_rand: (N,S) uniform [0,1) or NULL when perturb == 0. */
+int objnerf_sample_coarse(const float* rays, const float* z_steps, const float* perturb_rand,
+                          float perturb, int use_disp, int64_t n_rays, int S, float* z_vals,
+                          void* stream);
+
+/* Embedding.forward (embedding_helper.py:57-74): x (n, C) -> (n, C*(2F+1)) */
+int objnerf_pos_encode(const float* x, int64_t n, int C, int n_freqs, float* out, void* stream);
+
+/* EmbeddingVoxel.forward (embedding_helper.py:325-411): xyz (n,3) -> scene_ftr (n,271), obj_ftr (n,104) */
+int objnerf_voxel_embed(const objnerf_voxel_grid* grid, const float* xyz, int64_t n,
+                        float* scene_ftr, float* obj_ftr, void* stream);
+
+/* The fused encode + dual-branch MLP kernel.
+ * Replaces the chunk loop models/rendering.py:86-137 (embedding_xyz -> ObjectNeRF.forward ->
+ * ObjectNeRF.forward_instance) and render_tools/multi_rendering.py:30-93.
+ *
+ * Two input forms:
+ *   fused (emb_xyz == NULL): points are rays_o + rays_d * z_vals[n, s] (rendering.py:279),
+ *     embedded on the fly (voxel grid when use_voxel, else Embedding(3,10)); directions are
+ *     embedded per ray; object codes are codes + ray * code_stride (code_stride 0 = one code).
+ *   memory (emb_xyz != NULL): pre-embedded per-point inputs exactly as ObjectNeRF.forward /
+ *     forward_instance receive them (nerf_model.py:97-152): emb_xyz (P,in_xyz), emb_dir (P,27),
+ *     obj_voxel (P,104; voxel mode), obj_code (P,64).
+ * Outputs (any may be NULL when its branch is off): sigma (P), rgb (P,3), inst_sigma (P),
+ * inst_rgb (P,3); P = n_rays * S (fused) or n_points (memory). */
+typedef struct {
+  int32_t use_voxel;
+  int32_t do_scene;          /* evaluate ObjectNeRF.forward */
+  int32_t do_object;         /* evaluate ObjectNeRF.forward_instance */
+  const float* blob;         /* objnerf_blob_floats() */
+  const float* aux;          /* objnerf_aux_floats() */
+  /* fused form */
+  const float* rays;         /* (n_rays, 8) */
+  const float* z_vals;       /* (n_rays, S) */
+  int64_t n_rays;
+  int32_t S;
+  const float* codes;        /* embedding_instance */
+  int64_t code_stride;       /* floats between consecutive rays' codes (64) or 0 */
+  objnerf_voxel_grid grid;
+  /* memory form */
+  const float* emb_xyz;
+  const float* emb_dir;
+  const float* obj_voxel;
+  const float* obj_code;
+  int64_t n_points;
+  /* outputs */
+  float* sigma;
+  float* rgb;
+  float* inst_sigma;
+  float* inst_rgb;
+} objnerf_mlp_args;
+int objnerf_mlp_eval(const objnerf_mlp_args* args, void* stream);
+
+/* scene + instance alpha compositing: models/rendering.py:139-229.
+ * noise / noise_inst: (N,S) N(0,1) draws already multiplied by nothing (kernel multiplies by
+ * noise_std) or NULL when noise_std == 0.  pass_through_mask: (N) uint8 or NULL. */
+typedef struct {
+  int64_t n_rays;
+  int32_t S;
+  const float* z_vals;       /* (N,S) */
+  const float* sigma;        /* (N,S) */
+  const float* rgb;          /* (N,S,3) */
+  const float* inst_sigma;   /* NULL when forward_instance is off */
+  const float* inst_rgb;
+  const float* noise;
+  const float* noise_inst;
+  float noise_std;
+  int32_t white_back;
+  int32_t use_zero_as_last_delta;
+  int32_t occlusion;         /* (not is_eval) and frustum_bound_th > 0 */
+  float frustum_bound_th;
+  const uint8_t* pass_through_mask;
+  int32_t rays_in_bbox;      /* weights_out := instance weights (rendering.py:228-229) */
+  /* outputs */
+  float* weights;            /* (N,S) */
+  float* opacity;            /* (N) */
+  float* rgb_map;            /* (N,3) */
+  float* depth;              /* (N) */
+  float* rgb_inst;           /* (N,3) */
+  float* depth_inst;         /* (N) */
+  float* opacity_inst;       /* (N) */
+} objnerf_composite_args;
+int objnerf_composite(const objnerf_composite_args* args, void* stream);
+
+/* sample_pdf + sort(cat) : models/rendering.py:11-61 and 302-313.
+ * weights: (N,S) coarse weights (the kernel uses weights[:,1:-1] and z_mid of z_coarse);
+ * u: (I) = torch.linspace(0,1,I) when det (u_stride 0) or (N,I) uniform draws (u_stride I).
+ * z_samples (N,I) optional output of sample_pdf alone; z_fine (N,S+I) ascending. */
+int objnerf_sample_pdf_merge(const float* z_coarse, const float* weights, const float* u,
+                             int64_t u_stride, int64_t n_rays, int S, int I, float eps,
+                             float* z_samples, float* z_fine, void* stream);
+
+/* standalone sample_pdf (rendering.py:11-61): bins (N,nb), weights (N,nb-1) -> (N,I) */
+int objnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_stride,
+                       int64_t n_rays, int nb, int I, float eps, float* samples, void* stream);
+
+/* ---- multi-object path: render_tools/multi_rendering.py ---- */
+
+/* Oriented boxes (utils/bbox_utils.py::BBoxRayHelper): OBJNERF_BOX_DOUBLES float64 per box, device array:
+ *   [0] scale_factor, [1..9] pose_avg R (row-major), [10..12] pose_avg t, [13..21] axis_align_mat R,
+ *   [22..24] axis_align_mat t, [25..27] bbox min, [28..30] bbox max (after the caller applied
+ *   bbox_enlarge, bbox_utils.py:171-181).  The transform runs in float64 like the numpy code it
+ *   replaces (bbox_utils.py:119-130), the comparison in fp32 like the torch code (169-186). */
+#define OBJNERF_BOX_DOUBLES 31
+/* sigma[n, s] = -1e5 where z_vals[n, S-1] == 0 (multi_rendering.py:40,83,92) and, when n_boxes > 0,
+ * where the sample point rays_o + rays_d * z lies inside any box (multi_rendering.py:239-241). */
+int objnerf_mask_sigma(float* sigma, const float* rays, const float* z_vals, int64_t n_rays, int S,
+                       const double* boxes, int n_boxes, void* stream);
+/* check_in_any_boxes (bbox_utils.py:189-207) on explicit points: xyz (n,3) -> inside (n) uint8 */
+int objnerf_points_in_boxes(const float* xyz, int64_t n, const double* boxes, int n_boxes,
+                            uint8_t* inside, void* stream);
+
+/* volume_rendering_multi (multi_rendering.py:96-157): K ray sets of S samples each, given as
+ * arrays of K device pointers (host arrays).  Joint stable ascending sort by z, last delta 0.
+ * Outputs: z_sorted (N,K*S), weights (N,K*S), obj_ids (N,K*S) float (index into the K sets),
+ * opacity (N), rgb_map (N,3), depth (N); own_weights: optional K host pointers to (N,S) buffers
+ * receiving each set's weights in its own sample order (multi_rendering.py:269-271). */
+typedef struct {
+  int64_t n_rays;
+  int32_t K;
+  int32_t S;
+  const float* const* h_z;      /* K x (N,S) */
+  const float* const* h_sigma;  /* K x (N,S) */
+  const float* const* h_rgb;    /* K x (N,S,3) */
+  const float* noise;           /* (N,K*S) or NULL */
+  float noise_std;
+  int32_t white_back;
+  float* z_sorted;
+  float* weights;
+  float* obj_ids;               /* may be NULL */
+  float* opacity;
+  float* rgb_map;
+  float* depth;
+  float* const* h_own_weights;  /* may be NULL */
+} objnerf_composite_multi_args;
+int objnerf_composite_multi(const objnerf_composite_multi_args* args, void* stream);
+
+/* ---- whole render_rays (models/rendering.py:233-337) in one enqueue ---- */
+typedef struct {
+  int32_t use_voxel;
+  int32_t N_samples;
+  int32_t N_importance;
+  int32_t use_disp;
+  float perturb;
+  float noise_std;
+  int32_t white_back;
+  int32_t forward_instance;
+  int32_t is_eval;
+  int32_t use_zero_as_last_delta;
+  float frustum_bound_th;
+  int32_t rays_in_bbox;
+} objnerf_render_cfg;
+
+typedef struct {
+  /* (N,S_typ) */ float* weights; float* z_vals;
+  /* (N) */ float* opacity; float* depth; float* depth_instance; float* opacity_instance;
+  /* (N,3) */ float* rgb; float* rgb_instance;
+} objnerf_render_out;
+
+typedef struct {
+  const float* rays;               /* (N,8) */
+  int64_t n_rays;
+  const float* codes;              /* embedding_instance (N,64) (or one code with stride 0) */
+  int64_t code_stride;
+  const uint8_t* pass_through_mask;/* (N) or NULL */
+  const float* blob_coarse; const float* aux_coarse;
+  const float* blob_fine; const float* aux_fine;      /* NULL when N_importance == 0 */
+  objnerf_voxel_grid grid;
+  const float* z_steps;            /* linspace(0,1,N_samples) */
+  const float* u_det;              /* linspace(0,1,N_importance) (det) */
+  /* random inputs, only read when perturb > 0 / noise_std > 0 (caller draws them):
+   * perturb_rand (N,S), u_rand (N,I), noise[4] = coarse scene, coarse inst, fine scene, fine inst */
+  const float* perturb_rand; const float* u_rand; const float* noise[4];
+  void* workspace;                 /* objnerf_render_workspace_bytes() */
+} objnerf_render_in;
+
+int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_rays);
+int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* in,
+                        const objnerf_render_out* coarse, const objnerf_render_out* fine,
+                        void* stream);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the MLP kernel on `stream` ---- */
+/* When enabled, objnerf_mlp_eval brackets its launch with hipEvents; objnerf_timing_read
+ * synchronises those events and returns {launch count, total ms} since the last reset. */
+int objnerf_timing_enable(int on);
+int objnerf_timing_read(int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBJNERF_HIP_H */

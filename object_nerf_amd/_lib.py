@@ -1,0 +1,177 @@
+"""ctypes binding of libobjnerf_hip.so (include/objnerf_hip.h).
+
+The library is the product: there is NO CPU / PyTorch fallback.  If the shared object is
+missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libobjnerf_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_u8_p = C.POINTER(C.c_uint8)
+c_i32_p = C.POINTER(C.c_int32)
+c_u32_p = C.POINTER(C.c_uint32)
+c_f64_p = C.POINTER(C.c_double)
+
+BOX_DOUBLES = 31
+
+
+class VoxelGrid(C.Structure):
+    _fields_ = [
+        ("idx_map", C.c_void_p),
+        ("table", C.c_void_p),
+        ("shape", C.c_int32 * 3),
+        ("offset", C.c_float * 3),
+        ("voxel_size", C.c_float),
+        ("n_rows", C.c_int32),
+    ]
+
+
+class MlpArgs(C.Structure):
+    _fields_ = [
+        ("use_voxel", C.c_int32), ("do_scene", C.c_int32), ("do_object", C.c_int32),
+        ("blob", C.c_void_p), ("aux", C.c_void_p),
+        ("rays", C.c_void_p), ("z_vals", C.c_void_p), ("n_rays", C.c_int64), ("S", C.c_int32),
+        ("codes", C.c_void_p), ("code_stride", C.c_int64),
+        ("grid", VoxelGrid),
+        ("emb_xyz", C.c_void_p), ("emb_dir", C.c_void_p), ("obj_voxel", C.c_void_p), ("obj_code", C.c_void_p),
+        ("n_points", C.c_int64),
+        ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
+    ]
+
+
+class CompositeArgs(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_int64), ("S", C.c_int32),
+        ("z_vals", C.c_void_p), ("sigma", C.c_void_p), ("rgb", C.c_void_p),
+        ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
+        ("noise", C.c_void_p), ("noise_inst", C.c_void_p), ("noise_std", C.c_float),
+        ("white_back", C.c_int32), ("use_zero_as_last_delta", C.c_int32), ("occlusion", C.c_int32),
+        ("frustum_bound_th", C.c_float), ("pass_through_mask", C.c_void_p), ("rays_in_bbox", C.c_int32),
+        ("weights", C.c_void_p), ("opacity", C.c_void_p), ("rgb_map", C.c_void_p), ("depth", C.c_void_p),
+        ("rgb_inst", C.c_void_p), ("depth_inst", C.c_void_p), ("opacity_inst", C.c_void_p),
+    ]
+
+
+class CompositeMultiArgs(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_int64), ("K", C.c_int32), ("S", C.c_int32),
+        ("h_z", C.POINTER(C.c_void_p)), ("h_sigma", C.POINTER(C.c_void_p)), ("h_rgb", C.POINTER(C.c_void_p)),
+        ("noise", C.c_void_p), ("noise_std", C.c_float), ("white_back", C.c_int32),
+        ("z_sorted", C.c_void_p), ("weights", C.c_void_p), ("obj_ids", C.c_void_p),
+        ("opacity", C.c_void_p), ("rgb_map", C.c_void_p), ("depth", C.c_void_p),
+        ("h_own_weights", C.POINTER(C.c_void_p)),
+    ]
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [
+        ("use_voxel", C.c_int32), ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("use_disp", C.c_int32),
+        ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32),
+        ("forward_instance", C.c_int32), ("is_eval", C.c_int32), ("use_zero_as_last_delta", C.c_int32),
+        ("frustum_bound_th", C.c_float), ("rays_in_bbox", C.c_int32),
+    ]
+
+
+class RenderOut(C.Structure):
+    _fields_ = [
+        ("weights", C.c_void_p), ("z_vals", C.c_void_p),
+        ("opacity", C.c_void_p), ("depth", C.c_void_p), ("depth_instance", C.c_void_p),
+        ("opacity_instance", C.c_void_p), ("rgb", C.c_void_p), ("rgb_instance", C.c_void_p),
+    ]
+
+
+class RenderIn(C.Structure):
+    _fields_ = [
+        ("rays", C.c_void_p), ("n_rays", C.c_int64), ("codes", C.c_void_p), ("code_stride", C.c_int64),
+        ("pass_through_mask", C.c_void_p),
+        ("blob_coarse", C.c_void_p), ("aux_coarse", C.c_void_p), ("blob_fine", C.c_void_p), ("aux_fine", C.c_void_p),
+        ("grid", VoxelGrid),
+        ("z_steps", C.c_void_p), ("u_det", C.c_void_p),
+        ("perturb_rand", C.c_void_p), ("u_rand", C.c_void_p), ("noise", C.c_void_p * 4),
+        ("workspace", C.c_void_p),
+    ]
+
+
+# every symbol include/objnerf_hip.h declares: (restype, argtypes)
+_VP = C.c_void_p
+SIGNATURES = {
+    "objnerf_abi_version": (C.c_int, []),
+    "objnerf_last_error": (C.c_char_p, []),
+    "objnerf_blob_floats": (C.c_int64, [C.c_int]),
+    "objnerf_aux_floats": (C.c_int64, []),
+    "objnerf_num_param_ptrs": (C.c_int, []),
+    "objnerf_param_numel": (C.c_int64, [C.c_int, C.c_int]),
+    "objnerf_pack_index": (C.c_int, [C.c_int, _VP, _VP]),
+    "objnerf_pack_weights": (C.c_int, [C.c_int, _VP, _VP, C.POINTER(_VP), _VP, _VP, _VP]),
+    "objnerf_sample_coarse": (C.c_int, [_VP, _VP, _VP, C.c_float, C.c_int, C.c_int64, C.c_int, _VP, _VP]),
+    "objnerf_pos_encode": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
+    "objnerf_voxel_embed": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP]),
+    "objnerf_mlp_eval": (C.c_int, [C.POINTER(MlpArgs), _VP]),
+    "objnerf_composite": (C.c_int, [C.POINTER(CompositeArgs), _VP]),
+    "objnerf_sample_pdf_merge": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP]),
+    "objnerf_sample_pdf": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP]),
+    "objnerf_mask_sigma": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_int, _VP]),
+    "objnerf_points_in_boxes": (C.c_int, [_VP, C.c_int64, _VP, C.c_int, _VP, _VP]),
+    "objnerf_composite_multi": (C.c_int, [C.POINTER(CompositeMultiArgs), _VP]),
+    "objnerf_render_workspace_bytes": (C.c_int64, [C.POINTER(RenderCfg), C.c_int64]),
+    "objnerf_render_rays": (C.c_int, [C.POINTER(RenderCfg), C.POINTER(RenderIn), C.POINTER(RenderOut), C.POINTER(RenderOut), _VP]),
+    "objnerf_timing_enable": (C.c_int, [C.c_int]),
+    "objnerf_timing_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "object_nerf_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C object_nerf_amd/csrc`. There is no fallback path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the ABI header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if l.objnerf_abi_version() != 1:
+            raise RuntimeError("object_nerf_amd: ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().objnerf_last_error().decode("utf-8", "replace")
+        raise RuntimeError("objnerf_hip %s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "objnerf_hip needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "object_nerf_amd: %s must live on the GPU (got %s). The HIP path has no CPU fallback." % (name, t.device))
+
+
+def as_f32(t):
+    """contiguous fp32 view/copy of t"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

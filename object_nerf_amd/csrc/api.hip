@@ -1,0 +1,257 @@
+// api.hip -- host side of the C ABI: error state, the weight-packing index maps, the MLP
+// dispatcher, the whole-render_rays driver and the measurement hooks.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+#include "layout.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return -2;
+}
+
+// ---- reference parameter shapes (models/nerf_model.py:41-58, 77-95) --------------------------
+struct ParamShape { int out, in; };
+static ParamShape param_shape(bool voxel, int p) {
+  switch (p) {
+    case P_S1: return {kW, in_xyz(voxel)};
+    case P_S5: return {kW, in_xyz(voxel) + kW};
+    case P_S2: case P_S3: case P_S4: case P_S6: case P_S7: case P_S8: case P_SF: return {kW, kW};
+    case P_SD: return {kW / 2, kW + kDirC};
+    case P_SSIG: return {1, kW};
+    case P_SRGB: return {3, kW / 2};
+    case P_O1: return {kIW, in_obj(voxel)};
+    case P_O3: return {kIW, in_obj(voxel) + kIW};
+    case P_O2: case P_O4: case P_OF: return {kIW, kIW};
+    case P_OD: return {kIW / 2, kIW + kDirC};
+    case P_OSIG: return {1, kIW};
+    case P_ORGB: return {3, kIW / 2};
+  }
+  return {0, 0};
+}
+static int layer_param(int l) {
+  static const int map[L_COUNT] = {P_S1, P_S2, P_S3, P_S4, P_S5, P_S6, P_S7, P_S8, P_SF, P_SD,
+                                   P_O1, P_O2, P_O3, P_O4, P_OF, P_OD};
+  return map[l];
+}
+static inline uint32_t enc(int ptr_id, long off) { return ((uint32_t)ptr_id << 24) | (uint32_t)off; }
+
+// ---- measurement hooks ------------------------------------------------------------------------
+static std::mutex g_tmu;
+static bool g_timing = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
+
+}  // namespace objnerf
+
+using namespace objnerf;
+
+extern "C" {
+
+int objnerf_abi_version(void) { return OBJNERF_ABI_VERSION; }
+const char* objnerf_last_error(void) { return g_err; }
+
+int64_t objnerf_blob_floats(int use_voxel) { return (int64_t)total_chunks(use_voxel != 0) * kChunkFloats; }
+int64_t objnerf_aux_floats(void) { return kAuxFloats; }
+int objnerf_num_param_ptrs(void) { return kNumParamPtrs; }
+int64_t objnerf_param_numel(int use_voxel, int ptr_id) {
+  if (ptr_id < 0 || ptr_id >= kNumParamPtrs) return -1;
+  const ParamShape s = param_shape(use_voxel != 0, ptr_id >> 1);
+  return (ptr_id & 1) ? s.out : (int64_t)s.out * s.in;
+}
+
+int objnerf_pack_index(int use_voxel, uint32_t* blob_idx, uint32_t* aux_idx) {
+  if (!blob_idx || !aux_idx) return set_error(-1, "pack_index: null output");
+  const bool vox = use_voxel != 0;
+  const long nblob = objnerf_blob_floats(use_voxel);
+  for (long i = 0; i < nblob; ++i) blob_idx[i] = kPackZero;
+  for (int i = 0; i < kAuxFloats; ++i) aux_idx[i] = kPackZero;
+
+  for (int l = 0; l < L_COUNT; ++l) {
+    const int nt = layer_nt(l), kg = kChunkTiles / nt, ks_n = layer_ks(vox, l);
+    const int p = layer_param(l);
+    const ParamShape sh = param_shape(vox, p);
+    if (sh.out != layer_out(l) || sh.in != layer_in(vox, l)) return set_error(-3, "pack_index: layout self-check failed");
+    const long base = (long)layer_chunk_start(vox, l) * kChunkFloats;
+    for (int ks = 0; ks < ks_n; ++ks) {
+      const int chunk = ks / kg, kl = ks % kg, g4 = kl / 4, j = kl % 4;
+      for (int m = 0; m < nt; ++m)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = 32 * m + (lane & 31);
+          const int col = layer_kcol(vox, l, ks, lane >> 5);
+          if (row >= sh.out || col < 0) continue;
+          if (col >= sh.in) return set_error(-3, "pack_index: column out of range");
+          const long o = base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j;
+          blob_idx[o] = enc(2 * p, (long)row * sh.in + col);
+        }
+    }
+    // bias: [m][half][16]
+    for (int m = 0; m < nt; ++m)
+      for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * m + hid_feat(r, h);
+          if (row < sh.out) aux_idx[aux_bias_off(l) + (m * 2 + h) * 16 + r] = enc(2 * p + 1, row);
+        }
+  }
+  // heads: [t][half][16] per output row, then the biases
+  struct Head { int off, param, nt, rows; };
+  const Head heads[4] = {{kAuxSSig, P_SSIG, 8, 1}, {kAuxSRgb, P_SRGB, 4, 3}, {kAuxOSig, P_OSIG, 4, 1}, {kAuxORgb, P_ORGB, 2, 3}};
+  for (const Head& hd : heads) {
+    const int in = hd.nt * 32;
+    for (int c = 0; c < hd.rows; ++c)
+      for (int t = 0; t < hd.nt; ++t)
+        for (int h = 0; h < 2; ++h)
+          for (int r = 0; r < 16; ++r)
+            aux_idx[hd.off + c * in + (t * 2 + h) * 16 + r] = enc(2 * hd.param, (long)c * in + 32 * t + hid_feat(r, h));
+    for (int c = 0; c < hd.rows; ++c) aux_idx[hd.off + hd.rows * in + c] = enc(2 * hd.param + 1, c);
+  }
+  return 0;
+}
+
+int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
+  if (!a || !a->blob || !a->aux) return set_error(-1, "mlp_eval: null weights");
+  if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
+  if (a->do_scene && !a->sigma) return set_error(-1, "mlp_eval: scene branch needs a sigma output");
+  if (a->do_object && !a->inst_sigma) return set_error(-1, "mlp_eval: object branch needs an inst_sigma output");
+  const bool fused = a->emb_xyz == nullptr;
+  long P;
+  if (fused) {
+    if (!a->rays || !a->z_vals || a->S < 1 || a->n_rays < 0) return set_error(-1, "mlp_eval: bad fused inputs");
+    if (a->do_object && !a->codes) return set_error(-1, "mlp_eval: object branch needs codes");
+    if (a->use_voxel && (!a->grid.idx_map || !a->grid.table || a->grid.n_rows < 1))
+      return set_error(-1, "mlp_eval: voxel mode needs a voxel grid");
+    P = (long)a->n_rays * a->S;
+  } else {
+    if (!a->emb_dir || a->n_points < 0) return set_error(-1, "mlp_eval: bad memory-form inputs");
+    if (a->do_object && (!a->obj_code || (a->use_voxel && !a->obj_voxel)))
+      return set_error(-1, "mlp_eval: forward_instance needs obj_code (and obj_voxel in voxel mode)");
+    P = a->n_points;
+  }
+  if (P == 0) return 0;
+  const long ntiles = (P + 127) / 128;
+  int dev = 0, cus = 256;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);   // persistent: 1 workgroup per CU
+  hipStream_t s = (hipStream_t)stream;
+
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool timing;
+  { std::lock_guard<std::mutex> lk(g_tmu); timing = g_timing; }
+  if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
+  const int rc = fused ? launch_mlp_fused(*a, ntiles, grid, s) : launch_mlp_memory(*a, ntiles, grid, s);
+  if (timing) {
+    hipEventRecord(e1, s);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_events.emplace_back(e0, e1);
+  }
+  return rc;
+}
+
+int objnerf_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_tmu);
+  g_timing = on != 0;
+  for (auto& ev : g_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  g_events.clear();
+  return 0;
+}
+int objnerf_timing_read(int64_t* launches, double* total_ms) {
+  std::lock_guard<std::mutex> lk(g_tmu);
+  double tot = 0;
+  for (auto& ev : g_events) {
+    hipEventSynchronize(ev.second);
+    float ms = 0;
+    hipEventElapsedTime(&ms, ev.first, ev.second);
+    tot += ms;
+    hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+  }
+  if (launches) *launches = (int64_t)g_events.size();
+  if (total_ms) *total_ms = tot;
+  g_events.clear();
+  return 0;
+}
+
+// ---- whole render_rays (models/rendering.py:233-337) --------------------------------------------
+// workspace: sigma (N*Smax) | rgb (3*N*Smax) | inst_sigma (N*Smax) | inst_rgb (3*N*Smax)
+int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_rays) {
+  if (!cfg || n_rays < 0) return -1;
+  const int64_t smax = cfg->N_samples + (cfg->N_importance > 0 ? cfg->N_importance : 0);
+  return (int64_t)sizeof(float) * n_rays * smax * 8 + 256;
+}
+
+static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* out,
+                       const float* blob, const float* aux, int S, const float* noise, const float* noise_inst,
+                       void* stream) {
+  const int64_t N = in->n_rays;
+  float* ws = (float*)in->workspace;
+  float* sigma = ws;
+  float* rgb = sigma + N * S;
+  float* isig = rgb + 3 * N * S;
+  float* irgb = isig + N * S;
+
+  objnerf_mlp_args m;
+  memset(&m, 0, sizeof(m));
+  m.use_voxel = cfg->use_voxel; m.do_scene = 1; m.do_object = cfg->forward_instance;
+  m.blob = blob; m.aux = aux;
+  m.rays = in->rays; m.z_vals = out->z_vals; m.n_rays = N; m.S = S;
+  m.codes = in->codes; m.code_stride = in->code_stride; m.grid = in->grid;
+  m.sigma = sigma; m.rgb = rgb;
+  m.inst_sigma = cfg->forward_instance ? isig : nullptr;
+  m.inst_rgb = cfg->forward_instance ? irgb : nullptr;
+  int rc = objnerf_mlp_eval(&m, stream);
+  if (rc) return rc;
+
+  objnerf_composite_args c;
+  memset(&c, 0, sizeof(c));
+  c.n_rays = N; c.S = S; c.z_vals = out->z_vals; c.sigma = sigma; c.rgb = rgb;
+  c.inst_sigma = m.inst_sigma; c.inst_rgb = m.inst_rgb;
+  c.noise = noise; c.noise_inst = noise_inst; c.noise_std = cfg->noise_std;
+  c.white_back = cfg->white_back; c.use_zero_as_last_delta = cfg->use_zero_as_last_delta;
+  c.occlusion = (!cfg->is_eval && cfg->frustum_bound_th > 0.f) ? 1 : 0;     // rendering.py:192
+  c.frustum_bound_th = cfg->frustum_bound_th;
+  c.pass_through_mask = in->pass_through_mask;
+  c.rays_in_bbox = cfg->rays_in_bbox && cfg->forward_instance;
+  c.weights = out->weights; c.opacity = out->opacity; c.rgb_map = out->rgb; c.depth = out->depth;
+  c.rgb_inst = out->rgb_instance; c.depth_inst = out->depth_instance; c.opacity_inst = out->opacity_instance;
+  return objnerf_composite(&c, stream);
+}
+
+int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* coarse,
+                        const objnerf_render_out* fine, void* stream) {
+  if (!cfg || !in || !coarse) return set_error(-1, "render_rays: null argument");
+  if (!in->rays || !in->workspace || !in->blob_coarse || !in->aux_coarse || !in->z_steps)
+    return set_error(-1, "render_rays: missing input");
+  if (!in->codes) return set_error(-1, "render_rays: embedding_instance is mandatory (rendering.py:94)");
+  if (cfg->N_importance > 0 && (!fine || !in->blob_fine || !in->aux_fine))
+    return set_error(-1, "render_rays: N_importance > 0 needs the fine model and outputs");
+  if (cfg->N_importance > 0 && cfg->perturb == 0.f && !in->u_det) return set_error(-1, "render_rays: missing u_det");
+  if (cfg->N_importance > 0 && cfg->perturb != 0.f && !in->u_rand) return set_error(-1, "render_rays: missing u_rand");
+  if (in->n_rays == 0) return 0;
+  const int S = cfg->N_samples, I = cfg->N_importance;
+
+  int rc = objnerf_sample_coarse(in->rays, in->z_steps, in->perturb_rand, cfg->perturb, cfg->use_disp, in->n_rays, S,
+                                 coarse->z_vals, stream);
+  if (rc) return rc;
+  rc = render_pass(cfg, in, coarse, in->blob_coarse, in->aux_coarse, S, in->noise[0], in->noise[1], stream);
+  if (rc || I <= 0) return rc;
+  // sample_pdf(z_mid, weights_coarse[:,1:-1], I, det=(perturb==0)) + sort(cat) (rendering.py:301-313)
+  const bool det = cfg->perturb == 0.f;
+  rc = objnerf_sample_pdf_merge(coarse->z_vals, coarse->weights, det ? in->u_det : in->u_rand, det ? 0 : I,
+                                in->n_rays, S, I, 1e-5f, nullptr, fine->z_vals, stream);
+  if (rc) return rc;
+  return render_pass(cfg, in, fine, in->blob_fine, in->aux_fine, S + I, in->noise[2], in->noise[3], stream);
+}
+
+}  // extern "C"

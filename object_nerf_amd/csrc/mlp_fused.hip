@@ -1,0 +1,26 @@
+// mlp_fused.hip -- instantiations of the fused (embed-in-registers) MLP kernel.
+#include "mlp_kernel.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+template <bool VOXEL, bool SC, bool OB>
+static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles);
+}
+
+int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+  const bool sc = a.do_scene != 0, ob = a.do_object != 0;
+  if (a.use_voxel) {
+    if (sc && ob) launch<true, true, true>(a, ntiles, grid, s);
+    else if (sc) launch<true, true, false>(a, ntiles, grid, s);
+    else launch<true, false, true>(a, ntiles, grid, s);
+  } else {
+    if (sc && ob) launch<false, true, true>(a, ntiles, grid, s);
+    else if (sc) launch<false, true, false>(a, ntiles, grid, s);
+    else launch<false, false, true>(a, ntiles, grid, s);
+  }
+  return check_launch("mlp_eval(fused)");
+}
+
+}  // namespace objnerf

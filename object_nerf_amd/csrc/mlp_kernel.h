@@ -1,0 +1,496 @@
+// mlp_kernel.h -- fused encode + dual-branch MLP for gfx950 (MI355X).
+//
+// Replaces the reference's MLP chunk loop (models/rendering.py:106-130: EmbeddingVoxel.forward ->
+// ObjectNeRF.forward -> ObjectNeRF.forward_instance, 20 GEMMs + ~700 elementwise launches per
+// chunk) with ONE persistent kernel:
+//
+//   * workgroup = 4 waves (one per SIMD, up to 512 VGPR+AGPR each), 1 workgroup per CU;
+//     each wave owns 32 consecutive sample points, the workgroup 128;
+//   * activations never leave registers: layer l's 32x32 accumulator tiles (after bias +
+//     LeakyReLU) ARE the B operands of layer l+1 (layout.h explains the permutation);
+//   * weights are a linear stream of pre-permuted A tiles; 32 KiB chunks are DMA'd
+//     global->LDS (global_load_lds_dwordx4) one chunk ahead into a 2-slot ring shared by the
+//     4 waves, and read back as ds_read_b128 (4 k-steps of one out tile per instruction);
+//   * positional / voxel embeddings are generated in registers right where the MFMA needs
+//     them (never materialised: the reference writes 375 floats per sample to HBM);
+//   * the 1-row sigma heads and 3-row rgb heads run on the VALU (an MFMA tile would be
+//     31/32 empty), combined across the two lane halves with one DPP/permute.
+//
+// Roofline: MFMA-bound. 13,876 v_mfma_f32_32x32x2_f32 per 32 points (both branches, voxel
+// mode) = 1,776,128 algorithmic FLOP per point; fp32 MFMA peak 157.3 TFLOP/s.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <utility>
+#include <type_traits>
+#include "layout.h"
+#include "device_math.h"
+#include "../../include/objnerf_hip.h"
+
+namespace objnerf {
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight stream: 2-slot LDS ring, one chunk (32 KiB) prefetched ahead, one barrier per chunk
+// ---------------------------------------------------------------------------------------------
+struct WeightStream {
+  const char* win;     // global base of the stream window (first chunk of this mode)
+  int nchunks;         // chunks in the window (wraps around: every pass replays it)
+  int next;            // window index of the next chunk to DMA
+  int cur;             // ring slot holding the chunk being consumed
+  lds_char* ring;      // 2 * kChunkBytes
+  lds_char* rd;        // per-lane read base of the current slot (ring + cur*chunk + lane*16)
+  int tid;
+
+  __device__ __forceinline__ void issue(int slot) {
+    // `next` is statically predictable inside one pass; hide it from the optimiser or LICM hoists
+    // one 64-bit source address per (chunk, piece) out of the tile loop (hundreds of VGPRs, spills)
+    int n = next;
+    asm volatile("" : "+s"(n));
+    const char* src = win + (size_t)n * kChunkBytes + tid * 16;
+    // wave-uniform LDS base; the DMA adds lane*16 itself
+    lds_char* dst = ring + slot * kChunkBytes + (tid >> 6) * 1024;
+#pragma unroll
+    for (int i = 0; i < kChunkBytes / 4096; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + i * 4096),
+          (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    }
+    next = (next + 1 == nchunks) ? 0 : next + 1;
+  }
+  __device__ __forceinline__ void init(const char* w, int n, lds_char* r, int t) {
+    win = w; nchunks = n; next = 0; ring = r; tid = t; cur = 1;
+    issue(0);
+  }
+  // called right before the first A read of a chunk
+  __device__ __forceinline__ void next_chunk() {
+    __syncthreads();   // all DMA of the chunk landed (vmcnt(0) is part of the barrier) and every
+                       // wave is done reading the slot we are about to overwrite
+    cur ^= 1;
+    issue(cur ^ 1);
+    rd = ring + cur * kChunkBytes + (tid & 63) * 16;
+  }
+};
+
+__device__ __forceinline__ f32x4 lds_read16(const lds_char* p) {
+  return *(const __attribute__((address_space(3))) f32x4*)p;
+}
+
+// acc[m] += W_tile(m, ks) * B(ks) for every k-step of one layer.  Src::get<ks>() yields this
+// lane's B operand (feature (ks, lane>>5) of point lane&31).
+template <int NT>
+struct ATiles { f32x4 v[NT]; };
+
+template <int NT, int G>
+__device__ __forceinline__ void load_group(ATiles<NT>& a, WeightStream& st) {
+  constexpr int KG = kChunkTiles / NT;
+  constexpr int ks0 = G * 4;
+  if constexpr (ks0 % KG == 0) st.next_chunk();
+  constexpr int g4 = (ks0 % KG) / 4;
+#pragma unroll
+  for (int m = 0; m < NT; ++m) a.v[m] = lds_read16(st.rd + (g4 * NT + m) * 1024);
+}
+
+// Software pipeline, one group (4 k-steps x NT out tiles) per stage: the A tiles of group g+1 are
+// read from LDS (after the chunk barrier when g+1 opens a new chunk) before the MFMAs of group g
+// issue.  sched_barrier(0) between stages keeps the compiler from hoisting the embedding
+// arithmetic of later groups (it would otherwise keep hundreds of sin/cos values live and spill).
+template <int NT, int KS, class Src>
+__device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, Src& src) {
+  constexpr int NG4 = (KS + 3) / 4;
+  ATiles<NT> abuf[2];
+  load_group<NT, 0>(abuf[0], st);
+  static_for<NG4>([&](auto G) __attribute__((always_inline)) {
+    constexpr int g = decltype(G)::value;
+    constexpr int ks0 = g * 4;
+    ATiles<NT>& a = abuf[g & 1];
+    if constexpr (g + 1 < NG4) load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
+    static_for<4>([&](auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      constexpr int ks = ks0 + j;
+      if constexpr (ks < KS) {
+        const float b = src.template get<ks>();
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[m][j], b, acc[m], 0, 0, 0);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[NT], const float* aux, int layer, int half) {
+  const float* b = aux + aux_bias_off(layer) + half * 16;
+#pragma unroll
+  for (int m = 0; m < NT; ++m) acc[m] = *(const f32x16*)(b + m * 32);
+}
+
+template <int NT, bool ACT>
+__device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT]) {
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[m][r] = ACT ? leaky(acc[m][r]) : acc[m][r];
+}
+
+// dot of this lane's NT*16 hidden features with a packed head row, summed over both halves
+template <int NT>
+__device__ __forceinline__ float head_dot(const f32x16 (&h)[NT], const float* w, int half) {
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    const f32x16 wv = *(const f32x16*)(w + (m * 2 + half) * 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fmaf(h[m][r], wv[r], s);
+  }
+  return s + __shfl_xor(s, 32);
+}
+
+// ---------------------------------------------------------------------------------------------
+// B-operand sources
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+struct HidSrc {
+  const f32x16 (&h)[NT];
+  template <int I>
+  __device__ __forceinline__ float get() { return h[I >> 4][I & 15]; }
+};
+
+// Fused source: embeds the point in registers.  VOXEL: voxel-grid mode (EmbeddingVoxel), else
+// plain Embedding(3,10).
+template <bool VOXEL>
+struct FusedSrc {
+  float vf[12];        // trilinear voxel features of this half: 8 scene ch (half*8+i), 4 object ch
+  float pos[3];        // sample position
+  float dir[3];        // ray direction
+  float fscale;        // 2^(5*half): xyz frequency split
+  float dscale;        // 2^(2*half): dir frequency split
+  const float* code;   // this ray's object code + half*32
+  int half;
+  float saved_cos;
+
+  // Makes the embedding inputs opaque to the optimiser.  Called before every layer that consumes
+  // the embedding: without it LLVM's GVN reuses the sin/cos values of the first consumer for the
+  // later ones (S1 -> S5 -> O1 -> O3), keeps 136..220 values live across whole layers and spills.
+  // Recomputing costs ~1 % of the MFMA time; spilling costs scratch traffic inside the MFMA loops.
+  __device__ __forceinline__ void launder() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(vf[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(pos[i])); asm volatile("" : "+v"(dir[i])); }
+  }
+  // positional-encoding pair slots: even local index = sin, odd = cos of the same argument;
+  // slots are consumed in increasing order, so the cos rides along from the sin slot
+  __device__ __forceinline__ float pe_pair(float arg, int fn) {
+    if (fn == 0) { const SinCos sc = psincos(arg); saved_cos = sc.c; return sc.s; }
+    return saved_cos;
+  }
+  template <int I>
+  __device__ __forceinline__ float xyz_slot() {
+    if constexpr (I < 30) {
+      constexpr int p = I >> 1, coord = p / 5, kk = p % 5;
+      return pe_pair(pos[coord] * (float)(1 << kk) * fscale, I & 1);
+    } else if constexpr (I == 30) {
+      return half ? pos[2] : pos[0];
+    } else {
+      return half ? 0.f : pos[1];
+    }
+  }
+  template <int I, int BASE>
+  __device__ __forceinline__ float vox_slot() {
+    constexpr int fi = I / 13, j = I % 13;
+    if constexpr (j == 0) return vf[BASE + fi];
+    else {
+      constexpr int k = (j - 1) >> 1;
+      return pe_pair(vf[BASE + fi] * (float)(1 << k), (j - 1) & 1);
+    }
+  }
+  template <int I>
+  __device__ __forceinline__ float emb() {
+    if constexpr (VOXEL) {
+      if constexpr (I < kKsScnVox) return vox_slot<I, 0>();
+      else return xyz_slot<I - kKsScnVox>();
+    } else {
+      return xyz_slot<I>();
+    }
+  }
+  template <int I>
+  __device__ __forceinline__ float objin() {
+    constexpr int ne = ks_emb(VOXEL);
+    if constexpr (I < ne) return emb<I>();
+    else if constexpr (VOXEL && I < ne + kKsObjVox) return vox_slot<I - ne, 8>();
+    else return code[I - ne - (VOXEL ? kKsObjVox : 0)];
+  }
+  template <int I>
+  __device__ __forceinline__ float dirslot() {
+    if constexpr (I < 12) {
+      constexpr int p = I >> 1, coord = p % 3, kk = p / 3;
+      return pe_pair(dir[coord] * (float)(1 << kk) * dscale, I & 1);
+    } else if constexpr (I == 12) {
+      return half ? dir[2] : dir[0];
+    } else {
+      return half ? 0.f : dir[1];
+    }
+  }
+};
+
+// Memory source: pre-embedded rows exactly as ObjectNeRF.forward / forward_instance get them
+template <bool VOXEL>
+struct MemSrc {
+  const float* exyz;   // row of emb_xyz  (in_xyz)
+  const float* edir;   // row of emb_dir  (27)
+  const float* ovox;   // row of obj_voxel (104) or null
+  const float* ocode;  // row of obj_code (64)
+  int half;
+  __device__ __forceinline__ void launder() {}
+  __device__ __forceinline__ float pick(const float* row, int c0, int c1) {
+    const int c = half ? c1 : c0;
+    return c < 0 ? 0.f : row[c < 0 ? 0 : c];
+  }
+  template <int I>
+  __device__ __forceinline__ float emb() {
+    return pick(exyz, emb_slot_col(VOXEL, I, 0), emb_slot_col(VOXEL, I, 1));
+  }
+  template <int I>
+  __device__ __forceinline__ float objin() {
+    constexpr int ne = ks_emb(VOXEL);
+    if constexpr (I < ne) return emb<I>();
+    else if constexpr (VOXEL && I < ne + kKsObjVox) {
+      constexpr int ii = I - ne;
+      return pick(ovox, vox_slot_col(ii, 0, 4, kObjVoxC), vox_slot_col(ii, 1, 4, kObjVoxC));
+    } else {
+      constexpr int ii = I - ne - (VOXEL ? kKsObjVox : 0);
+      return ocode[half * 32 + ii];
+    }
+  }
+  template <int I>
+  __device__ __forceinline__ float dirslot() {
+    return pick(edir, dir_slot_col(I, 0), dir_slot_col(I, 1));
+  }
+};
+
+// adaptors: one layer's concatenated K list
+template <class S> struct EmbOnly { S& s; template <int I> __device__ __forceinline__ float get() { return s.template emb<I>(); } };
+template <class S> struct ObjInOnly { S& s; template <int I> __device__ __forceinline__ float get() { return s.template objin<I>(); } };
+template <class S, int NE, int NT> struct EmbThenHid {
+  S& s; const f32x16 (&h)[NT];
+  template <int I> __device__ __forceinline__ float get() {
+    if constexpr (I < NE) return s.template emb<I>(); else return h[(I - NE) >> 4][(I - NE) & 15];
+  }
+};
+template <class S, int NE, int NT> struct ObjInThenHid {
+  S& s; const f32x16 (&h)[NT];
+  template <int I> __device__ __forceinline__ float get() {
+    if constexpr (I < NE) return s.template objin<I>(); else return h[(I - NE) >> 4][(I - NE) & 15];
+  }
+};
+template <class S, int NH, int NT> struct HidThenDir {
+  S& s; const f32x16 (&h)[NT];
+  template <int I> __device__ __forceinline__ float get() {
+    if constexpr (I < NH) return h[I >> 4][I & 15]; else return s.template dirslot<I - NH>();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// voxel feature fetch: EmbeddingVoxel.compute_voxel_features_sparse (embedding_helper.py:354-411)
+// restricted to the 12 channels of this lane half.  Operation order mirrors the reference:
+// s = (xyz + offset) / voxel_size (IEEE divide), q = floor(s), p = s - q, corner weights as the
+// products (a*b)*c, sum over the 8 corners in itertools.product([0,1],repeat=3) order.
+// ---------------------------------------------------------------------------------------------
+struct VoxelCell {
+  float w[8];
+  int row[8];     // table row or -1
+};
+__device__ __forceinline__ VoxelCell voxel_cell(const objnerf_voxel_grid& g, float x, float y, float z) {
+  VoxelCell c;
+  const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
+  const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
+  const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
+  const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
+  const float u = sx - qx, v = sy - qy, w = sz - qz;
+  const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
+  c.w[0] = (lu * lv) * lw; c.w[1] = (lu * lv) * w; c.w[2] = (lu * v) * lw; c.w[3] = (lu * v) * w;
+  c.w[4] = (u * lv) * lw;  c.w[5] = (u * lv) * w;  c.w[6] = (u * v) * lw;  c.w[7] = (u * v) * w;
+  const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
+    const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
+    int r = -1;
+    if (ok) {
+      const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
+      r = g.idx_map[((size_t)ix * g.shape[1] + iy) * g.shape[2] + iz];
+      if (r >= g.n_rows) r = -1;
+    }
+    c.row[k] = r;
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ>
+__global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles) {
+  __shared__ __attribute__((aligned(16))) char ring_mem[2 * kChunkBytes];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int wave = tid >> 6;
+
+  constexpr int kStart = DO_SCENE ? 0 : scene_chunks(VOXEL);
+  constexpr int kEnd = DO_OBJ ? total_chunks(VOXEL) : scene_chunks(VOXEL);
+  WeightStream st;
+  st.init((const char*)a.blob + (size_t)kStart * kChunkBytes, kEnd - kStart,
+          (lds_char*)ring_mem, tid);
+
+  const long P = FUSED ? a.n_rays * (long)a.S : a.n_points;
+  const float* aux = a.aux;
+
+  using Src = std::conditional_t<FUSED, FusedSrc<VOXEL>, MemSrc<VOXEL>>;
+  constexpr int NE = ks_emb(VOXEL);
+  constexpr int NO = ks_objin(VOXEL);
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long p_raw = tile * 128 + wave * 32 + (lane & 31);
+    const bool valid = p_raw < P;
+    const long p = valid ? p_raw : P - 1;
+
+    Src src;
+    src.half = half;
+    if constexpr (FUSED) {
+      const long ray = p / a.S;
+      const float* r = a.rays + ray * 8;
+      const float zv = a.z_vals[p];
+      // xyz = rays_o + rays_d * z  (rendering.py:279): separately rounded mul and add
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        src.dir[c] = r[3 + c];
+        src.pos[c] = r[c] + src.dir[c] * zv;
+      }
+      src.fscale = half ? 32.f : 1.f;
+      src.dscale = half ? 4.f : 1.f;
+      src.code = DO_OBJ ? a.codes + ray * a.code_stride + half * 32 : nullptr;
+      if constexpr (VOXEL) {
+        const VoxelCell cell = voxel_cell(a.grid, src.pos[0], src.pos[1], src.pos[2]);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) src.vf[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int row = cell.row[k];
+          const float* t = a.grid.table + (size_t)(row < 0 ? 0 : row) * kVoxC;
+          f32x4 s0 = *(const f32x4*)(t + half * 8);
+          f32x4 s1 = *(const f32x4*)(t + half * 8 + 4);
+          f32x4 o0 = *(const f32x4*)(t + kScnVoxC + half * 4);
+          const float wk = cell.w[k];
+          // voxel_ftr[invalid] = 0 ; (voxel_ftr * weights).sum(0)   (embedding_helper.py:351,387-389)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float f0 = row < 0 ? 0.f : s0[i], f1 = row < 0 ? 0.f : s1[i], f2 = row < 0 ? 0.f : o0[i];
+            if (k == 0) { src.vf[i] = f0 * wk; src.vf[4 + i] = f1 * wk; src.vf[8 + i] = f2 * wk; }
+            else { src.vf[i] = src.vf[i] + f0 * wk; src.vf[4 + i] = src.vf[4 + i] + f1 * wk; src.vf[8 + i] = src.vf[8 + i] + f2 * wk; }
+          }
+        }
+      }
+    } else {
+      src.exyz = a.emb_xyz + p * in_xyz(VOXEL);
+      src.edir = a.emb_dir + p * kDirC;
+      src.ovox = (VOXEL && DO_OBJ) ? a.obj_voxel + p * kObjVoxPE : nullptr;
+      src.ocode = DO_OBJ ? a.obj_code + p * kCodeC : nullptr;
+    }
+
+    if constexpr (DO_SCENE) {
+      f32x16 acc[8], h[8];
+      // xyz_encoding_1
+      src.launder();
+      load_bias<8>(acc, aux, L_S1, half);
+      { EmbOnly<Src> s{src}; layer_mac<8, NE>(acc, st, s); }
+      finish<8, true>(acc, h);
+      // xyz_encoding_2..4
+#pragma unroll 1
+      for (int l = L_S2; l <= L_S4; ++l) {
+        load_bias<8>(acc, aux, l, half);
+        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+        finish<8, true>(acc, h);
+      }
+      // xyz_encoding_5 (skip: cat([emb, h]))
+      src.launder();
+      load_bias<8>(acc, aux, L_S5, half);
+      { EmbThenHid<Src, NE, 8> s{src, h}; layer_mac<8, NE + 128>(acc, st, s); }
+      finish<8, true>(acc, h);
+#pragma unroll 1
+      for (int l = L_S6; l <= L_S8; ++l) {
+        load_bias<8>(acc, aux, l, half);
+        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+        finish<8, true>(acc, h);
+      }
+      // sigma head (no activation, nerf_model.py:108)
+      const float sg = head_dot<8>(h, aux + kAuxSSig, half) + aux[kAuxSSig + 8 * 32];
+      // xyz_encoding_final (no activation)
+      load_bias<8>(acc, aux, L_SF, half);
+      { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+      finish<8, false>(acc, h);
+      // dir_encoding: cat([final, dir]) -> W/2, LeakyReLU
+      f32x16 acc4[4], hd[4];
+      src.launder();
+      load_bias<4>(acc4, aux, L_SD, half);
+      { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s); }
+      finish<4, true>(acc4, hd);
+      float col[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        col[c] = sigmoidf(head_dot<4>(hd, aux + kAuxSRgb + c * 4 * 32, half) + aux[kAuxSRgb + 3 * 4 * 32 + c]);
+      if (valid && half == 0) {
+        a.sigma[p] = sg;
+        if (a.rgb) { a.rgb[p * 3 + 0] = col[0]; a.rgb[p * 3 + 1] = col[1]; a.rgb[p * 3 + 2] = col[2]; }
+      }
+    }
+
+    if constexpr (DO_OBJ) {
+      f32x16 acc[4], h[4];
+      src.launder();
+      load_bias<4>(acc, aux, L_O1, half);
+      { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
+      finish<4, true>(acc, h);
+      load_bias<4>(acc, aux, L_O2, half);
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+      finish<4, true>(acc, h);
+      src.launder();
+      load_bias<4>(acc, aux, L_O3, half);
+      { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s); }
+      finish<4, true>(acc, h);
+      load_bias<4>(acc, aux, L_O4, half);
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+      finish<4, true>(acc, h);
+      const float sg = head_dot<4>(h, aux + kAuxOSig, half) + aux[kAuxOSig + 4 * 32];
+      load_bias<4>(acc, aux, L_OF, half);
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+      finish<4, false>(acc, h);
+      f32x16 acc2[2], hd[2];
+      src.launder();
+      load_bias<2>(acc2, aux, L_OD, half);
+      { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s); }
+      finish<2, true>(acc2, hd);
+      float col[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        col[c] = sigmoidf(head_dot<2>(hd, aux + kAuxORgb + c * 2 * 32, half) + aux[kAuxORgb + 3 * 2 * 32 + c]);
+      if (valid && half == 0) {
+        a.inst_sigma[p] = sg;
+        if (a.inst_rgb) { a.inst_rgb[p * 3 + 0] = col[0]; a.inst_rgb[p * 3 + 1] = col[1]; a.inst_rgb[p * 3 + 2] = col[2]; }
+      }
+    }
+  }
+}
+
+}  // namespace objnerf

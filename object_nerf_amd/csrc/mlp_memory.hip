@@ -1,0 +1,27 @@
+// mlp_memory.hip -- instantiations of the MLP kernel that reads pre-embedded inputs
+// (backs ObjectNeRF.forward / forward_instance, nerf_model.py:97-152, called directly by
+// tools/extract_mesh.py:85-108, and the teacher-forced per-branch parity tests).
+#include "mlp_kernel.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+template <bool VOXEL, bool SC, bool OB>
+static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, false, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles);
+}
+
+int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+  const bool sc = a.do_scene != 0, ob = a.do_object != 0;
+  if (sc && ob) return set_error(-1, "mlp_eval(memory): one branch per call (forward or forward_instance)");
+  if (a.use_voxel) {
+    if (sc) launch<true, true, false>(a, ntiles, grid, s);
+    else launch<true, false, true>(a, ntiles, grid, s);
+  } else {
+    if (sc) launch<false, true, false>(a, ntiles, grid, s);
+    else launch<false, false, true>(a, ntiles, grid, s);
+  }
+  return check_launch("mlp_eval(memory)");
+}
+
+}  // namespace objnerf

@@ -1,0 +1,590 @@
+// ray_kernels.hip -- the HBM-bound stages around the MLP: coarse depth sampling, alpha
+// compositing (scene + instance), inverse-CDF importance sampling + merge, the multi-object
+// sort/composite and the oriented-box masks, plus the stand-alone embedding kernels that back
+// Embedding.forward / EmbeddingVoxel.forward.  One wave (64 lanes) owns one ray in every
+// per-ray kernel: lane i holds samples i, i+64, ...; scans and reductions are wave-level
+// (DPP/permute), no LDS traffic except where a per-ray table is searched (cdf, merge).
+//
+// Compiled with -ffp-contract=off; see device_math.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "layout.h"
+#include "device_math.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+// ------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// inclusive product scan over the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o);
+    if (lane >= o) v *= t;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: coarse depths (models/rendering.py:260-277)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coarse_z(float near, float far, float t, int use_disp) {
+  if (!use_disp) return near * (1.f - t) + far * t;                       // rendering.py:262
+  return __fdiv_rn(1.f, __fdiv_rn(1.f, near) * (1.f - t) + __fdiv_rn(1.f, far) * t);   // :264
+}
+
+__global__ void sample_coarse_kernel(const float* __restrict__ rays, const float* __restrict__ z_steps,
+                                     const float* __restrict__ perturb_rand, float perturb, int use_disp,
+                                     long n_rays, int S, float* __restrict__ z_vals) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rays * S) return;
+  const long ray = idx / S;
+  const int s = (int)(idx - ray * S);
+  const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
+  float z = coarse_z(near, far, z_steps[s], use_disp);
+  if (perturb > 0.f) {                                                   // rendering.py:268-277
+    const float zl = s > 0 ? coarse_z(near, far, z_steps[s - 1], use_disp) : z;
+    const float zu = s < S - 1 ? coarse_z(near, far, z_steps[s + 1], use_disp) : z;
+    const float lower = s > 0 ? 0.5f * (zl + z) : z;
+    const float upper = s < S - 1 ? 0.5f * (z + zu) : z;
+    z = lower + (upper - lower) * (perturb * perturb_rand[idx]);
+  }
+  z_vals[idx] = z;
+}
+
+// ------------------------------------------------------------------------------------------
+// Embedding.forward (embedding_helper.py:57-74)
+// ------------------------------------------------------------------------------------------
+__global__ void pos_encode_kernel(const float* __restrict__ x, long n, int C, int F, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * C) return;
+  const long row = idx / C;
+  const int c = (int)(idx - row * C);
+  const float v = x[idx];
+  float* o = out + row * (long)C * (2 * F + 1);
+  o[c] = v;
+  float f = 1.f;
+  for (int k = 0; k < F; ++k) {
+    const SinCos sc = psincos(f * v);
+    o[C * (1 + 2 * k) + c] = sc.s;
+    o[C * (2 + 2 * k) + c] = sc.c;
+    f *= 2.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// EmbeddingVoxel.forward (embedding_helper.py:325-411), one thread per point
+// ------------------------------------------------------------------------------------------
+__global__ void voxel_embed_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz, long n,
+                                   float* __restrict__ scene_ftr, float* __restrict__ obj_ftr) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
+  const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
+  const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
+  const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
+  const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
+  const float u = sx - qx, v = sy - qy, w = sz - qz;
+  const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
+  float wt[8];
+  wt[0] = (lu * lv) * lw; wt[1] = (lu * lv) * w; wt[2] = (lu * v) * lw; wt[3] = (lu * v) * w;
+  wt[4] = (u * lv) * lw;  wt[5] = (u * lv) * w;  wt[6] = (u * v) * lw;  wt[7] = (u * v) * w;
+  float f[kVoxC];
+#pragma unroll
+  for (int i = 0; i < kVoxC; ++i) f[i] = 0.f;
+  const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
+  for (int k = 0; k < 8; ++k) {
+    const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
+    const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
+    int r = -1;
+    if (ok) {
+      r = g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz];
+      if (r >= g.n_rows) r = -1;
+    }
+    const float* t = g.table + (size_t)(r < 0 ? 0 : r) * kVoxC;
+#pragma unroll
+    for (int i = 0; i < kVoxC; ++i) {
+      const float fv = r < 0 ? 0.f : t[i];
+      f[i] = k == 0 ? fv * wt[k] : f[i] + fv * wt[k];
+    }
+  }
+  float* so = scene_ftr + p * (long)(kScnVoxPE + kXyzPE);
+  float* oo = obj_ftr + p * (long)kObjVoxPE;
+#pragma unroll
+  for (int c = 0; c < kVoxC; ++c) {
+    const bool scn = c < kScnVoxC;
+    float* o = scn ? so : oo;
+    const int C = scn ? kScnVoxC : kObjVoxC;
+    const int cc = scn ? c : c - kScnVoxC;
+    o[cc] = f[c];
+    float fr = 1.f;
+    for (int k = 0; k < kFreqVox; ++k) {
+      const SinCos sc = psincos(fr * f[c]);
+      o[C * (1 + 2 * k) + cc] = sc.s;
+      o[C * (2 + 2 * k) + cc] = sc.c;
+      fr *= 2.f;
+    }
+  }
+  const float pos[3] = {x, y, z};
+  float* xo = so + kScnVoxPE;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    xo[c] = pos[c];
+    float fr = 1.f;
+    for (int k = 0; k < kFreqXyz; ++k) {
+      const SinCos sc = psincos(fr * pos[c]);
+      xo[3 * (1 + 2 * k) + c] = sc.s;
+      xo[3 * (2 + 2 * k) + c] = sc.c;
+      fr *= 2.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: alpha compositing, scene + instance (models/rendering.py:139-229).  One wave per ray.
+// ------------------------------------------------------------------------------------------
+struct CompositeOut { float opacity, r, g, b, depth; };
+
+// composites one channel set over the ray; when `wout` != null writes per-sample weights.
+// occl_depth: when occl, alphas with (occl_depth + th) < z are zeroed (rendering.py:192-202).
+__device__ __forceinline__ CompositeOut composite_ray(const float* __restrict__ z, const float* __restrict__ sigma,
+                                                      const float* __restrict__ rgb, const float* __restrict__ noise,
+                                                      float noise_std, float last_delta, int S, int lane,
+                                                      bool occl, float occl_limit, float* __restrict__ wout) {
+  float carry = 1.f;   // prod_{j<base} (1 - a_j + 1e-10)
+  float so = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    const bool in = i < S;
+    float zi = 0.f, alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (in) {
+      zi = z[i];
+      const float delta = i + 1 < S ? z[i + 1] - zi : last_delta;
+      float sg_ = sigma[i];
+      if (noise) sg_ = sg_ + noise[i] * noise_std;
+      alpha = 1.f - expf(-delta * fmaxf(sg_, 0.f));          // rendering.py:157
+      if (occl && occl_limit < zi) alpha = 0.f;
+      c0 = rgb[i * 3]; c1 = rgb[i * 3 + 1]; c2 = rgb[i * 3 + 2];
+    }
+    const float t = in ? (1.f - alpha) + 1e-10f : 1.f;     // alphas_shifted, rendering.py:159-161
+    const float incl = wave_scan_mul(t, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.f;
+    const float T = carry * excl;
+    const float w = alpha * T;                              // rendering.py:162
+    if (in) {
+      if (wout) wout[i] = w;
+      so += w; sr += w * c0; sg += w * c1; sb += w * c2; sd += w * zi;
+    }
+    carry = carry * __shfl(incl, 63);
+  }
+  CompositeOut o;
+  o.opacity = wave_sum(so); o.r = wave_sum(sr); o.g = wave_sum(sg); o.b = wave_sum(sb); o.depth = wave_sum(sd);
+  return o;
+}
+
+__global__ void __launch_bounds__(256) composite_kernel(const objnerf_composite_args a) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int S = a.S;
+  for (long ray = wave; ray < a.n_rays; ray += nwaves) {
+    const float* z = a.z_vals + ray * S;
+    const bool inst = a.inst_sigma != nullptr;
+    // scene: last delta 1e10 unless use_zero_as_last_delta (rendering.py:143-153)
+    float* wscene = (inst && a.rays_in_bbox) ? nullptr : a.weights + ray * S;
+    const CompositeOut s = composite_ray(z, a.sigma + ray * S, a.rgb + ray * S * 3,
+                                         a.noise ? a.noise + ray * S : nullptr, a.noise_std,
+                                         a.use_zero_as_last_delta ? 0.f : 1e10f, S, lane, false, 0.f, wscene);
+    if (lane == 0) {
+      a.opacity[ray] = s.opacity;
+      a.depth[ray] = s.depth;
+      // rgb_map + 1 - weights_sum when white_back, rendering.py:178-179
+      a.rgb_map[ray * 3 + 0] = a.white_back ? s.r + 1.f - s.opacity : s.r;
+      a.rgb_map[ray * 3 + 1] = a.white_back ? s.g + 1.f - s.opacity : s.g;
+      a.rgb_map[ray * 3 + 2] = a.white_back ? s.b + 1.f - s.opacity : s.b;
+    }
+    if (inst) {
+      bool occl = a.occlusion != 0;
+      if (occl && a.pass_through_mask && a.pass_through_mask[ray]) occl = false;   // rendering.py:198-200
+      float* winst = a.rays_in_bbox ? a.weights + ray * S : nullptr;              // rendering.py:228-229
+      const CompositeOut q = composite_ray(z, a.inst_sigma + ray * S, a.inst_rgb + ray * S * 3,
+                                           a.noise_inst ? a.noise_inst + ray * S : nullptr, a.noise_std,
+                                           0.f, S, lane, occl, s.depth + a.frustum_bound_th, winst);
+      if (lane == 0) {
+        a.opacity_inst[ray] = q.opacity;
+        a.depth_inst[ray] = q.depth;
+        a.rgb_inst[ray * 3 + 0] = q.r + 1.f - q.opacity;      // always white-backed, rendering.py:223
+        a.rgb_inst[ray * 3 + 1] = q.g + 1.f - q.opacity;
+        a.rgb_inst[ray * 3 + 2] = q.b + 1.f - q.opacity;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: sample_pdf (rendering.py:11-61) and the merge sort(cat([z, z_])) (rendering.py:313)
+// One wave per ray; cdf / bins tables live in LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxBins = 1024;      // supports N_samples up to 1025
+constexpr int kMaxMerge = 2048;     // S + I
+
+// builds cdf[0..nb) for weights w[0..nb-1) and draws `I` samples into out (lane-strided)
+__device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf_lds, const float* __restrict__ wts,
+                                               int nb, const float* __restrict__ u, int I, float eps,
+                                               float* out_lds, float* __restrict__ out_glb, int lane) {
+  const int nw = nb - 1;
+  // weights + eps, row sum  (rendering.py:30-31)
+  float part = 0.f;
+  for (int i = lane; i < nw; i += 64) {
+    const float w = wts[i] + eps;
+    cdf_lds[i + 1] = w;
+    part += w;
+  }
+  const float tot = wave_sum(part);
+  __syncthreads();
+  // cdf = cat([0, cumsum(pdf)]) in the reference's sequential order (rendering.py:32-33)
+  if (lane == 0) {
+    float c = 0.f;
+    cdf_lds[0] = 0.f;
+    for (int i = 0; i < nw; ++i) {
+      c = c + __fdiv_rn(cdf_lds[i + 1], tot);
+      cdf_lds[i + 1] = c;
+    }
+  }
+  __syncthreads();
+  for (int j = lane; j < I; j += 64) {
+    const float uj = u[j];
+    // searchsorted(cdf, u, right=True): first index with cdf[idx] > u  (rendering.py:43)
+    int lo = 0, hi = nb;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf_lds[mid] <= uj) lo = mid + 1; else hi = mid;
+    }
+    const int below = lo - 1 < 0 ? 0 : lo - 1;       // clamp_min(inds-1, 0)
+    const int above = lo > nw ? nw : lo;             // clamp_max(inds, N_samples_)
+    const float c0 = cdf_lds[below], c1 = cdf_lds[above];
+    const float b0 = bins_lds[below], b1 = bins_lds[above];
+    float denom = c1 - c0;
+    if (denom < eps) denom = 1.f;                    // rendering.py:53-54
+    const float smp = b0 + __fdiv_rn(uj - c0, denom) * (b1 - b0);   // rendering.py:58-60
+    if (out_lds) out_lds[j] = smp;
+    if (out_glb) out_glb[j] = smp;
+  }
+}
+
+__global__ void __launch_bounds__(64) sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ weights,
+                                                        const float* __restrict__ u, long u_stride, long n_rays,
+                                                        int nb, int I, float eps, float* __restrict__ samples) {
+  __shared__ float bins_lds[kMaxBins];
+  __shared__ float cdf_lds[kMaxBins];
+  const int lane = threadIdx.x;
+  for (long ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+    for (int i = lane; i < nb; i += 64) bins_lds[i] = bins[ray * nb + i];
+    __syncthreads();
+    sample_pdf_ray(bins_lds, cdf_lds, weights + ray * (nb - 1), nb, u + ray * u_stride, I, eps,
+                   nullptr, samples + ray * I, lane);
+    __syncthreads();
+  }
+}
+
+// fine depths: z_mid bins from the coarse depths, weights[:,1:-1], then ascending merge
+__global__ void __launch_bounds__(64) sample_pdf_merge_kernel(const float* __restrict__ z_coarse,
+                                                              const float* __restrict__ weights,
+                                                              const float* __restrict__ u, long u_stride,
+                                                              long n_rays, int S, int I, float eps,
+                                                              float* __restrict__ z_samples, float* __restrict__ z_fine) {
+  __shared__ float bins_lds[kMaxBins];
+  __shared__ float cdf_lds[kMaxBins];
+  __shared__ float all_lds[kMaxMerge];   // [0,S) coarse z, [S,S+I) new samples
+  const int lane = threadIdx.x;
+  const int nb = S - 1;
+  const int M = S + I;
+  for (long ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+    const float* z = z_coarse + ray * S;
+    for (int i = lane; i < S; i += 64) all_lds[i] = z[i];
+    // z_vals_mid = 0.5 * (z[:-1] + z[1:])   (rendering.py:302-304)
+    for (int i = lane; i < nb; i += 64) bins_lds[i] = 0.5f * (z[i] + z[i + 1]);
+    __syncthreads();
+    sample_pdf_ray(bins_lds, cdf_lds, weights + ray * S + 1, nb, u + ray * u_stride, I, eps,
+                   all_lds + S, z_samples ? z_samples + ray * I : nullptr, lane);
+    __syncthreads();
+    // stable rank sort of the concatenation (== torch.sort(torch.cat([z, z_]))[0])
+    for (int i = lane; i < M; i += 64) {
+      const float v = all_lds[i];
+      int rank = 0;
+      for (int j = 0; j < M; ++j) {
+        const float o = all_lds[j];
+        rank += (o < v || (o == v && j < i)) ? 1 : 0;
+      }
+      z_fine[ray * M + rank] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-object path (render_tools/multi_rendering.py)
+// ------------------------------------------------------------------------------------------
+// oriented boxes: BOX_DOUBLES doubles per box:
+//   [0] scale_factor, [1..9] R_avg, [10..12] t_avg, [13..21] R_box, [22..24] t_box, [25..27] min, [28..30] max
+// x_b = R_box (R_avg (xyz*scale) + t_avg) + t_box in float64, rounded to fp32, compared against the
+// fp32-rounded bounds: utils/bbox_utils.py:119-130 (numpy float64) then 169-186 (torch fp32).
+__device__ __forceinline__ bool in_any_box(float x, float y, float z, const double* __restrict__ boxes, int n_boxes) {
+  bool in = false;
+  for (int b = 0; b < n_boxes; ++b) {
+    const double* B = boxes + (size_t)b * OBJNERF_BOX_DOUBLES;
+    const double sx = (double)x * B[0], sy = (double)y * B[0], sz = (double)z * B[0];
+    const double ax = B[1] * sx + B[2] * sy + B[3] * sz + B[10];
+    const double ay = B[4] * sx + B[5] * sy + B[6] * sz + B[11];
+    const double az = B[7] * sx + B[8] * sy + B[9] * sz + B[12];
+    const float bx = (float)(B[13] * ax + B[14] * ay + B[15] * az + B[22]);
+    const float by = (float)(B[16] * ax + B[17] * ay + B[18] * az + B[23]);
+    const float bz = (float)(B[19] * ax + B[20] * ay + B[21] * az + B[24]);
+    const bool ib = bx >= (float)B[25] && bx <= (float)B[28] && by >= (float)B[26] && by <= (float)B[29] &&
+                    bz >= (float)B[27] && bz <= (float)B[30];
+    in = in || ib;
+  }
+  return in;
+}
+
+__global__ void mask_sigma_kernel(float* __restrict__ sigma, const float* __restrict__ rays,
+                                  const float* __restrict__ z_vals, long n_rays, int S,
+                                  const double* __restrict__ boxes, int n_boxes) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rays * S) return;
+  const long ray = idx / S;
+  bool kill = z_vals[ray * S + S - 1] == 0.f;          // zero_mask, multi_rendering.py:40,83,92
+  if (!kill && n_boxes > 0) {
+    const float* r = rays + ray * 8;
+    const float zv = z_vals[idx];
+    kill = in_any_box(r[0] + r[3] * zv, r[1] + r[4] * zv, r[2] + r[5] * zv, boxes, n_boxes);   // :239-241
+  }
+  if (kill) sigma[idx] = -1e5f;
+}
+
+__global__ void points_in_boxes_kernel(const float* __restrict__ xyz, long n, const double* __restrict__ boxes,
+                                       int n_boxes, uint8_t* __restrict__ inside) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  inside[idx] = in_any_box(xyz[idx * 3], xyz[idx * 3 + 1], xyz[idx * 3 + 2], boxes, n_boxes) ? 1 : 0;
+}
+
+// volume_rendering_multi (multi_rendering.py:96-157): joint stable sort by z of K*S samples,
+// gather, composite with last delta 0.  One wave per ray, everything staged in LDS.
+constexpr int kMaxSets = 16;
+struct MultiPtrs {
+  const float* z[kMaxSets];
+  const float* sigma[kMaxSets];
+  const float* rgb[kMaxSets];
+  float* own_w[kMaxSets];
+};
+
+__global__ void __launch_bounds__(64) composite_multi_kernel(const MultiPtrs ptrs, long n_rays, int K, int S,
+                                                             const float* __restrict__ noise, float noise_std,
+                                                             int white_back, float* __restrict__ z_sorted,
+                                                             float* __restrict__ weights, float* __restrict__ obj_ids,
+                                                             float* __restrict__ opacity, float* __restrict__ rgb_map,
+                                                             float* __restrict__ depth, int has_own) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int M = K * S;
+  float* zin = sm;            // M   unsorted z
+  float* zs = sm + M;         // M   sorted z
+  float* sgs = sm + 2 * M;    // M   sorted sigma
+  float* cs = sm + 3 * M;     // 3M  sorted rgb
+  int* rk = (int*)(sm + 6 * M);   // M  rank of unsorted element
+  const int lane = threadIdx.x;
+  for (long ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+    for (int i = lane; i < M; i += 64) zin[i] = ptrs.z[i / S][ray * S + (i % S)];
+    __syncthreads();
+    for (int i = lane; i < M; i += 64) {
+      const float v = zin[i];
+      int rank = 0;
+      for (int j = 0; j < M; ++j) {
+        const float o = zin[j];
+        rank += (o < v || (o == v && j < i)) ? 1 : 0;
+      }
+      const int k = i / S, s = i % S;
+      rk[i] = rank;
+      zs[rank] = v;
+      sgs[rank] = ptrs.sigma[k][ray * S + s];
+      const float* c = ptrs.rgb[k] + (ray * S + s) * 3;
+      cs[rank * 3] = c[0]; cs[rank * 3 + 1] = c[1]; cs[rank * 3 + 2] = c[2];
+      if (obj_ids) obj_ids[ray * M + rank] = (float)k;
+    }
+    __syncthreads();
+    float* wrow = weights + ray * M;
+    const CompositeOut o = composite_ray(zs, sgs, cs, noise ? noise + ray * M : nullptr, noise_std,
+                                         0.f, M, lane, false, 0.f, wrow);
+    for (int i = lane; i < M; i += 64) z_sorted[ray * M + i] = zs[i];
+    if (lane == 0) {
+      opacity[ray] = o.opacity;
+      depth[ray] = o.depth;
+      rgb_map[ray * 3 + 0] = white_back ? o.r + 1.f - o.opacity : o.r;
+      rgb_map[ray * 3 + 1] = white_back ? o.g + 1.f - o.opacity : o.g;
+      rgb_map[ray * 3 + 2] = white_back ? o.b + 1.f - o.opacity : o.b;
+    }
+    if (has_own) {
+      // weights[obj_ids == k] in own sample order (multi_rendering.py:269-271); same wave wrote wrow
+      __syncthreads();
+      for (int i = lane; i < M; i += 64) ptrs.own_w[i / S][ray * S + (i % S)] = wrow[rk[i]];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packer: gather through the index map
+// ------------------------------------------------------------------------------------------
+struct ParamPtrs { const float* p[kNumParamPtrs]; };
+__global__ void pack_kernel(const uint32_t* __restrict__ idx, long n, const ParamPtrs pp, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t e = idx[i];
+  out[i] = e == kPackZero ? 0.f : pp.p[e >> 24][e & 0xFFFFFFu];
+}
+
+}  // namespace objnerf
+
+// ==========================================================================================
+// host side of the C ABI for these stages
+// ==========================================================================================
+using namespace objnerf;
+
+static inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" {
+
+int objnerf_sample_coarse(const float* rays, const float* z_steps, const float* perturb_rand, float perturb,
+                          int use_disp, int64_t n_rays, int S, float* z_vals, void* stream) {
+  if (!rays || !z_steps || !z_vals || S < 1 || n_rays < 0) return set_error(-1, "sample_coarse: bad arguments");
+  if (perturb > 0.f && !perturb_rand) return set_error(-1, "sample_coarse: perturb > 0 needs perturb_rand");
+  if (n_rays == 0) return 0;
+  hipLaunchKernelGGL(sample_coarse_kernel, dim3(blocks_for(n_rays * S, 256)), dim3(256), 0, (hipStream_t)stream,
+                     rays, z_steps, perturb_rand, perturb, use_disp, (long)n_rays, S, z_vals);
+  return check_launch("sample_coarse");
+}
+
+int objnerf_pos_encode(const float* x, int64_t n, int C, int n_freqs, float* out, void* stream) {
+  if (!x || !out || C < 1 || n_freqs < 0) return set_error(-1, "pos_encode: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(pos_encode_kernel, dim3(blocks_for(n * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, (long)n, C, n_freqs, out);
+  return check_launch("pos_encode");
+}
+
+int objnerf_voxel_embed(const objnerf_voxel_grid* grid, const float* xyz, int64_t n, float* scene_ftr,
+                        float* obj_ftr, void* stream) {
+  if (!grid || !grid->idx_map || !grid->table || !xyz || !scene_ftr || !obj_ftr)
+    return set_error(-1, "voxel_embed: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(voxel_embed_kernel, dim3(blocks_for(n, 128)), dim3(128), 0, (hipStream_t)stream,
+                     *grid, xyz, (long)n, scene_ftr, obj_ftr);
+  return check_launch("voxel_embed");
+}
+
+int objnerf_composite(const objnerf_composite_args* a, void* stream) {
+  if (!a || !a->z_vals || !a->sigma || !a->rgb || !a->weights || !a->opacity || !a->rgb_map || !a->depth)
+    return set_error(-1, "composite: bad arguments");
+  if (a->inst_sigma && (!a->inst_rgb || !a->rgb_inst || !a->depth_inst || !a->opacity_inst))
+    return set_error(-1, "composite: instance outputs missing");
+  if (a->noise_std != 0.f && (!a->noise || (a->inst_sigma && !a->noise_inst)))
+    return set_error(-1, "composite: noise_std != 0 needs noise draws");
+  if (a->n_rays == 0) return 0;
+  objnerf_composite_args c = *a;
+  if (c.noise_std == 0.f) { c.noise = nullptr; c.noise_inst = nullptr; }
+  const long waves = c.n_rays;
+  unsigned grid = (unsigned)((waves + 3) / 4);
+  if (grid > 256u * 32u) grid = 256u * 32u;
+  hipLaunchKernelGGL(composite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c);
+  return check_launch("composite");
+}
+
+int objnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_stride, int64_t n_rays,
+                       int nb, int I, float eps, float* samples, void* stream) {
+  if (!bins || !weights || !u || !samples || nb < 2 || nb > kMaxBins || I < 1)
+    return set_error(-1, "sample_pdf: bad arguments (2 <= bins <= 1024)");
+  if (n_rays == 0) return 0;
+  unsigned grid = (unsigned)(n_rays < 65536 ? n_rays : 65536);
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, bins, weights, u,
+                     (long)u_stride, (long)n_rays, nb, I, eps, samples);
+  return check_launch("sample_pdf");
+}
+
+int objnerf_sample_pdf_merge(const float* z_coarse, const float* weights, const float* u, int64_t u_stride,
+                             int64_t n_rays, int S, int I, float eps, float* z_samples, float* z_fine,
+                             void* stream) {
+  if (!z_coarse || !weights || !u || !z_fine || S < 3 || S - 1 > kMaxBins || I < 1 || S + I > kMaxMerge)
+    return set_error(-1, "sample_pdf_merge: bad arguments (3 <= S <= 1025, S + I <= 2048)");
+  if (n_rays == 0) return 0;
+  unsigned grid = (unsigned)(n_rays < 65536 ? n_rays : 65536);
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, z_coarse, weights, u,
+                     (long)u_stride, (long)n_rays, S, I, eps, z_samples, z_fine);
+  return check_launch("sample_pdf_merge");
+}
+
+int objnerf_mask_sigma(float* sigma, const float* rays, const float* z_vals, int64_t n_rays, int S,
+                       const double* boxes, int n_boxes, void* stream) {
+  if (!sigma || !rays || !z_vals || S < 1 || (n_boxes > 0 && !boxes)) return set_error(-1, "mask_sigma: bad arguments");
+  if (n_rays == 0) return 0;
+  hipLaunchKernelGGL(mask_sigma_kernel, dim3(blocks_for(n_rays * S, 256)), dim3(256), 0, (hipStream_t)stream,
+                     sigma, rays, z_vals, (long)n_rays, S, boxes, n_boxes);
+  return check_launch("mask_sigma");
+}
+
+int objnerf_points_in_boxes(const float* xyz, int64_t n, const double* boxes, int n_boxes, uint8_t* inside,
+                            void* stream) {
+  if (!xyz || !inside || (n_boxes > 0 && !boxes)) return set_error(-1, "points_in_boxes: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(points_in_boxes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     xyz, (long)n, boxes, n_boxes, inside);
+  return check_launch("points_in_boxes");
+}
+
+int objnerf_composite_multi(const objnerf_composite_multi_args* a, void* stream) {
+  if (!a || a->K < 1 || a->K > kMaxSets || a->S < 1 || !a->h_z || !a->h_sigma || !a->h_rgb || !a->z_sorted ||
+      !a->weights || !a->opacity || !a->rgb_map || !a->depth)
+    return set_error(-1, "composite_multi: bad arguments (1 <= K <= 16)");
+  const long M = (long)a->K * a->S;
+  const size_t lds = (size_t)M * 7 * sizeof(float);
+  if (lds > 64 * 1024) return set_error(-1, "composite_multi: K*S too large (K*S*28 bytes must fit 64 KiB of LDS)");
+  if (a->noise_std != 0.f && !a->noise) return set_error(-1, "composite_multi: noise_std != 0 needs noise draws");
+  if (a->n_rays == 0) return 0;
+  MultiPtrs p;
+  for (int k = 0; k < kMaxSets; ++k) {
+    const bool on = k < a->K;
+    p.z[k] = on ? a->h_z[k] : nullptr;
+    p.sigma[k] = on ? a->h_sigma[k] : nullptr;
+    p.rgb[k] = on ? a->h_rgb[k] : nullptr;
+    p.own_w[k] = (on && a->h_own_weights) ? a->h_own_weights[k] : nullptr;
+    if (on && (!p.z[k] || !p.sigma[k] || !p.rgb[k])) return set_error(-1, "composite_multi: null set pointer");
+  }
+  unsigned grid = (unsigned)(a->n_rays < 65536 ? a->n_rays : 65536);
+  hipLaunchKernelGGL(composite_multi_kernel, dim3(grid), dim3(64), lds, (hipStream_t)stream, p, (long)a->n_rays,
+                     a->K, a->S, a->noise_std != 0.f ? a->noise : nullptr, a->noise_std, a->white_back, a->z_sorted,
+                     a->weights, a->obj_ids, a->opacity, a->rgb_map, a->depth, a->h_own_weights ? 1 : 0);
+  return check_launch("composite_multi");
+}
+
+int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx,
+                         const float* const* h_param_ptrs, float* blob, float* aux, void* stream) {
+  if (!blob_idx || !aux_idx || !h_param_ptrs || !blob || !aux) return set_error(-1, "pack_weights: bad arguments");
+  ParamPtrs pp;
+  for (int i = 0; i < kNumParamPtrs; ++i) {
+    if (!h_param_ptrs[i]) return set_error(-1, "pack_weights: null parameter pointer");
+    pp.p[i] = h_param_ptrs[i];
+  }
+  const long nb = objnerf_blob_floats(use_voxel), na = objnerf_aux_floats();
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, pp, blob);
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(na, 256)), dim3(256), 0, (hipStream_t)stream, aux_idx, na, pp, aux);
+  return check_launch("pack_weights");
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""Drop-in `ObjectNeRF` (reference: models/nerf_model.py:6-152) whose forward passes run on the
+gfx950 MLP kernel.
+
+Kept from the reference so checkpoints and callers interoperate:
+  * constructor signature `ObjectNeRF(model_config)` (attribute / item / .get access);
+  * parameter names `xyz_encoding_{1..8}.0.{weight,bias}`, `xyz_encoding_final`, `sigma`,
+    `dir_encoding.0`, `rgb.0`, `instance_encoding_{1..4}.0`, `instance_encoding_final.0`,
+    `instance_sigma`, `inst_dir_encoding.0`, `inst_rgb.0` with nn.Linear (out,in) layout;
+  * `forward(inputs, sigma_only=False)` / `forward_instance(inputs, sigma_only=False)` taking and
+    returning the same dict keys.
+
+Different by design: the module never multiplies anything in PyTorch.  Its parameters are
+gathered once per parameter version into the MFMA operand stream (`packed()`), and both forward
+methods enqueue the HIP kernel (csrc/mlp_kernel.h) on the current stream.  The kernel is
+specialised for the architecture every shipped reference config uses
+(config/default_conf.yml:7-36); other widths/depths are rejected loudly.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_SCENE_LAYERS = ["xyz_encoding_%d.0" % i for i in range(1, 9)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"]
+_OBJ_LAYERS = ["instance_encoding_%d.0" % i for i in range(1, 5)] + [
+    "instance_encoding_final.0", "inst_dir_encoding.0", "instance_sigma", "inst_rgb.0"]
+# canonical order of the packer's pointer table (include/objnerf_hip.h)
+PARAM_LAYERS = _SCENE_LAYERS + _OBJ_LAYERS
+
+_index_cache = {}   # (use_voxel, device) -> (blob_idx, aux_idx) uint32 device tensors
+
+
+def _pack_index(use_voxel, device):
+    key = (bool(use_voxel), str(device))
+    if key not in _index_cache:
+        l = _lib.lib()
+        nb, na = l.objnerf_blob_floats(int(use_voxel)), l.objnerf_aux_floats()
+        bi = torch.empty(nb, dtype=torch.int32)
+        ai = torch.empty(na, dtype=torch.int32)
+        _lib.check(l.objnerf_pack_index(int(use_voxel), C.c_void_p(bi.data_ptr()), C.c_void_p(ai.data_ptr())), "pack_index")
+        _index_cache[key] = (bi.to(device), ai.to(device))
+    return _index_cache[key]
+
+
+def _linear_act(i, o, act):
+    return nn.Sequential(nn.Linear(i, o), act)
+
+
+class ObjectNeRF(nn.Module):
+    def __init__(self, model_config):
+        super().__init__()
+        self.model_config = model_config
+        self.use_voxel_embedding = bool(model_config.use_voxel_embedding)
+        cfg = model_config
+        self.D, self.W = cfg["D"], cfg["W"]
+        self.N_freq_xyz, self.N_freq_dir = cfg["N_freq_xyz"], cfg["N_freq_dir"]
+        self.skips = list(cfg["skips"])
+        self.inst_D, self.inst_W = cfg["inst_D"], cfg["inst_W"]
+        self.inst_skips = list(cfg["inst_skips"])
+        n_code = cfg["N_obj_code_length"]
+        if self.use_voxel_embedding:
+            self.N_scn_voxel_size = cfg.get("N_scn_voxel_size", 0)
+            self.N_freq_voxel = cfg["N_freq_voxel"]
+            n_obj_vox = cfg.get("N_obj_voxel_size", 0)
+            scn_vox = self.N_scn_voxel_size * (1 + 2 * self.N_freq_voxel)
+            obj_vox = n_obj_vox * (1 + 2 * self.N_freq_voxel)
+        else:
+            scn_vox = obj_vox = 0
+        self.in_channels_xyz = 3 * (1 + 2 * self.N_freq_xyz) + scn_vox
+        self.in_channels_dir = 3 * (1 + 2 * self.N_freq_dir)
+        self.inst_channel_in = self.in_channels_xyz + n_code + obj_vox
+
+        # the gfx950 kernel is built for exactly this architecture (csrc/layout.h)
+        expect = dict(D=8, W=256, skips=[4], inst_D=4, inst_W=128, inst_skips=[2], N_freq_xyz=10, N_freq_dir=4)
+        got = dict(D=self.D, W=self.W, skips=self.skips, inst_D=self.inst_D, inst_W=self.inst_W,
+                   inst_skips=self.inst_skips, N_freq_xyz=self.N_freq_xyz, N_freq_dir=self.N_freq_dir)
+        want_xyz = 271 if self.use_voxel_embedding else 63
+        want_obj = 439 if self.use_voxel_embedding else 127
+        if got != expect or self.in_channels_xyz != want_xyz or self.inst_channel_in != want_obj:
+            raise NotImplementedError(
+                "object_nerf_amd.ObjectNeRF: the HIP kernel is specialised for the reference's shipped "
+                "architecture %r with in_channels_xyz=%d, inst_channel_in=%d; got %r (%d, %d)"
+                % (expect, want_xyz, want_obj, got, self.in_channels_xyz, self.inst_channel_in))
+
+        self.activation = nn.LeakyReLU(inplace=True)
+        # scene branch (same registration order as the reference so seeded inits coincide)
+        for i in range(self.D):
+            fan_in = self.in_channels_xyz if i == 0 else (self.W + self.in_channels_xyz if i in self.skips else self.W)
+            setattr(self, "xyz_encoding_%d" % (i + 1), _linear_act(fan_in, self.W, self.activation))
+        self.xyz_encoding_final = nn.Linear(self.W, self.W)
+        self.sigma = nn.Linear(self.W, 1)
+        self.rgb = nn.Sequential(nn.Linear(self.W // 2, 3), nn.Sigmoid())
+        self.dir_encoding = _linear_act(self.W + self.in_channels_dir, self.W // 2, self.activation)
+        # object branch
+        for i in range(self.inst_D):
+            fan_in = self.inst_channel_in if i == 0 else (
+                self.inst_W + self.inst_channel_in if i in self.inst_skips else self.inst_W)
+            setattr(self, "instance_encoding_%d" % (i + 1), _linear_act(fan_in, self.inst_W, self.activation))
+        self.instance_encoding_final = nn.Sequential(nn.Linear(self.inst_W, self.inst_W))
+        self.instance_sigma = nn.Linear(self.inst_W, 1)
+        self.inst_dir_encoding = _linear_act(self.inst_W + self.in_channels_dir, self.inst_W // 2, self.activation)
+        self.inst_rgb = nn.Sequential(nn.Linear(self.inst_W // 2, 3), nn.Sigmoid())
+
+        self._packed = None
+        self._packed_key = None
+
+    # ---- weight stream ---------------------------------------------------------------------
+    def _param_list(self):
+        mods = dict(self.named_modules())
+        out = []
+        for name in PARAM_LAYERS:
+            m = mods[name]
+            out += [m.weight, m.bias]
+        return out
+
+    def packed(self):
+        """(blob, aux) device tensors for the kernel; re-gathered when any parameter changed
+        (optimizer step, load_state_dict, .to()) -- keyed on (data_ptr, _version)."""
+        params = self._param_list()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        dev = params[0].device
+        _lib.require_cuda(params[0], "ObjectNeRF parameters")
+        l = _lib.lib()
+        uv = int(self.use_voxel_embedding)
+        n = l.objnerf_num_param_ptrs()
+        assert n == len(params)
+        srcs = []
+        for i, p in enumerate(params):
+            if p.numel() != l.objnerf_param_numel(uv, i):
+                raise RuntimeError("ObjectNeRF parameter %d has %d elements, kernel layout expects %d"
+                                   % (i, p.numel(), l.objnerf_param_numel(uv, i)))
+            srcs.append(_lib.as_f32(p.detach()))
+        bi, ai = _pack_index(uv, dev)
+        blob = torch.empty(l.objnerf_blob_floats(uv), dtype=torch.float32, device=dev)
+        aux = torch.empty(l.objnerf_aux_floats(), dtype=torch.float32, device=dev)
+        table = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        _lib.check(l.objnerf_pack_weights(uv, _lib.ptr(bi), _lib.ptr(ai), table, _lib.ptr(blob), _lib.ptr(aux),
+                                          _lib.stream_ptr()), "pack_weights")
+        self._packed, self._packed_key = (blob, aux), key
+        return self._packed
+
+    # ---- reference-compatible forward passes (pre-embedded inputs) -------------------------------
+    def _check_no_grad(self, *tensors):
+        if torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
+                                        or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "object_nerf_amd: the HIP path is forward-only in this round (backward = SURVEY §8 row f1). "
+                "Call under torch.no_grad(); there is deliberately no PyTorch fallback.")
+
+    def _run(self, inputs, scene):
+        emb_xyz = inputs["emb_xyz"]
+        emb_dir = inputs.get("emb_dir", None)
+        self._check_no_grad(emb_xyz, emb_dir)
+        _lib.require_cuda(emb_xyz, "emb_xyz")
+        n = emb_xyz.shape[0]
+        dev = emb_xyz.device
+        if emb_xyz.shape[-1] != self.in_channels_xyz:
+            raise RuntimeError("emb_xyz has %d channels, expected %d" % (emb_xyz.shape[-1], self.in_channels_xyz))
+        if emb_dir is None:   # sigma_only callers may omit it (tools/extract_mesh.py:85-108)
+            emb_dir = torch.zeros(n, self.in_channels_dir, device=dev)
+        blob, aux = self.packed()
+        a = _lib.MlpArgs()
+        a.use_voxel = int(self.use_voxel_embedding)
+        a.do_scene, a.do_object = (1, 0) if scene else (0, 1)
+        a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
+        exyz, edir = _lib.as_f32(emb_xyz), _lib.as_f32(emb_dir)
+        a.emb_xyz, a.emb_dir, a.n_points = exyz.data_ptr(), edir.data_ptr(), n
+        sig = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        keep = [exyz, edir]
+        if scene:
+            a.sigma, a.rgb = sig.data_ptr(), rgb.data_ptr()
+        else:
+            code = _lib.as_f32(inputs["obj_code"])
+            a.obj_code = code.data_ptr()
+            keep.append(code)
+            if self.use_voxel_embedding:
+                ov = _lib.as_f32(inputs["obj_voxel"])
+                a.obj_voxel = ov.data_ptr()
+                keep.append(ov)
+            a.inst_sigma, a.inst_rgb = sig.data_ptr(), rgb.data_ptr()
+        _lib.check(_lib.lib().objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval")
+        return sig, rgb
+
+    def forward(self, inputs, sigma_only=False):
+        sig, rgb = self._run(inputs, scene=True)
+        out = {"sigma": sig}
+        if not sigma_only:
+            out["rgb"] = rgb
+        return out
+
+    def forward_instance(self, inputs, sigma_only=False):
+        sig, rgb = self._run(inputs, scene=False)
+        out = {"inst_sigma": sig}
+        if not sigma_only:
+            out["inst_rgb"] = rgb
+        return out

@@ -1,0 +1,188 @@
+"""Drop-in `render_rays` / `sample_pdf` (reference: models/rendering.py:233-337, 11-61).
+
+One call = one enqueue of objnerf_render_rays (csrc/api.hip): coarse depths -> fused
+embed+MLP kernel -> scene/instance compositing -> inverse-CDF sampling + merge -> fine pass.
+The Python below only validates arguments, allocates the result tensors and draws the random
+tensors the training-mode paths need (perturb > 0, noise_std > 0); it never computes.
+
+Signature, keyword plumbing (`is_eval` / `use_zero_as_last_delta` arrive via **dummy_kwargs,
+rendering.py:75-76), result keys and quirks are the reference's:
+  * `embedding_instance` is mandatory even with forward_instance=False (rendering.py:94);
+  * `chunk` is accepted and ignored (the kernel is persistent; nothing is chunked for memory);
+  * with rays_in_bbox the returned `weights_*` are the instance weights (rendering.py:228-229).
+"""
+import ctypes as C
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import _lib
+from .embedding_helper import Embedding, EmbeddingVoxel
+
+__all__ = ["render_rays", "sample_pdf"]
+
+_tables = {}
+
+
+def _linspace(n, device):
+    """torch.linspace(0,1,n) on the device -- the reference's own table (it is not i/(n-1):
+    30 of 64 entries differ by an ulp), cached per (n, device).
+    Built on the CPU so that the values are the ones the CPU reference uses too."""
+    key = (n, str(device))
+    if key not in _tables:
+        _tables[key] = torch.linspace(0, 1, n).to(device)
+    return _tables[key]
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
+    """models/rendering.py:11-61.  `u` (N_rays, N_importance) optionally injects the uniform draws
+    used when det=False (tests); otherwise they are drawn with torch.rand like the reference."""
+    _lib.require_cuda(bins, "bins")
+    n, nb = bins.shape
+    assert weights.shape == (n, nb - 1)
+    b, w = _lib.as_f32(bins), _lib.as_f32(weights.detach())
+    if det:
+        uu, stride = _linspace(N_importance, bins.device), 0
+    else:
+        uu = _lib.as_f32(u) if u is not None else torch.rand(n, N_importance, device=bins.device)
+        stride = N_importance
+    out = torch.empty(n, N_importance, dtype=torch.float32, device=bins.device)
+    _lib.check(_lib.lib().objnerf_sample_pdf(_lib.ptr(b), _lib.ptr(w), _lib.ptr(uu), stride, n, nb, N_importance,
+                                             eps, _lib.ptr(out), _lib.stream_ptr()), "sample_pdf")
+    return out
+
+
+def _alloc_out(n, s, dev, inst):
+    o = {
+        "weights": torch.empty(n, s, dtype=torch.float32, device=dev),
+        "z_vals": torch.empty(n, s, dtype=torch.float32, device=dev),
+        "opacity": torch.empty(n, dtype=torch.float32, device=dev),
+        "depth": torch.empty(n, dtype=torch.float32, device=dev),
+        "rgb": torch.empty(n, 3, dtype=torch.float32, device=dev),
+    }
+    if inst:
+        o["rgb_instance"] = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        o["depth_instance"] = torch.empty(n, dtype=torch.float32, device=dev)
+        o["opacity_instance"] = torch.empty(n, dtype=torch.float32, device=dev)
+    return o
+
+
+def _out_struct(o):
+    s = _lib.RenderOut()
+    for k, t in o.items():
+        setattr(s, k, t.data_ptr())
+    return s
+
+
+def render_rays(
+    models: Dict[str, Any],
+    embeddings: Dict[str, Any],
+    rays: torch.Tensor,
+    N_samples: int = 64,
+    use_disp: bool = False,
+    perturb: float = 0,
+    noise_std: float = 1,
+    N_importance: int = 0,
+    chunk: int = 1024 * 32,
+    white_back: bool = False,
+    forward_instance: bool = True,
+    embedding_instance: Optional[torch.Tensor] = None,
+    frustum_bound_th: float = 0,
+    pass_through_mask: Optional[torch.Tensor] = None,
+    rays_in_bbox: bool = False,
+    **dummy_kwargs,
+):
+    is_eval = bool(dummy_kwargs.get("is_eval", False))
+    use_zero_as_last_delta = bool(dummy_kwargs.get("use_zero_as_last_delta", False))
+    # test hook: pre-drawn random tensors {"perturb_rand","u_rand","noise":[4]} (never set by the reference callers)
+    randoms = dummy_kwargs.get("_randoms", None)
+
+    _lib.require_cuda(rays, "rays")
+    if embedding_instance is None:
+        raise TypeError("render_rays: embedding_instance is required (models/rendering.py:94 repeats it unconditionally)")
+    coarse = models["coarse"]
+    coarse._check_no_grad(rays, embedding_instance)
+    dev = rays.device
+    n = rays.shape[0]
+    S, I = int(N_samples), int(N_importance)
+    emb_xyz = embeddings["xyz"]
+    use_voxel = isinstance(emb_xyz, EmbeddingVoxel)
+    if use_voxel != bool(coarse.use_voxel_embedding):
+        raise RuntimeError("render_rays: embeddings['xyz'] and the model disagree about use_voxel_embedding")
+    if not use_voxel and not isinstance(emb_xyz, Embedding):
+        raise TypeError("render_rays: embeddings['xyz'] must be object_nerf_amd Embedding or EmbeddingVoxel")
+
+    rays_c = _lib.as_f32(rays)
+    if rays_c.shape[1] != 8:
+        rays_c = rays_c[:, :8].contiguous()
+    codes = _lib.as_f32(embedding_instance.detach())
+    if codes.shape != (n, 64):
+        raise RuntimeError("embedding_instance must be (N_rays, 64), got %s" % (tuple(codes.shape),))
+
+    cfg = _lib.RenderCfg(
+        use_voxel=int(use_voxel), N_samples=S, N_importance=I, use_disp=int(bool(use_disp)),
+        perturb=float(perturb), noise_std=float(noise_std), white_back=int(bool(white_back)),
+        forward_instance=int(bool(forward_instance)), is_eval=int(is_eval),
+        use_zero_as_last_delta=int(use_zero_as_last_delta), frustum_bound_th=float(frustum_bound_th),
+        rays_in_bbox=int(bool(rays_in_bbox)))
+    l = _lib.lib()
+    ws = torch.empty(l.objnerf_render_workspace_bytes(C.byref(cfg), n), dtype=torch.uint8, device=dev)
+
+    rin = _lib.RenderIn()
+    rin.rays, rin.n_rays = rays_c.data_ptr(), n
+    rin.codes, rin.code_stride = codes.data_ptr(), 64
+    keep = [rays_c, codes, ws]
+    if pass_through_mask is not None:
+        ptm = pass_through_mask.reshape(n).to(torch.uint8).contiguous()
+        rin.pass_through_mask = ptm.data_ptr()
+        keep.append(ptm)
+    bc, ac = coarse.packed()
+    rin.blob_coarse, rin.aux_coarse = bc.data_ptr(), ac.data_ptr()
+    if I > 0:
+        bf, af = models["fine"].packed()
+        rin.blob_fine, rin.aux_fine = bf.data_ptr(), af.data_ptr()
+    if use_voxel:
+        rin.grid = emb_xyz.grid_struct()
+    rin.z_steps = _linspace(S, dev).data_ptr()
+    if I > 0:
+        rin.u_det = _linspace(I, dev).data_ptr()
+    # random draws (training mode only), same distributions as rendering.py:276, 40, 156, 187
+    if perturb > 0:
+        pr = randoms["perturb_rand"] if randoms else torch.rand(n, S, device=dev)
+        keep.append(pr)
+        rin.perturb_rand = _lib.as_f32(pr).data_ptr()
+        if I > 0:
+            ur = randoms["u_rand"] if randoms else torch.rand(n, I, device=dev)
+            keep.append(ur)
+            rin.u_rand = _lib.as_f32(ur).data_ptr()
+    if noise_std != 0:
+        shapes = [(n, S), (n, S), (n, S + I), (n, S + I)]
+        for k in range(4 if I > 0 else 2):
+            if not forward_instance and (k & 1):
+                continue
+            nz = randoms["noise"][k] if randoms else torch.randn(*shapes[k], device=dev)
+            keep.append(nz)
+            rin.noise[k] = _lib.as_f32(nz).data_ptr()
+    rin.workspace = ws.data_ptr()
+
+    oc = _alloc_out(n, S, dev, forward_instance)
+    of = _alloc_out(n, S + I, dev, forward_instance) if I > 0 else None
+    so_c = _out_struct(oc)
+    so_f = _out_struct(of) if of is not None else None
+    _lib.check(l.objnerf_render_rays(C.byref(cfg), C.byref(rin), C.byref(so_c),
+                                     C.byref(so_f) if so_f is not None else None, _lib.stream_ptr()), "render_rays")
+
+    results = {}
+    for typ, o in (("coarse", oc), ("fine", of)):
+        if o is None:
+            continue
+        results["weights_%s" % typ] = o["weights"]
+        results["opacity_%s" % typ] = o["opacity"]
+        results["z_vals_%s" % typ] = o["z_vals"]
+        results["rgb_%s" % typ] = o["rgb"]
+        results["depth_%s" % typ] = o["depth"]
+        if forward_instance:
+            results["rgb_instance_%s" % typ] = o["rgb_instance"]
+            results["depth_instance_%s" % typ] = o["depth_instance"]
+            results["opacity_instance_%s" % typ] = o["opacity_instance"]
+    return results
