@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- render_rays throughput on MI355X (BASELINE.json metric: ray-samples/sec/GPU).
+
+A "step" = one full 640x480 frame (307,200 rays) through render_rays, scene + object branches,
+64 coarse + 64 fine samples, voxel embedding, eval mode (BASELINE.json configs[1]); i.e.
+192 MLP-evaluated sample points ("ray-samples") per ray, 58,982,400 per step.
+Inputs (rays, codes, weights, voxel grid) are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank renders
+its own frame of a N-frame batch (rays are independent, no data-path collective inside the
+renderer), then ONE all_gather_into_tensor of the rendered pixels (rgb_fine, 3 floats/ray) over
+RCCL so that every rank holds all frames; that collective is inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- fused MLP kernel, fp32 MFMA bound: algorithmic FLOP (1,776,128 per eval) /
+                  HIP-event time of the kernel launches on the launch stream;
+  cpu_baseline -- the oracle ("port" of the reference's PyTorch path, oracle/objnerf_oracle.py)
+                  timed on the host cores on a bounded sample of the same rays (N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_EVAL_BOTH_VOXEL = 1_776_128
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--n-importance", type=int, default=64)
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
+        dist = dist_mod
+
+    import object_nerf_amd as A
+    from object_nerf_amd import synth, _lib
+    from object_nerf_amd.distributed import gather_pixels
+
+    S, I = 64, args.n_importance
+    preset = synth.TOYDESK_LIKE
+    sc = synth.build_scene(A, use_voxel=True, preset=preset, max_voxels=800_000, device=dev, n_importance=I)
+    # rank r renders its own camera (frame r of the batch)
+    rays = synth.camera_rays(args.width, args.height, near=preset["near"], far=preset["far"],
+                             yaw_deg=35.0 + 20.0 * rank).to(dev)
+    n = rays.shape[0]
+    with torch.no_grad():
+        ids = torch.full((n,), 1, dtype=torch.long, device=dev)     # val_instance_id = 1 (config/toy_desk_2.yml:39)
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"].contiguous()
+    kw = dict(N_samples=S, N_importance=I, perturb=0, noise_std=0, white_back=False, forward_instance=True,
+              embedding_instance=codes, frustum_bound_th=preset["frustum_bound_th"], is_eval=True)
+
+    def step():
+        with torch.no_grad():
+            r = A.render_rays(sc.models, sc.embeddings, rays, **kw)
+            if dist is not None:
+                return gather_pixels(r["rgb_fine"])
+            return r["rgb_fine"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("scene ready: %d rays/frame, world %d" % (n, world))
+    for _ in range(args.warmup):
+        step()
+    fence()
+    log("warmup done")
+    lib = _lib.lib()
+    lib.objnerf_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    t1 = time.perf_counter()
+    launches, kms = C.c_int64(0), C.c_double(0.0)
+    lib.objnerf_timing_read(C.byref(launches), C.byref(kms))
+    lib.objnerf_timing_enable(0)
+
+    log("timed region done: %.3f s for %d steps" % (t1 - t0, args.steps))
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+    evals_per_ray = S + (S + I)
+    evals_step_rank = n * evals_per_ray
+    value = world * evals_step_rank * args.steps / elapsed
+
+    res = None
+    if rank == 0:
+        mlp_s = kms.value / 1e3
+        flop = float(evals_step_rank) * args.steps * FLOP_PER_EVAL_BOTH_VOXEL
+        achieved = flop / mlp_s / 1e12 if mlp_s > 0 else 0.0
+        res = {
+            "metric": "ray-samples/sec (MLP-evaluated sample points, 64c+64f, scene+object, 256-wide MLP)",
+            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ToyDesk-2-like %dx%d frame per GPU, scene+object branches, "
+                                   "%d coarse + %d fine, voxel embedding (800000x24 table), eval mode, W1 random-init weights"
+                                   % (args.width, args.height, S, I),
+                       "rays_per_step_per_gpu": n, "evals_per_ray": evals_per_ray,
+                       "rays_per_s": world * n * args.steps / elapsed,
+                       "collective": "all_gather_into_tensor(rgb_fine) over RCCL" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": "objnerf::mlp_kernel<voxel,fused,scene,object>",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "launches": int(launches.value), "avg_launch_ms": kms.value / max(1, launches.value),
+                         "flop_per_eval": FLOP_PER_EVAL_BOTH_VOXEL, "mlp_time_frac_of_step": mlp_s / elapsed},
+        }
+        if world == 1 and args.cpu_rays > 0:
+            res["cpu_baseline"] = cpu_baseline(sc, rays, codes, kw, args.cpu_rays, evals_per_ray)
+        chk = float(out.float().mean().item())
+        res["config"]["mean_rgb_fine"] = chk
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
+
+
+def cpu_baseline(sc, rays, codes, kw, n_sample, evals_per_ray):
+    """Times the oracle (CPU restatement of the reference's PyTorch path; bit-exact with the
+    reference on CPU, tests/test_oracle_vs_reference.py) on `n_sample` rays spread over the frame."""
+    from oracle import objnerf_oracle as O
+    # host cores actually available to this process (cgroup/affinity aware), not the machine total
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    idx = torch.linspace(0, rays.shape[0] - 1, n_sample).long()
+    r_cpu = rays[idx.to(rays.device)].cpu()
+    c_cpu = codes[idx.to(rays.device)].cpu()
+    ev = sc.embeddings["xyz"]
+    grid = dict(voxel_idx_map=ev.voxel_idx_map.cpu(), table=ev.embedding_space_ftr.weight.detach().cpu(),
+                voxel_offset=ev.voxel_offset.cpu(), voxel_size=ev.voxel_size.cpu(), voxel_shape=ev.voxel_shape.cpu())
+    pc = {k: v.detach().cpu() for k, v in sc.models["coarse"].state_dict().items()}
+    pf = {k: v.detach().cpu() for k, v in sc.models["fine"].state_dict().items()}
+    okw = dict(N_samples=kw["N_samples"], N_importance=kw["N_importance"], embedding_instance=c_cpu,
+               frustum_bound_th=kw["frustum_bound_th"], is_eval=True)
+    times = []
+    with torch.no_grad():
+        # The reference's path is hundreds of small ATen ops per chunk: more threads is not faster.
+        # Probe a few thread counts on a 128-ray slab and keep the best (reported as `cores`).
+        best = None
+        for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+            torch.set_num_threads(nt)
+            O.render_rays(pc, pf, grid, r_cpu[:128], **dict(okw, embedding_instance=c_cpu[:128]))   # warm-up
+            t0 = time.perf_counter()
+            O.render_rays(pc, pf, grid, r_cpu[:128], **dict(okw, embedding_instance=c_cpu[:128]))
+            dt = time.perf_counter() - t0
+            log("cpu_baseline probe: %d threads -> %.1f ms/ray" % (nt, dt / 128 * 1e3))
+            if best is None or dt < best[1]:
+                best = (nt, dt)
+        ncpu, per_ray = best[0], best[1] / 128
+        torch.set_num_threads(ncpu)
+        # bound the sample to ~8 s per repetition
+        n_fit = int(max(128, min(n_sample, 8.0 / max(per_ray, 1e-6))))
+        if n_fit < n_sample:
+            log("cpu_baseline: shrinking sample %d -> %d rays (%.1f ms/ray)" % (n_sample, n_fit, per_ray * 1e3))
+            n_sample = n_fit
+            r_cpu, c_cpu = r_cpu[:n_sample], c_cpu[:n_sample]
+            okw["embedding_instance"] = c_cpu
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.render_rays(pc, pf, grid, r_cpu, **okw)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return {"value": n_sample * evals_per_ray / med, "unit": "ray-samples/s", "cores": ncpu, "cores_available": avail, "kind": "port",
+            "sample": "%d rays evenly spread over the frame, same weights/grid/codes, median of 3 (%.2f s each)"
+                      % (n_sample, med)}
+
+
+if __name__ == "__main__":
+    main()
