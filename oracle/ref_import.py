@@ -14,8 +14,9 @@ What it does (SURVEY.md §8c recipe, nothing in the reference tree is modified):
   * inserts empty stub modules for `torch_optimizer`, `open3d` (with
     io.read_point_cloud), `ipdb` so `utils/__init__.py:5`, `utils/util.py:12`,
     `render_tools/multi_rendering.py:1` import;
-  * pre-registers a stub `utils.bbox_utils` exposing `check_in_any_boxes`
-    (the real file drags in cv2/numba/kornia via datasets/__init__.py);
+  * pre-registers a stub `datasets.geo_utils` (the real one drags in cv2/numba/kornia via
+    datasets/__init__.py) so that the REAL `utils/bbox_utils.py` imports; `make_box()` builds a
+    BBoxRayHelper without its file-reading constructor;
   * makes `Tensor.cuda()` / `Module.cuda()` identity when no GPU is visible, because
     `models/embedding_helper.py:103,125,163,166,193,200,367` hard-code `.cuda()`.
 """
@@ -84,26 +85,23 @@ def load_reference():
     try:
         import utils  # noqa: F401  (real package; needs the stubs above)
 
-        bb = types.ModuleType("utils.bbox_utils")
+        # utils/bbox_utils.py:6 imports datasets.geo_utils (-> datasets/__init__.py -> cv2, numba,
+        # kornia, torchvision).  Only `bbox_intersection_batch` is taken from it and the hot path
+        # (check_in_any_boxes / check_xyz_in_bounds, bbox_utils.py:158-207) never calls it, so a stub
+        # `datasets` package lets the REAL utils/bbox_utils.py import unmodified.
+        if "datasets" not in sys.modules:
+            ds = types.ModuleType("datasets")
+            ds.__path__ = []
+            geo = types.ModuleType("datasets.geo_utils")
 
-        def check_in_any_boxes(boxes, xyz, scale_factor=None, bbox_enlarge=0.0):
-            # restatement of utils/bbox_utils.py:189-207 for duck-typed box objects that
-            # offer check_xyz_in_bounds(xyz, scale_factor, bbox_enlarge) -> bool (n,)
-            need_reshape = False
-            if len(xyz.shape) == 3:
-                n1, n2, _ = xyz.shape
-                xyz = xyz.reshape(-1, 3)
-                need_reshape = True
-            in_bounds = torch.zeros_like(xyz[:, 0]).bool()
-            for _, box in boxes.items():
-                in_bounds = torch.logical_or(box.check_xyz_in_bounds(xyz, scale_factor, bbox_enlarge), in_bounds)
-            if need_reshape:
-                in_bounds = in_bounds.view(n1, n2)
-            return in_bounds
+            def bbox_intersection_batch(*a, **k):
+                raise NotImplementedError("stub: ray/box intersection is outside the oracle's scope")
 
-        bb.check_in_any_boxes = check_in_any_boxes
-        sys.modules["utils.bbox_utils"] = bb
-        utils.bbox_utils = bb
+            geo.bbox_intersection_batch = bbox_intersection_batch
+            ds.geo_utils = geo
+            sys.modules["datasets"] = ds
+            sys.modules["datasets.geo_utils"] = geo
+        import utils.bbox_utils as bbox_utils
 
         import models.rendering as rendering
         import models.nerf_model as nerf_model
@@ -124,8 +122,51 @@ def load_reference():
         render_rays_multi=multi_rendering.render_rays_multi,
         volume_rendering_multi=multi_rendering.volume_rendering_multi,
         inference_from_model=multi_rendering.inference_from_model,
-        modules=dict(rendering=rendering, nerf_model=nerf_model, embedding_helper=embedding_helper,
+        BBoxRayHelper=bbox_utils.BBoxRayHelper,
+        check_in_any_boxes=bbox_utils.check_in_any_boxes,
+        modules=dict(rendering=rendering, bbox_utils=bbox_utils, nerf_model=nerf_model, embedding_helper=embedding_helper,
                      code_library=code_library, multi_rendering=multi_rendering),
     )
     _loaded = ns
     return ns
+
+
+def make_box(box):
+    """A reference BBoxRayHelper (utils/bbox_utils.py:9-117) for a box dict as produced by
+    object_nerf_amd.synth.oriented_box, bypassing the constructor that reads dataset files."""
+    ns = load_reference()
+    b = object.__new__(ns.BBoxRayHelper)
+    b.scale_factor = box["scale_factor"]
+    b.pose_avg = np.eye(4)
+    b.pose_avg[:3, :3] = box["R_avg"]
+    b.pose_avg[:3, 3] = box["t_avg"]
+    b.axis_align_mat = np.eye(4)
+    b.axis_align_mat[:3, :3] = box["R_box"]
+    b.axis_align_mat[:3, 3] = box["t_box"]
+    b.bbox_bounds = np.array([np.asarray(box["bmin"], dtype=np.float64), np.asarray(box["bmax"], dtype=np.float64)])
+    return b
+
+
+class inject_randoms:
+    """Context manager: while active, torch.rand_like / torch.randn_like / torch.rand return the
+    queued tensors (in call order) instead of drawing.  Lets the reference's training-mode paths
+    (rendering.py:276, 40, 156, 187) run on the same random tensors as the oracle / HIP path."""
+
+    def __init__(self, rand_like=(), randn_like=(), rand=()):
+        self.q = {"rand_like": list(rand_like), "randn_like": list(randn_like), "rand": list(rand)}
+
+    def __enter__(self):
+        self.saved = {k: getattr(torch, k) for k in self.q}
+        for k in self.q:
+            def fake(*a, _k=k, **kw):
+                return self.q[_k].pop(0).clone()
+            setattr(torch, k, fake)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            setattr(torch, k, v)
+        left = {k: len(v) for k, v in self.q.items() if v}
+        if left and exc[0] is None:
+            raise RuntimeError("inject_randoms: unused tensors %r" % left)
+        return False
