@@ -42,7 +42,10 @@ def gather_pixels(local: torch.Tensor, n_total: int = None) -> torch.Tensor:
         return local
     world = dist.get_world_size()
     squeeze = local.dim() == 1
-    x = local.reshape(local.shape[0], -1).contiguous()
+    cols = 1
+    for d in local.shape[1:]:
+        cols *= int(d)
+    x = local.reshape(local.shape[0], cols).contiguous()     # explicit width: reshape(0, -1) is ambiguous
     per = x.shape[0] if n_total is None else (n_total + world - 1) // world
     if x.shape[0] < per:
         x = torch.cat([x, x.new_zeros(per - x.shape[0], x.shape[1])], 0)

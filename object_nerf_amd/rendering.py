@@ -97,11 +97,11 @@ def render_rays(
     # test hook: pre-drawn random tensors {"perturb_rand","u_rand","noise":[4]} (never set by the reference callers)
     randoms = dummy_kwargs.get("_randoms", None)
 
-    _lib.require_cuda(rays, "rays")
     if embedding_instance is None:
         raise TypeError("render_rays: embedding_instance is required (models/rendering.py:94 repeats it unconditionally)")
     coarse = models["coarse"]
     coarse._check_no_grad(rays, embedding_instance)
+    _lib.require_cuda(rays, "rays")
     dev = rays.device
     n = rays.shape[0]
     S, I = int(N_samples), int(N_importance)

@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by running the REAL reference (/root/reference, imported through
+oracle/ref_import.py) on the deterministic cases of tests/cases.py.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python oracle/make_golden.py
+The committed vectors pin both the oracle (tests/test_oracle_vs_golden.py, CPU) and the HIP path
+(tests/test_gpu_*.py).  The reference itself ships no golden vectors or tests for this path
+(SURVEY.md §4), so these are outputs of the reference code itself, fp32, torch 2.10 CPU kernels.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref_import  # noqa: E402
+import cases  # noqa: E402
+from object_nerf_amd import synth  # noqa: E402
+from object_nerf_amd.config import AttrDict  # noqa: E402
+
+
+def ref_types(ref):
+    def mk_ev(ch, nf, mv, conf):
+        c = AttrDict(conf)
+        key = "synthetic_%d.ply" % len(ref_import.POINT_CLOUDS)
+        ref_import.POINT_CLOUDS[key] = np.asarray(conf["pcd_xyz"])
+        c["pcd_path"] = key
+        return ref.EmbeddingVoxel(ch, nf, mv, c)
+    return types.SimpleNamespace(ObjectNeRF=ref.ObjectNeRF, Embedding=ref.Embedding, EmbeddingVoxel=mk_ev,
+                                 CodeLibrary=ref.CodeLibrary)
+
+
+def save(name, d):
+    os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
+    arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+    np.savez_compressed(os.path.join(cases.GOLDEN_DIR, name + ".npz"), **arrs)
+    print("wrote %-28s %s" % (name, {k: tuple(a.shape) for k, a in list(arrs.items())[:4]}))
+
+
+def main():
+    torch.set_num_threads(8)
+    ref = ref_import.load_reference()
+    rt = ref_types(ref)
+    scenes = {}
+
+    def scene(name):
+        if name not in scenes:
+            scenes[name] = cases.scene_for(rt, name)
+        return scenes[name]
+
+    with torch.no_grad():
+        # ---- render_rays end to end ----
+        for case, c in cases.RENDER_CASES.items():
+            sc = scene(c["scene"])
+            rays, ids, ptm, randoms = cases.render_inputs(case)
+            codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+            kw = dict(c["kw"])
+            kw.setdefault("perturb", 0)
+            kw.setdefault("noise_std", 0)
+            if ptm is not None:
+                kw["pass_through_mask"] = ptm
+            if randoms is None:
+                out = ref.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, chunk=32768, **kw)
+            else:
+                fi = kw.get("forward_instance", True)
+                nz = randoms["noise"]
+                with ref_import.inject_randoms(rand_like=[randoms["perturb_rand"]], rand=[randoms["u_rand"]],
+                                               randn_like=[nz[0], nz[1], nz[2], nz[3]] if fi else [nz[0], nz[2]]):
+                    out = ref.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, chunk=32768, **kw)
+            out = dict(out)
+            out["_rays"] = rays
+            out["_codes"] = codes
+            save("render_" + case, out)
+
+        # ---- stages ----
+        pe = {}
+        for k, (x, nf) in cases.pe_inputs().items():
+            pe[k] = ref.Embedding(x.shape[1], nf)(x)
+        save("stage_pe", pe)
+
+        pts = cases.voxel_points()
+        for sname in ("voxel", "sparse"):
+            ev = scene(sname).embeddings["xyz"]
+            s_ftr, o_ftr = ev(pts.clone())
+            save("stage_voxel_embed_" + sname, dict(scene_ftr=s_ftr, obj_ftr=o_ftr, idx_map_sum=ev.voxel_idx_map.sum(),
+                                                    occupied=ev.voxel_occupancy.sum(), shape=ev.voxel_shape))
+
+        for sname in ("voxel", "plain"):
+            m = scene(sname).models["coarse"]
+            inp = cases.mlp_inputs(sname == "voxel")
+            o = m({"emb_xyz": inp["emb_xyz"], "emb_dir": inp["emb_dir"]})
+            oi = m.forward_instance(dict(inp))
+            so = m({"emb_xyz": inp["emb_xyz"], "emb_dir": inp["emb_dir"]}, sigma_only=True)
+            assert list(so.keys()) == ["sigma"]
+            save("stage_mlp_" + sname, dict(sigma=o["sigma"], rgb=o["rgb"], inst_sigma=oi["inst_sigma"], inst_rgb=oi["inst_rgb"]))
+
+        bins, w, u = cases.pdf_inputs()
+        det = ref.sample_pdf(bins, w, 64, det=True)
+        with ref_import.inject_randoms(rand=[u]):
+            rnd = ref.sample_pdf(bins, w, u.shape[1], det=False)
+        save("stage_sample_pdf", dict(det=det, rnd=rnd))
+
+        # ---- render_rays_multi ----
+        sc = scene("voxel")
+        sets, boxes = cases.multi_inputs()
+        ref_boxes = {4: ref_import.make_box(boxes[0])}
+        m = cases.MULTI
+        out = ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets], m["obj_ids"],
+                                    N_samples=m["N_samples"], N_importance=m["N_importance"], perturb=0, noise_std=0,
+                                    chunk=32768, white_back=False, background_skip_bbox=ref_boxes)
+        save("multi_scannet_dup", dict(out))
+        out = ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets], m["obj_ids"],
+                                    N_samples=m["N_samples"], N_importance=0, perturb=0, noise_std=0,
+                                    chunk=32768, white_back=True, background_skip_bbox=None)
+        save("multi_coarse_only_white", dict(out))
+        xyz = cases.voxel_points(600).view(20, 30, 3)
+        save("stage_points_in_boxes", dict(inside=ref.check_in_any_boxes(ref_boxes, xyz)))
+
+
+if __name__ == "__main__":
+    main()

@@ -295,7 +295,7 @@ def composite_multi(z_list, rgb_list, sigma_list, noise_std=0.0, white_back=Fals
     rgb = torch.cat(rgb_list, 1)
     sg = torch.cat(sigma_list, 1)
     ids = torch.cat([torch.full_like(s, float(i)) for i, s in enumerate(sigma_list)], 1)
-    z, idx = torch.sort(z, -1, stable=True)
+    z, idx = torch.sort(z, dim=-1, stable=True)
     rgb = torch.gather(rgb, 1, idx[..., None].expand(-1, -1, 3))
     sg = torch.gather(sg, 1, idx)
     ids = torch.gather(ids, 1, idx)

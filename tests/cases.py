@@ -1,0 +1,146 @@
+"""Deterministic parity cases shared by oracle/make_golden.py (which runs the REFERENCE on them and
+commits the outputs under tests/golden/) and by the tests (which run the oracle and the HIP path
+on the same inputs).  Inputs are regenerated from seeds; only reference OUTPUTS are stored."""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from object_nerf_amd import synth  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+N_RAYS = 48
+MAX_VOXELS = 120_000
+
+# scene variants: name -> (use_voxel, n_points of the synthetic cloud)
+SCENES = {"voxel": (True, 200_000), "plain": (False, 0), "sparse": (True, 1500)}
+
+# render_rays cases: scene, kwargs for render_rays, extras
+RENDER_CASES = {
+    # BASELINE configs[1]-like: scene + object, 64+64, eval
+    "voxel_eval": dict(scene="voxel", kw=dict(N_samples=64, N_importance=64, is_eval=True)),
+    "plain_eval": dict(scene="plain", kw=dict(N_samples=64, N_importance=64, is_eval=True)),
+    # BASELINE configs[0]: scene branch only, 64 coarse
+    "voxel_scene_only": dict(scene="voxel", kw=dict(N_samples=64, N_importance=0, forward_instance=False, is_eval=True)),
+    # training-time flags: occlusion mask + pass-through + rays_in_bbox weights overwrite + white background
+    "voxel_train_flags": dict(scene="voxel", ptm=True,
+                              kw=dict(N_samples=64, N_importance=64, is_eval=False, frustum_bound_th=0.025,
+                                      rays_in_bbox=True, white_back=True)),
+    "voxel_disp_zero": dict(scene="voxel", kw=dict(N_samples=64, N_importance=64, use_disp=True,
+                                                   use_zero_as_last_delta=True, is_eval=True)),
+    # BASELINE configs[2]: 5 object codes, 64+128, frustum bound, val-time use_bbox
+    "voxel_imp128": dict(scene="voxel", kw=dict(N_samples=64, N_importance=128, is_eval=True, frustum_bound_th=0.025,
+                                                rays_in_bbox=True)),
+    # empty voxels and rays leaving the grid
+    "sparse_eval": dict(scene="sparse", far=6.0, kw=dict(N_samples=64, N_importance=64, is_eval=True)),
+    # RNG paths with injected draws: perturb > 0 (rendering.py:268-277, 40) and noise_std > 0 (156, 187)
+    "voxel_random": dict(scene="voxel", ptm=True, randoms=True,
+                         kw=dict(N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0, is_eval=False,
+                                 frustum_bound_th=0.025)),
+    "plain_odd_sizes": dict(scene="plain", kw=dict(N_samples=40, N_importance=24, is_eval=True)),
+}
+
+
+def scene_for(types, name, device="cpu"):
+    use_voxel, n_points = SCENES[name]
+    return synth.build_scene(types, use_voxel, max_voxels=MAX_VOXELS, n_points=max(n_points, 1), device=device)
+
+
+def render_inputs(case):
+    """rays (N,8), per-ray ids (N), pass_through_mask (N,1) or None, randoms dict or None"""
+    c = RENDER_CASES[case]
+    far = c.get("far", 3.0)
+    rays_all = synth.camera_rays(64, 48, far=far)
+    idx = torch.arange(0, rays_all.shape[0], 61)[:N_RAYS]
+    rays = rays_all[idx].contiguous()
+    n = rays.shape[0]
+    ids = synth.per_ray_ids(n, seed=3)
+    ptm = (torch.arange(n) % 3 == 0).view(n, 1) if c.get("ptm") else None
+    randoms = None
+    if c.get("randoms"):
+        g = torch.Generator().manual_seed(11)
+        S, I = c["kw"]["N_samples"], c["kw"]["N_importance"]
+        randoms = dict(perturb_rand=torch.rand(n, S, generator=g), u_rand=torch.rand(n, I, generator=g),
+                       noise=[torch.randn(n, S, generator=g), torch.randn(n, S, generator=g),
+                              torch.randn(n, S + I, generator=g), torch.randn(n, S + I, generator=g)])
+    return rays, ids, ptm, randoms
+
+
+# ---- stage-level inputs -----------------------------------------------------------------------------
+def pe_inputs():
+    g = torch.Generator().manual_seed(21)
+    return {"xyz10": (torch.randn(200, 3, generator=g) * 1.5, 10), "dir4": (torch.randn(120, 3, generator=g), 4),
+            "vox6": (torch.randn(90, 16, generator=g) * 2.0, 6)}
+
+
+def voxel_points(n=400):
+    """points inside, near the faces of, and outside the normalised room"""
+    g = torch.Generator().manual_seed(22)
+    lo, hi = torch.tensor([-1.3, -1.3, -0.3]), torch.tensor([2.3, 2.3, 1.6])
+    p = lo + (hi - lo) * torch.rand(n, 3, generator=g)
+    p[:8] = torch.tensor([[-1.0, -1.0, 0.0], [2.0, 2.0, 1.25], [-1.0, 2.0, 0.0], [0.0, 0.0, 0.0],
+                          [1e3, 0.0, 0.0], [-1e3, 5.0, 0.5], [0.5, 0.5, -5.0], [0.05, 0.05, 0.05]])
+    return p
+
+
+def mlp_inputs(use_voxel, n=200):
+    g = torch.Generator().manual_seed(23)
+    return dict(emb_xyz=torch.randn(n, 271 if use_voxel else 63, generator=g), emb_dir=torch.randn(n, 27, generator=g),
+                obj_voxel=torch.randn(n, 104, generator=g) if use_voxel else None, obj_code=torch.randn(n, 64, generator=g))
+
+
+def pdf_inputs():
+    g = torch.Generator().manual_seed(24)
+    n, nb = 37, 63
+    bins = torch.sort(torch.rand(n, nb, generator=g) * 3.0, -1)[0]
+    w = torch.rand(n, nb - 1, generator=g) ** 4
+    w[::3, 10:30] = 0.0        # empty bins -> denom < eps branch (rendering.py:53-54)
+    w[5] = 0.0                 # all-zero row
+    u = torch.rand(n, 50, generator=g)
+    return bins, w, u
+
+
+# ---- multi-object case (render_rays_multi, BASELINE configs[4]: ids [0,4,4]) ----------------------------
+MULTI = dict(obj_ids=[0, 4, 4], N_samples=64, N_importance=64, n_rays=40)
+
+
+def multi_inputs():
+    n = MULTI["n_rays"]
+    rays_all = synth.camera_rays(64, 48, far=3.0)
+    idx = torch.arange(0, rays_all.shape[0], 73)[:n]
+    bg = rays_all[idx].contiguous()
+    sets = [bg]
+    for k, (shift, near, far) in enumerate([((0.05, 0.10, 0.0), 0.613, 1.707), ((-0.05, -0.20, 0.0), 0.917, 2.231)]):
+        r = bg.clone()
+        r[:, 0:3] += torch.tensor(shift)
+        ang = math.radians(10.0 * (k + 1))
+        R = torch.tensor([[math.cos(ang), -math.sin(ang), 0], [math.sin(ang), math.cos(ang), 0], [0, 0, 1]],
+                         dtype=torch.float32)
+        r[:, 3:6] = r[:, 3:6] @ R.T
+        r[:, 6], r[:, 7] = near, far
+        miss = (torch.arange(n) % (4 + k)) == 0        # rays that miss the object's box: near = far = 0
+        r[miss, 6:8] = 0.0
+        sets.append(r.contiguous())
+    # Exact z ties between DIFFERENT sets are resolved by torch.sort's unspecified (unstable) order in
+    # the reference (multi_rendering.py:112) and by set order here; the near/far values above avoid them
+    # (asserted below).  Ties at z == 0 (rays that miss their box) remain: they carry zero weight.
+    zc = [r[:, 6:7] + (r[:, 7:8] - r[:, 6:7]) * torch.linspace(0, 1, MULTI["N_samples"]) for r in sets]
+    for a in range(3):
+        for b in range(a + 1, 3):
+            tie = (zc[a][:, :, None] == zc[b][:, None, :]) & (zc[a][:, :, None] != 0)
+            assert not tie.any(), "multi_inputs: cross-set z tie"
+    box = synth.oriented_box(center=[2.9, 3.1, 0.5], size=[1.0, 0.8, 1.0], yaw_deg=20.0,
+                             scene_center=synth.SCANNET_LIKE["scene_center"], scale_factor=synth.SCANNET_LIKE["scale_factor"])
+    return sets, [box]
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    z = np.load(path)
+    return {k: torch.from_numpy(z[k]) for k in z.files}

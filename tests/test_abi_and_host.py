@@ -1,0 +1,131 @@
+"""CPU: the C-ABI library loads and exports every symbol include/objnerf_hip.h declares, the
+weight-packing index maps are a bijection onto the reference's parameter tensors, and the host-side
+plumbing (module types, error behaviour, sharding arithmetic) behaves.  No kernel is launched."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import cases
+import helpers as H
+import object_nerf_amd as A
+from object_nerf_amd import _lib, synth
+from object_nerf_amd.distributed import shard_bounds
+from object_nerf_amd.nerf_model import PARAM_LAYERS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "objnerf_hip.h")).read()
+    declared = set(re.findall(r"\b(objnerf_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    l = _lib.lib()
+    assert l.objnerf_abi_version() == 1
+    assert l.objnerf_blob_floats(1) == 111 * 8192 and l.objnerf_blob_floats(0) == 87 * 8192
+    assert l.objnerf_num_param_ptrs() == 2 * len(PARAM_LAYERS) == 40
+
+
+@pytest.mark.parametrize("use_voxel", [True, False])
+def test_pack_index_is_a_bijection(use_voxel):
+    """every element of every nn.Linear weight/bias appears exactly once in blob+aux; the rest is padding"""
+    l = _lib.lib()
+    uv = int(use_voxel)
+    nb, na = l.objnerf_blob_floats(uv), l.objnerf_aux_floats()
+    bi = torch.empty(nb, dtype=torch.int32)
+    ai = torch.empty(na, dtype=torch.int32)
+    assert l.objnerf_pack_index(uv, C.c_void_p(bi.data_ptr()), C.c_void_p(ai.data_ptr())) == 0
+    allidx = torch.cat([bi, ai]).to(torch.int64) & 0xFFFFFFFF
+    used = allidx[allidx != 0xFFFFFFFF]
+    m = A.ObjectNeRF(A.default_model_config(use_voxel_embedding=use_voxel))
+    params = m._param_list()
+    total = 0
+    for pid, p in enumerate(params):
+        assert p.numel() == l.objnerf_param_numel(uv, pid)
+        offs = used[(used >> 24) == pid] & 0xFFFFFF
+        assert offs.numel() == p.numel(), (pid, offs.numel(), p.numel())
+        assert torch.equal(torch.sort(offs)[0], torch.arange(p.numel()))
+        total += p.numel()
+    assert used.numel() == total == sum(p.numel() for p in m.parameters())
+    # weights live in the stream, biases and heads in the aux block
+    assert set(((bi.to(torch.int64) & 0xFFFFFFFF)[bi != -1] >> 24).unique().tolist()) <= set(range(0, 40, 2))
+
+
+def test_module_types_and_state_dict_names():
+    sc = cases.scene_for(A, "voxel")
+    m = sc.models["coarse"]
+    names = set(m.state_dict())
+    for lname in PARAM_LAYERS:
+        assert lname + ".weight" in names and lname + ".bias" in names
+    assert m.in_channels_xyz == 271 and m.inst_channel_in == 439 and m.in_channels_dir == 27
+    assert sum(p.numel() for p in m.parameters()) == 891_208          # SURVEY.md §2.3 [probed]
+    ev = sc.embeddings["xyz"]
+    for b in ("voxel_size", "bounds", "voxel_offset", "voxel_shape", "voxel_count", "voxel_occupancy", "voxel_idx_map"):
+        assert b in dict(ev.named_buffers())
+    assert ev.voxel_idx_map.dtype == torch.int64 and ev.embedding_space_ftr.weight.shape == (cases.MAX_VOXELS, 24)
+    assert sc.code_library({"instance_ids": torch.tensor([[1], [3]])})["embedding_instance"].shape == (2, 64)
+    assert sc.code_library({}) == {}
+    assert A.Embedding(3, 10).out_channels == 63 and A.Embedding(3, 4).out_channels == 27
+    plain = A.ObjectNeRF(A.default_model_config(use_voxel_embedding=False))
+    assert plain.in_channels_xyz == 63 and plain.inst_channel_in == 127
+    assert sum(p.numel() for p in plain.parameters()) == 704_840
+
+
+def test_unsupported_architecture_is_rejected():
+    with pytest.raises(NotImplementedError):
+        A.ObjectNeRF(A.default_model_config(W=128))
+    with pytest.raises(NotImplementedError):
+        A.Embedding(3, 4, logscale=False)
+
+
+def test_no_silent_cpu_fallback():
+    """CPU tensors must raise, not compute: the HIP path is the only path"""
+    sc = cases.scene_for(A, "plain")
+    rays = H.test_rays(8)
+    codes = torch.zeros(8, 64)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="GPU"):
+            A.render_rays(sc.models, sc.embeddings, rays, N_samples=8, embedding_instance=codes, noise_std=0)
+        with pytest.raises(RuntimeError, match="GPU"):
+            sc.models["coarse"]({"emb_xyz": torch.zeros(4, 63), "emb_dir": torch.zeros(4, 27)})
+        with pytest.raises(RuntimeError, match="GPU"):
+            A.Embedding(3, 4)(torch.zeros(4, 3))
+        with pytest.raises(TypeError):
+            A.render_rays(sc.models, sc.embeddings, rays, N_samples=8, noise_std=0)      # embedding_instance missing
+    with pytest.raises(NotImplementedError):      # autograd requested -> loud refusal, no torch fallback
+        A.render_rays(sc.models, sc.embeddings, rays, N_samples=8, embedding_instance=codes, noise_std=0)
+
+
+def test_attrdict_access_forms():
+    c = A.default_model_config()
+    assert c.D == c["D"] == c.get("D", 0) == 8 and c.get("missing", 7) == 7
+    with pytest.raises(AttributeError):
+        c.missing
+
+
+def test_shard_bounds_cover_all_rays():
+    for n in (0, 1, 7, 307200, 307201):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert max(hi - lo for lo, hi in spans) == (n + world - 1) // world
+
+
+def test_c_abi_argument_validation():
+    """entry points reject bad arguments with an error string instead of launching"""
+    l = _lib.lib()
+    a = _lib.MlpArgs()
+    assert l.objnerf_mlp_eval(C.byref(a), None) < 0
+    assert b"null weights" in l.objnerf_last_error()
+    assert l.objnerf_sample_coarse(None, None, None, 0.0, 0, 4, 8, None, None) < 0
+    assert l.objnerf_sample_pdf_merge(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None) < 0
+    cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * 128 * 8 + 256

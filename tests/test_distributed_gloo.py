@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the ray-sharding + pixel all-gather wrapper (the N>1 path of
+bench.py / SURVEY.md §8e).  The renderer itself needs a GPU, so a per-ray stand-in function plays
+its role here; what is tested is the partitioning, padding of short shards and the collective."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from object_nerf_amd.distributed import gather_pixels, render_rays_sharded, shard_rays
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_render(rays, embedding_instance=None, scale=1.0, **kw):
+    # any function that is independent per ray
+    rgb = torch.stack([rays[:, 0] * scale, rays[:, 3] + embedding_instance[:, 0], rays[:, 7]], -1)
+    return {"rgb_fine": rgb, "depth_fine": rays[:, 6] * 2, "weights_fine": rays[:, :4]}
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        rays = torch.randn(n, 8, generator=g)
+        codes = torch.randn(n, 64, generator=g)
+        full = _fake_render(rays, codes, scale=3.0)
+        out = render_rays_sharded(_fake_render, rays, {"embedding_instance": codes}, scale=3.0,
+                                  gather_keys=("rgb_fine", "depth_fine"))
+        ok = torch.equal(out["rgb_fine"], full["rgb_fine"]) and torch.equal(out["depth_fine"], full["depth_fine"])
+        ok = ok and "weights_fine" not in out
+        r_loc, ex = shard_rays(rays, {"embedding_instance": codes, "flag": 1.5})
+        ok = ok and ex["flag"] == 1.5 and ex["embedding_instance"].shape[0] == r_loc.shape[0]
+        ok = ok and torch.equal(gather_pixels(r_loc[:, 0], n), rays[:, 0])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10, 7, 1])
+def test_sharded_render_world2(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
