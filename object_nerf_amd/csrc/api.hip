@@ -122,6 +122,7 @@ int objnerf_pack_index(int use_voxel, uint32_t* blob_idx, uint32_t* aux_idx) {
 
 int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (!a || !a->blob || !a->aux) return set_error(-1, "mlp_eval: null weights");
+  if ((a->emb_xyz == nullptr ? a->n_rays * (int64_t)a->S : a->n_points) == 0) return 0;   // nothing to do
   if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
   if (a->do_scene && !a->sigma) return set_error(-1, "mlp_eval: scene branch needs a sigma output");
   if (a->do_object && !a->inst_sigma) return set_error(-1, "mlp_eval: object branch needs an inst_sigma output");

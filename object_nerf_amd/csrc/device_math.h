@@ -12,12 +12,26 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // sin / cos with 3-term Cody-Waite reduction by pi/2 and the classic degree-7/8 minimax
 // polynomials on [-pi/4, pi/4] (abs error ~1e-7 for |x| < 2^15, i.e. f32-roundoff class;
 // the reference calls torch.sin/torch.cos, embedding_helper.py:69-74).
-// Arguments beyond 2^15 (never produced by 2^k * coordinate; only reachable by a learned voxel
-// feature > 1024) are answered branch-free by the hardware v_sin/v_cos on fract(x / 2pi), whose
-// abs error there is ~1e-3 (documented limitation).
+// The reduction is exact-product safe while n = x * 2/pi < 2^16, i.e. |x| < 65536 (2^9 * coordinate
+// stays below that for |coordinate| < 128 normalised units; a learned voxel feature would have to
+// exceed 2048).  Beyond it:
+//   EXACT_BIG = true  (stand-alone embedding kernels): branch to OCML sinf/cosf (Payne-Hanek);
+//   EXACT_BIG = false (fused MLP kernel, where a branch would split the MFMA schedule): answered
+//     branch-free by the hardware v_sin/v_cos on fract(x / 2pi), abs error up to ~1e-2 for such
+//     arguments (documented limitation).
 struct SinCos { float s, c; };
+constexpr float kSinCosBig = 65536.0f;
 
+template <bool EXACT_BIG = false>
 __device__ __forceinline__ SinCos psincos(float x) {
+  if constexpr (EXACT_BIG) {
+    if (__builtin_expect(!(fabsf(x) < kSinCosBig), 0)) {
+      SinCos o;
+      o.s = sinf(x);
+      o.c = cosf(x);
+      return o;
+    }
+  }
   const float n = rintf(x * 0.636619772367581343f);
   float r = fmaf(-n, 1.5703125f, x);
   r = fmaf(-n, 4.837512969970703125e-4f, r);
@@ -35,14 +49,14 @@ __device__ __forceinline__ SinCos psincos(float x) {
   const float c1 = (q & 1) ? s : c;
   o.s = (q & 2) ? -s1 : s1;
   o.c = ((q + 1) & 2) ? -c1 : c1;
-  const bool big = !(fabsf(x) < 32768.0f);
-  const float rev = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
-  o.s = big ? __builtin_amdgcn_sinf(rev) : o.s;
-  o.c = big ? __builtin_amdgcn_cosf(rev) : o.c;
+  if constexpr (!EXACT_BIG) {
+    const bool big = !(fabsf(x) < kSinCosBig);
+    const float rev = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+    o.s = big ? __builtin_amdgcn_sinf(rev) : o.s;
+    o.c = big ? __builtin_amdgcn_cosf(rev) : o.c;
+  }
   return o;
 }
-__device__ __forceinline__ float psin(float x) { return psincos(x).s; }
-__device__ __forceinline__ float pcos(float x) { return psincos(x).c; }
 
 // nn.LeakyReLU() default slope 0.01 (nerf_model.py:38)
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.01f * v); }

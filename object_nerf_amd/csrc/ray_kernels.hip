@@ -72,7 +72,7 @@ __global__ void pos_encode_kernel(const float* __restrict__ x, long n, int C, in
   o[c] = v;
   float f = 1.f;
   for (int k = 0; k < F; ++k) {
-    const SinCos sc = psincos(f * v);
+    const SinCos sc = psincos<true>(f * v);
     o[C * (1 + 2 * k) + c] = sc.s;
     o[C * (2 + 2 * k) + c] = sc.c;
     f *= 2.f;
@@ -126,7 +126,7 @@ __global__ void voxel_embed_kernel(const objnerf_voxel_grid g, const float* __re
     o[cc] = f[c];
     float fr = 1.f;
     for (int k = 0; k < kFreqVox; ++k) {
-      const SinCos sc = psincos(fr * f[c]);
+      const SinCos sc = psincos<true>(fr * f[c]);
       o[C * (1 + 2 * k) + cc] = sc.s;
       o[C * (2 + 2 * k) + cc] = sc.c;
       fr *= 2.f;
@@ -139,7 +139,7 @@ __global__ void voxel_embed_kernel(const objnerf_voxel_grid g, const float* __re
     xo[c] = pos[c];
     float fr = 1.f;
     for (int k = 0; k < kFreqXyz; ++k) {
-      const SinCos sc = psincos(fr * pos[c]);
+      const SinCos sc = psincos<true>(fr * pos[c]);
       xo[3 * (1 + 2 * k) + c] = sc.s;
       xo[3 * (2 + 2 * k) + c] = sc.c;
       fr *= 2.f;

@@ -170,6 +170,8 @@ class ObjectNeRF(nn.Module):
         a.emb_xyz, a.emb_dir, a.n_points = exyz.data_ptr(), edir.data_ptr(), n
         sig = torch.empty(n, 1, dtype=torch.float32, device=dev)
         rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        if n == 0:
+            return sig, rgb
         keep = [exyz, edir]
         if scene:
             a.sigma, a.rgb = sig.data_ptr(), rgb.data_ptr()

@@ -35,3 +35,27 @@ def scene(use_voxel=True, device="cpu", max_voxels=120000, n_points=200_000, pre
 def normwise(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def cdf_position(bins, weights, z, eps=1e-5):
+    """F(z): position of samples z (N,I) on the float64 piecewise-linear CDF that sample_pdf inverts
+    (bins (N,nb), weights (N,nb-1)); used to grade samplers in the well-conditioned domain."""
+    bins, w, z = bins.double(), weights.double() + eps, z.double()
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    idx = (torch.searchsorted(bins.contiguous(), z.contiguous(), right=True) - 1).clamp(0, bins.shape[1] - 2)
+    b0, b1 = torch.gather(bins, 1, idx), torch.gather(bins, 1, idx + 1)
+    c0, c1 = torch.gather(cdf, 1, idx), torch.gather(cdf, 1, idx + 1)
+    t = ((z - b0) / (b1 - b0).clamp_min(1e-300)).clamp(0, 1)
+    return c0 + t * (c1 - c0)
+
+
+def sampler_residual(bins, weights, u, z, eps=1e-5):
+    """Per-sample grade of an inverse-CDF sampler, robust to both kinds of ill-conditioning:
+    flat CDF (tiny pdf: z is sensitive, F(z) is not) and steep CDF (narrow heavy bin: F(z) is
+    sensitive to one ulp of z, z is not).  Returns min(|F64(z) - u|, |z - z64| / max|bins|)."""
+    from oracle import objnerf_oracle as O
+    q = cdf_position(bins, weights, z, eps)
+    z64 = O.sample_pdf(bins.double(), weights.double(), u.shape[1], det=False, eps=eps, u=u.double())
+    rz = (z.double() - z64).abs() / bins.double().abs().max()
+    return torch.minimum((q - u.double()).abs(), rz)
