@@ -144,7 +144,7 @@ def main():
                        "collective": "all_gather_into_tensor(rgb_fine) over RCCL" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "objnerf::mlp_kernel<voxel,fused,scene,object>",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(),
                          "launches": int(launches.value), "avg_launch_ms": kms.value / max(1, launches.value),
                          "flop_per_eval": FLOP_PER_EVAL_BOTH_VOXEL, "mlp_time_frac_of_step": mlp_s / elapsed},
         }
@@ -157,6 +157,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return res
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the MLP kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE, separate passes; profiles/r*_pmc.json, tools/pmc_run.sh).  bench.py
+    cannot collect PMC counters on itself, so this is the latest profiled value of the same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))["derived"]
+        return {"bytes_per_launch": d["hbm_traffic_bytes_per_launch"], "bytes_per_unit": d["hbm_traffic_bytes_per_eval"],
+                "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
 
 
 def cpu_baseline(sc, rays, codes, kw, n_sample, evals_per_ray):
