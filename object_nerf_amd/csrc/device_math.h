@@ -16,9 +16,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // stays below that for |coordinate| < 128 normalised units; a learned voxel feature would have to
 // exceed 2048).  Beyond it:
 //   EXACT_BIG = true  (stand-alone embedding kernels): branch to OCML sinf/cosf (Payne-Hanek);
-//   EXACT_BIG = false (fused MLP kernel, where a branch would split the MFMA schedule): answered
-//     branch-free by the hardware v_sin/v_cos on fract(x / 2pi), abs error up to ~1e-2 for such
-//     arguments (documented limitation).
+//   EXACT_BIG = false (fused MLP kernel): no special handling -- fp32 MFMA and VALU share the
+//     SIMD's ALUs (PMC: MFMA-busy + VALU-active + waits = 100 %), so every VALU instruction here
+//     costs MFMA time.  Accuracy then degrades progressively with |x| / 65536 (output stays
+//     bounded); unreachable by 2^k * coordinate inside a scene (documented limitation).
 struct SinCos { float s, c; };
 constexpr float kSinCosBig = 65536.0f;
 
@@ -49,12 +50,6 @@ __device__ __forceinline__ SinCos psincos(float x) {
   const float c1 = (q & 1) ? s : c;
   o.s = (q & 2) ? -s1 : s1;
   o.c = ((q + 1) & 2) ? -c1 : c1;
-  if constexpr (!EXACT_BIG) {
-    const bool big = !(fabsf(x) < kSinCosBig);
-    const float rev = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
-    o.s = big ? __builtin_amdgcn_sinf(rev) : o.s;
-    o.c = big ? __builtin_amdgcn_cosf(rev) : o.c;
-  }
   return o;
 }
 

@@ -116,9 +116,12 @@ OBJ_HD constexpr int objin_slot_col(bool voxel, int i, int h) {
 // One "A tile" = 64 floats (lane l: W[32 m + (l & 31)][kcol(ks, l >> 5)]).  A chunk = 128 A tiles
 // = 32 KiB = (128 / NT) k-steps x NT out tiles, laid out [ks/4][m][lane][ks%4] so that one
 // ds_read_b128 per out tile feeds 4 consecutive k-steps.  Every layer is padded to whole chunks.
-constexpr int kChunkTiles = 128;
-constexpr int kChunkFloats = kChunkTiles * 64;      // 8192
-constexpr int kChunkBytes = kChunkFloats * 4;       // 32768
+#ifndef OBJ_CHUNK_TILES
+#define OBJ_CHUNK_TILES 128
+#endif
+constexpr int kChunkTiles = OBJ_CHUNK_TILES;        // 128 -> 32 KiB chunks
+constexpr int kChunkFloats = kChunkTiles * 64;
+constexpr int kChunkBytes = kChunkFloats * 4;
 
 enum LayerId {
   L_S1 = 0, L_S2, L_S3, L_S4, L_S5, L_S6, L_S7, L_S8, L_SF, L_SD,

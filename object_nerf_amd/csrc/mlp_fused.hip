@@ -11,6 +11,11 @@ static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStr
 
 int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
+#ifdef OBJ_TUNE_ONLY_MAIN   // tuning builds (tools/tune_mlp.py): only the bench instantiation, to compile fast
+  if (!(a.use_voxel && sc && ob)) return set_error(-9, "tuning build: only voxel scene+object is compiled");
+  launch<true, true, true>(a, ntiles, grid, s);
+  return check_launch("mlp_eval(fused)");
+#else
   if (a.use_voxel) {
     if (sc && ob) launch<true, true, true>(a, ntiles, grid, s);
     else if (sc) launch<true, true, false>(a, ntiles, grid, s);
@@ -21,6 +26,7 @@ int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipS
     else launch<false, false, true>(a, ntiles, grid, s);
   }
   return check_launch("mlp_eval(fused)");
+#endif
 }
 
 }  // namespace objnerf

