@@ -64,9 +64,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("OBJNERF_BENCH_FORCE_DIST") == "1":
+        # launched by torch.distributed.run: exercise the RCCL path even at world size 1
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist_mod.init_process_group("nccl", rank=rank, world_size=world)
         dist = dist_mod
@@ -141,7 +143,7 @@ def main():
                                    % (args.width, args.height, S, I),
                        "rays_per_step_per_gpu": n, "evals_per_ray": evals_per_ray,
                        "rays_per_s": world * n * args.steps / elapsed,
-                       "collective": "all_gather_into_tensor(rgb_fine) over RCCL" if world > 1 else "none"},
+                       "collective": "all_gather_into_tensor(rgb_fine) over RCCL" if dist is not None else "none"},
             "roofline": {"bound": "mfma", "kernel": "objnerf::mlp_kernel<voxel,fused,scene,object>",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(),

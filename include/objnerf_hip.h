@@ -110,6 +110,10 @@ typedef struct {
   float* rgb;
   float* inst_sigma;
   float* inst_rgb;
+  /* memory form only: evaluate just the density head of the selected branch (nerf_model.py:111-112,
+   * 142-143 `sigma_only=True`, used by tools/extract_mesh.py:85-108): the final / direction / rgb
+   * layers are skipped (scene branch: 597,760 instead of 699,904 MAC per point) */
+  int32_t sigma_only;
 } objnerf_mlp_args;
 int objnerf_mlp_eval(const objnerf_mlp_args* args, void* stream);
 
@@ -196,6 +200,16 @@ typedef struct {
   float* const* h_own_weights;  /* may be NULL */
 } objnerf_composite_multi_args;
 int objnerf_composite_multi(const objnerf_composite_multi_args* args, void* stream);
+
+/* Ray generation for the editor: one kernel replaces get_ray_directions + get_rays
+ * (datasets/ray_utils.py:5-51), EditableRenderer.generate_rays (render_tools/editable_renderer.py:153-181) and
+ * the CPU numba slab test behind it (utils/bbox_utils.py:100-117,132-156; datasets/geo_utils.py:111-162).
+ * h_c2w: HOST 12 floats, the (3,4) camera-to-object matrix `Toc` (translation already / scale_factor).
+ * h_box: HOST OBJNERF_BOX_DOUBLES doubles or NULL.  NULL: near/far are the given constants (background set);
+ * else near/far = ray/box entry/exit in float64 (bounds grown by bbox_enlarge when > 0) / scale_factor, and 0/0
+ * for rays that miss the box or start inside it.  rays: (H*W, 8) row-major pixel order. */
+int objnerf_generate_rays(int H, int W, float focal, const float* h_c2w, float near, float far,
+                          const double* h_box, double bbox_enlarge, float* rays, void* stream);
 
 /* ---- whole render_rays (models/rendering.py:233-337) in one enqueue ---- */
 typedef struct {

@@ -41,6 +41,7 @@ class MlpArgs(C.Structure):
         ("emb_xyz", C.c_void_p), ("emb_dir", C.c_void_p), ("obj_voxel", C.c_void_p), ("obj_code", C.c_void_p),
         ("n_points", C.c_int64),
         ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
+        ("sigma_only", C.c_int32),
     ]
 
 
@@ -118,6 +119,7 @@ SIGNATURES = {
     "objnerf_mask_sigma": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_int, _VP]),
     "objnerf_points_in_boxes": (C.c_int, [_VP, C.c_int64, _VP, C.c_int, _VP, _VP]),
     "objnerf_composite_multi": (C.c_int, [C.POINTER(CompositeMultiArgs), _VP]),
+    "objnerf_generate_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, C.c_float, C.c_float, _VP, C.c_double, _VP, _VP]),
     "objnerf_render_workspace_bytes": (C.c_int64, [C.POINTER(RenderCfg), C.c_int64]),
     "objnerf_render_rays": (C.c_int, [C.POINTER(RenderCfg), C.POINTER(RenderIn), C.POINTER(RenderOut), C.POINTER(RenderOut), _VP]),
     "objnerf_timing_enable": (C.c_int, [C.c_int]),

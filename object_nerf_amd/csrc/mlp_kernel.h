@@ -502,8 +502,9 @@ __device__ __forceinline__ VoxelCell voxel_cell(const objnerf_voxel_grid& g, flo
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ>
+template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles) {
+  static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read of a glds
   // pipeline, guide §5 "three .s-level traps"): [2-slot weight ring | aux block]
   __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)];
@@ -513,7 +514,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   const int wave = tid >> 6;
 
   constexpr int kStart = DO_SCENE ? 0 : scene_chunks(VOXEL);
-  constexpr int kEnd = DO_OBJ ? total_chunks(VOXEL) : scene_chunks(VOXEL);
+  constexpr int kEnd = SIGMA_ONLY ? layer_chunk_start(VOXEL, DO_SCENE ? L_SF : L_OF)
+                                  : (DO_OBJ ? total_chunks(VOXEL) : scene_chunks(VOXEL));
   WeightStream st;
   st.init((const char*)a.blob + (size_t)kStart * kChunkBytes, kEnd - kStart,
           (lds_char*)ring_mem, tid);
@@ -612,6 +614,9 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       }
       // sigma head (no activation, nerf_model.py:108)
       const float sg = head_dot<8>(h, aux + kAuxSSig, half) + aux[kAuxSSig + 8 * 32];
+      if constexpr (SIGMA_ONLY) {
+        if (valid && half == 0) a.sigma[p] = sg;
+      } else {
       // xyz_encoding_final (no activation)
       load_bias<8>(acc, aux, L_SF, half);
       { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
@@ -629,6 +634,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       if (valid && half == 0) {
         a.sigma[p] = sg;
         if (a.rgb) { a.rgb[p * 3 + 0] = col[0]; a.rgb[p * 3 + 1] = col[1]; a.rgb[p * 3 + 2] = col[2]; }
+      }
       }
     }
 
@@ -650,6 +656,9 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
       finish<4, true>(acc, h);
       const float sg = head_dot<4>(h, aux + kAuxOSig, half) + aux[kAuxOSig + 4 * 32];
+      if constexpr (SIGMA_ONLY) {
+        if (valid && half == 0) a.inst_sigma[p] = sg;
+      } else {
       load_bias<4>(acc, aux, L_OF, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
       finish<4, false>(acc, h);
@@ -665,6 +674,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       if (valid && half == 0) {
         a.inst_sigma[p] = sg;
         if (a.inst_rgb) { a.inst_rgb[p * 3 + 0] = col[0]; a.inst_rgb[p * 3 + 1] = col[1]; a.inst_rgb[p * 3 + 2] = col[2]; }
+      }
       }
     }
   }

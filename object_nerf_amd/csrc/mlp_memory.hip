@@ -9,7 +9,10 @@ namespace objnerf {
 #ifndef OBJ_TUNE_STUB_MEMORY
 template <bool VOXEL, bool SC, bool OB>
 static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((mlp_kernel<VOXEL, false, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  if (a.sigma_only)
+    hipLaunchKernelGGL((mlp_kernel<VOXEL, false, SC, OB, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  else
+    hipLaunchKernelGGL((mlp_kernel<VOXEL, false, SC, OB, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
 }
 #endif
 

@@ -377,6 +377,72 @@ __global__ void points_in_boxes_kernel(const float* __restrict__ xyz, long n, co
   inside[idx] = in_any_box(xyz[idx * 3], xyz[idx * 3 + 1], xyz[idx * 3 + 2], boxes, n_boxes) ? 1 : 0;
 }
 
+// Ray generation for one ray set of the editor (datasets/ray_utils.py:5-51, editable_renderer.py:153-181).
+struct GenRaysArgs {
+  int H, W;
+  float focal;
+  float c2w[12];
+  float near, far;
+  int has_box;
+  double box[OBJNERF_BOX_DOUBLES];
+  double enlarge;
+};
+__global__ void generate_rays_kernel(const GenRaysArgs a, float* __restrict__ rays) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)a.H * a.W) return;
+  const int y = (int)(idx / a.W), x = (int)(idx - (long)y * a.W);
+  // directions = [(i - W/2)/focal, -(j - H/2)/focal, -1]   (ray_utils.py:21-23; no +0.5)
+  const float dx = __fdiv_rn((float)x - (float)a.W / 2.f, a.focal);
+  const float dy = -__fdiv_rn((float)y - (float)a.H / 2.f, a.focal);
+  const float dz = -1.f;
+  // rays_d = directions @ c2w[:, :3].T, normalised (ray_utils.py:43-44)
+  float d[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = dx * a.c2w[r * 4 + 0] + dy * a.c2w[r * 4 + 1] + dz * a.c2w[r * 4 + 2];
+  const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = __fdiv_rn(d[r], nrm);
+  const float o[3] = {a.c2w[3], a.c2w[7], a.c2w[11]};
+  float near = a.near, far = a.far;
+  if (a.has_box) {
+    // float64 transform to box coordinates (bbox_utils.py:100-117), slab test (geo_utils.py:126-162)
+    const double* B = a.box;
+    const double sx = (double)o[0] * B[0], sy = (double)o[1] * B[0], sz = (double)o[2] * B[0];
+    const double ax = B[1] * sx + B[2] * sy + B[3] * sz + B[10];
+    const double ay = B[4] * sx + B[5] * sy + B[6] * sz + B[11];
+    const double az = B[7] * sx + B[8] * sy + B[9] * sz + B[12];
+    double ob[3], db[3];
+    ob[0] = B[13] * ax + B[14] * ay + B[15] * az + B[22];
+    ob[1] = B[16] * ax + B[17] * ay + B[18] * az + B[23];
+    ob[2] = B[19] * ax + B[20] * ay + B[21] * az + B[24];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)      // direction: box rotation only (bbox_utils.py:115)
+      db[r] = B[13 + 3 * r] * (double)d[0] + B[14 + 3 * r] * (double)d[1] + B[15 + 3 * r] * (double)d[2];
+    const double e = a.enlarge > 0 ? a.enlarge : 0.0;
+    double tmin = 0, tmax = 0;
+    bool hit = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double dd = db[r] == 0.0 ? 1.0e-14 : db[r];
+      const double inv = 1.0 / dd;
+      const double lo = B[25 + r] - e, hi = B[28 + r] + e;
+      const double t0 = ((inv < 0 ? hi : lo) - ob[r]) * inv;
+      const double t1 = ((inv < 0 ? lo : hi) - ob[r]) * inv;
+      if (r == 0) { tmin = t0; tmax = t1; }
+      else {
+        if (tmin > t1 || t0 > tmax) hit = false;
+        if (t0 > tmin) tmin = t0;
+        if (t1 < tmax) tmax = t1;
+      }
+    }
+    if (tmin < 0 || tmax < 0) hit = false;       // origin inside the box counts as a miss
+    near = hit ? __fdiv_rn((float)tmin, (float)B[0]) : 0.f;
+    far = hit ? __fdiv_rn((float)tmax, (float)B[0]) : 0.f;
+  }
+  float* r = rays + idx * 8;
+  r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2]; r[6] = near; r[7] = far;
+}
+
 // volume_rendering_multi (multi_rendering.py:96-157): joint stable sort by z of K*S samples,
 // gather, composite with last delta 0.  One wave per ray, everything staged in LDS.
 constexpr int kMaxSets = 16;
@@ -546,6 +612,19 @@ int objnerf_points_in_boxes(const float* xyz, int64_t n, const double* boxes, in
   hipLaunchKernelGGL(points_in_boxes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      xyz, (long)n, boxes, n_boxes, inside);
   return check_launch("points_in_boxes");
+}
+
+int objnerf_generate_rays(int H, int W, float focal, const float* h_c2w, float near, float far, const double* h_box,
+                          double bbox_enlarge, float* rays, void* stream) {
+  if (H < 1 || W < 1 || !(focal > 0.f) || !h_c2w || !rays) return set_error(-1, "generate_rays: bad arguments");
+  GenRaysArgs a;
+  a.H = H; a.W = W; a.focal = focal; a.near = near; a.far = far;
+  for (int i = 0; i < 12; ++i) a.c2w[i] = h_c2w[i];
+  a.has_box = h_box != nullptr;
+  for (int i = 0; i < OBJNERF_BOX_DOUBLES; ++i) a.box[i] = h_box ? h_box[i] : 0.0;
+  a.enlarge = bbox_enlarge;
+  hipLaunchKernelGGL(generate_rays_kernel, dim3(blocks_for((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, a, rays);
+  return check_launch("generate_rays");
 }
 
 int objnerf_composite_multi(const objnerf_composite_multi_args* a, void* stream) {

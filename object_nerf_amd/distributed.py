@@ -38,7 +38,7 @@ def gather_pixels(local: torch.Tensor, n_total: int = None) -> torch.Tensor:
     """All-gathers per-ray pixel rows.  `local` is (n_local, C) (or (n_local,)); every rank must
     hold the same n_local except possibly trailing short/empty shards, which are padded to
     ceil(n_total/world) for the collective and trimmed afterwards.  Returns (n_total, C)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     world = dist.get_world_size()
     squeeze = local.dim() == 1

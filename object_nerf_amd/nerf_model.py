@@ -150,7 +150,7 @@ class ObjectNeRF(nn.Module):
                 "object_nerf_amd: the HIP path is forward-only in this round (backward = SURVEY §8 row f1). "
                 "Call under torch.no_grad(); there is deliberately no PyTorch fallback.")
 
-    def _run(self, inputs, scene):
+    def _run(self, inputs, scene, sigma_only=False):
         emb_xyz = inputs["emb_xyz"]
         emb_dir = inputs.get("emb_dir", None)
         self._check_no_grad(emb_xyz, emb_dir)
@@ -165,6 +165,7 @@ class ObjectNeRF(nn.Module):
         a = _lib.MlpArgs()
         a.use_voxel = int(self.use_voxel_embedding)
         a.do_scene, a.do_object = (1, 0) if scene else (0, 1)
+        a.sigma_only = int(bool(sigma_only))
         a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
         exyz, edir = _lib.as_f32(emb_xyz), _lib.as_f32(emb_dir)
         a.emb_xyz, a.emb_dir, a.n_points = exyz.data_ptr(), edir.data_ptr(), n
@@ -188,14 +189,14 @@ class ObjectNeRF(nn.Module):
         return sig, rgb
 
     def forward(self, inputs, sigma_only=False):
-        sig, rgb = self._run(inputs, scene=True)
+        sig, rgb = self._run(inputs, scene=True, sigma_only=sigma_only)
         out = {"sigma": sig}
         if not sigma_only:
             out["rgb"] = rgb
         return out
 
     def forward_instance(self, inputs, sigma_only=False):
-        sig, rgb = self._run(inputs, scene=False)
+        sig, rgb = self._run(inputs, scene=False, sigma_only=sigma_only)
         out = {"inst_sigma": sig}
         if not sigma_only:
             out["inst_rgb"] = rgb

@@ -119,6 +119,20 @@ def main():
                                     N_samples=m["N_samples"], N_importance=0, perturb=0, noise_std=0,
                                     chunk=32768, white_back=True, background_skip_bbox=None)
         save("multi_coarse_only_white", dict(out))
+        # ---- editor ray generation (row f2) ----
+        h, w, focal, Toc, box = cases.raygen_inputs()
+        rg = cases.RAYGEN
+        directions = ref.get_ray_directions(h, w, focal)
+        rays_o, rays_d = ref.get_rays(directions, Toc)
+        bg = torch.cat([rays_o, rays_d, rg["near"] * torch.ones_like(rays_o[:, :1]), rg["far"] * torch.ones_like(rays_o[:, :1])], 1)
+        helper = ref_import.make_box(box)
+        mask, bn, bf = helper.get_ray_bbox_intersections(rays_o, rays_d, box["scale_factor"], bbox_enlarge=rg["bbox_enlarge"])
+        bn[~mask] = torch.zeros_like(bn[~mask])          # editable_renderer.py:175-176
+        bf[~mask] = torch.zeros_like(bf[~mask])
+        obj = torch.cat([rays_o, rays_d, bn, bf], 1)
+        assert 0 < int(mask.sum()) < mask.numel()
+        save("stage_generate_rays", dict(background=bg, object=obj, hit=mask))
+
         xyz = cases.voxel_points(600).view(20, 30, 3)
         save("stage_points_in_boxes", dict(inside=ref.check_in_any_boxes(ref_boxes, xyz)))
 

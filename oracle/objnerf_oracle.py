@@ -265,6 +265,67 @@ def render_rays(params_coarse, params_fine, grid, rays, N_samples=64, use_disp=F
 
 
 # ---------------------------------------------------------------------------------------------
+# ray generation for the editor
+# ---------------------------------------------------------------------------------------------
+def get_ray_directions(H, W, focal):
+    """datasets/ray_utils.py:5-25 (kornia.create_meshgrid(H, W, False): grid[y, x] = (x, y))"""
+    j, i = torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij")
+    return torch.stack([(i - W / 2) / focal, -(j - H / 2) / focal, -torch.ones_like(i)], -1)
+
+
+def get_rays(directions, c2w):
+    """datasets/ray_utils.py:28-51: rotate, normalise, broadcast the origin"""
+    d = directions @ c2w[:, :3].T
+    d = d / torch.norm(d, dim=-1, keepdim=True)
+    o = c2w[:, 3].expand(d.shape)
+    return o.reshape(-1, 3), d.reshape(-1, 3)
+
+
+def ray_box_near_far(rays_o, rays_d, box, bbox_enlarge=0.0):
+    """BBoxRayHelper.get_ray_bbox_intersections (utils/bbox_utils.py:100-117, 132-156) with the slab test of
+    datasets/geo_utils.py:126-162, vectorised in float64.  Returns hit (N) bool, near (N,1), far (N,1) fp32
+    already divided by scale_factor.  Mirrors the reference's quirks: the direction is rotated by the box
+    rotation only (bbox_utils.py:115), zero direction components become 1e-14 (geo_utils.py:131), a ray whose
+    origin is inside the box (tmin < 0) counts as a miss (158-160)."""
+    import numpy as np
+    sf = box["scale_factor"]
+    R_avg, t_avg = np.asarray(box["R_avg"], dtype=np.float64), np.asarray(box["t_avg"], dtype=np.float64)
+    R_box, t_box = np.asarray(box["R_box"], dtype=np.float64), np.asarray(box["t_box"], dtype=np.float64)
+    o = rays_o.detach().cpu().numpy() * sf
+    d = rays_d.detach().cpu().numpy()
+    o = (R_avg @ o.T).T + t_avg
+    o = (R_box @ o.T).T + t_box
+    d = (R_box @ d.T).T
+    lo = np.asarray(box["bmin"], dtype=np.float64) - (bbox_enlarge if bbox_enlarge > 0 else 0.0)
+    hi = np.asarray(box["bmax"], dtype=np.float64) + (bbox_enlarge if bbox_enlarge > 0 else 0.0)
+    d = np.where(d == 0, 1.0e-14, d)
+    inv = 1 / d
+    t0 = (np.where(inv < 0, hi, lo) - o) * inv
+    t1 = (np.where(inv < 0, lo, hi) - o) * inv
+    tmin, tmax = t0[:, 0].copy(), t1[:, 0].copy()
+    hit = np.ones(o.shape[0], dtype=bool)
+    for a in (1, 2):
+        hit &= ~((tmin > t1[:, a]) | (t0[:, a] > tmax))
+        tmin = np.where(t0[:, a] > tmin, t0[:, a], tmin)
+        tmax = np.where(t1[:, a] < tmax, t1[:, a], tmax)
+    hit &= ~((tmin < 0) | (tmax < 0))
+    near = torch.Tensor(np.where(hit, tmin, 0.0)[:, None]) / sf
+    far = torch.Tensor(np.where(hit, tmax, 0.0)[:, None]) / sf
+    return torch.from_numpy(hit), near, far
+
+
+def generate_rays(H, W, focal, c2w, near, far, box=None, bbox_enlarge=0.0):
+    """render_tools/editable_renderer.py:153-181 + 213-215, 257: (H*W, 8) rays of one ray set.
+    box None: constant near/far (background, id 0); else near/far from the box, 0/0 where missed."""
+    o, d = get_rays(get_ray_directions(H, W, focal), c2w)
+    if box is None:
+        n_, f_ = near * torch.ones_like(o[:, :1]), far * torch.ones_like(o[:, :1])
+    else:
+        _, n_, f_ = ray_box_near_far(o, d, box, bbox_enlarge)
+    return torch.cat([o, d, n_, f_], 1)
+
+
+# ---------------------------------------------------------------------------------------------
 # multi-object path
 # ---------------------------------------------------------------------------------------------
 def points_in_boxes(xyz, boxes):

@@ -14,8 +14,10 @@ What it does (SURVEY.md §8c recipe, nothing in the reference tree is modified):
   * inserts empty stub modules for `torch_optimizer`, `open3d` (with
     io.read_point_cloud), `ipdb` so `utils/__init__.py:5`, `utils/util.py:12`,
     `render_tools/multi_rendering.py:1` import;
-  * pre-registers a stub `datasets.geo_utils` (the real one drags in cv2/numba/kornia via
-    datasets/__init__.py) so that the REAL `utils/bbox_utils.py` imports; `make_box()` builds a
+  * registers a `datasets` package object pointing at the reference's datasets/ directory (so that the
+    REAL datasets/geo_utils.py, datasets/ray_utils.py and utils/bbox_utils.py import without running
+    datasets/__init__.py, which drags in cv2/torchvision), an identity `numba.jit`, and a restatement of
+    `kornia.create_meshgrid` (kornia==0.4.1 is a pinned, un-vendored dependency); `make_box()` builds a
     BBoxRayHelper without its file-reading constructor;
   * makes `Tensor.cuda()` / `Module.cuda()` identity when no GPU is visible, because
     `models/embedding_helper.py:103,125,163,166,193,200,367` hard-code `.cuda()`.
@@ -90,17 +92,32 @@ def load_reference():
         # (check_in_any_boxes / check_xyz_in_bounds, bbox_utils.py:158-207) never calls it, so a stub
         # `datasets` package lets the REAL utils/bbox_utils.py import unmodified.
         if "datasets" not in sys.modules:
+            # a package object whose __path__ is the reference's datasets/ directory: submodules
+            # (geo_utils.py, ray_utils.py) import from the REAL files, datasets/__init__.py is never run
             ds = types.ModuleType("datasets")
-            ds.__path__ = []
-            geo = types.ModuleType("datasets.geo_utils")
-
-            def bbox_intersection_batch(*a, **k):
-                raise NotImplementedError("stub: ray/box intersection is outside the oracle's scope")
-
-            geo.bbox_intersection_batch = bbox_intersection_batch
-            ds.geo_utils = geo
+            ds.__path__ = [os.path.join(REF_ROOT, "datasets")]
             sys.modules["datasets"] = ds
-            sys.modules["datasets.geo_utils"] = geo
+        if "numba" not in sys.modules:      # datasets/geo_utils.py:2,111,126: @nb.jit(nopython=True) -> plain Python
+            nb = types.ModuleType("numba")
+            nb.jit = lambda *a, **k: (lambda f: f)
+            sys.modules["numba"] = nb
+        if "kornia" not in sys.modules:
+            # datasets/ray_utils.py:2,17 uses kornia.create_meshgrid (requirements.txt pins kornia==0.4.1, not
+            # vendored, not installed here).  Restatement of its published behaviour for normalized_coordinates=False:
+            # grid[0, y, x] = (x, y) as float32.
+            kn = types.ModuleType("kornia")
+
+            def create_meshgrid(height, width, normalized_coordinates=True, device=None):
+                assert not normalized_coordinates
+                xs = torch.linspace(0, width - 1, width, dtype=torch.float)
+                ys = torch.linspace(0, height - 1, height, dtype=torch.float)
+                gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+                return torch.stack([gx, gy], -1)[None]
+
+            kn.create_meshgrid = create_meshgrid
+            sys.modules["kornia"] = kn
+        import datasets.geo_utils as geo_utils
+        import datasets.ray_utils as ray_utils
         import utils.bbox_utils as bbox_utils
 
         import models.rendering as rendering
@@ -122,6 +139,9 @@ def load_reference():
         render_rays_multi=multi_rendering.render_rays_multi,
         volume_rendering_multi=multi_rendering.volume_rendering_multi,
         inference_from_model=multi_rendering.inference_from_model,
+        get_ray_directions=ray_utils.get_ray_directions,
+        get_rays=ray_utils.get_rays,
+        bbox_intersection_batch=geo_utils.bbox_intersection_batch,
         BBoxRayHelper=bbox_utils.BBoxRayHelper,
         check_in_any_boxes=bbox_utils.check_in_any_boxes,
         modules=dict(rendering=rendering, bbox_utils=bbox_utils, nerf_model=nerf_model, embedding_helper=embedding_helper,

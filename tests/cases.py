@@ -140,6 +140,22 @@ def multi_inputs():
     return sets, [box]
 
 
+# ---- editor ray generation (row f2): one background set and one object set with an enlarged box ----
+RAYGEN = dict(H=36, W=48, fov_x_deg=60.0, near=0.15, far=3.0, bbox_enlarge=0.06)
+
+
+def raygen_inputs():
+    h, w = RAYGEN["H"], RAYGEN["W"]
+    focal = (w / 2) / np.tan((RAYGEN["fov_x_deg"] / 2) / (180 / np.pi))       # editable_renderer.py:214
+    cy, sy = math.cos(math.radians(35.0)), math.sin(math.radians(35.0))
+    cp, sp = math.cos(math.radians(75.0)), math.sin(math.radians(75.0))
+    R = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]]) @ np.array([[1.0, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Toc = np.concatenate([R, np.array([[0.5], [0.5], [0.6]])], 1)               # (3,4), translation in scene units
+    box = synth.oriented_box(center=[3.6, 3.9, 0.5], size=[1.0, 0.8, 1.0], yaw_deg=20.0,
+                             scene_center=synth.SCANNET_LIKE["scene_center"], scale_factor=synth.SCANNET_LIKE["scale_factor"])
+    return h, w, float(focal), torch.from_numpy(Toc).float(), box
+
+
 def load_golden(name):
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     z = np.load(path)
