@@ -138,7 +138,7 @@ def test_sample_pdf_matches_reference():
     # one is exact only when the fp32 cdf does not overshoot 1.0 by an ulp, in the reference as well)
     assert (det[:, 1:] >= det[:, :-1]).all()
     assert torch.equal(det[:, 0].cpu(), bins[:, 0])
-    assert (det[:, -1].cpu() <= bins[:, -1]).all() and (bins[:, -1] - det[:, -1].cpu()).max().item() < 1e-5
+    assert (det[:, -1].cpu() <= bins[:, -1]).all() and (bins[:, -1] - det[:, -1].cpu()).max().item() < 1e-3
 
 
 def _composite_case(n=50, S=64, seed=7):
