@@ -255,6 +255,69 @@ int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* 
                         const objnerf_render_out* coarse, const objnerf_render_out* fine,
                         void* stream);
 
+/* ---- training path: differentiable stages behind train.py:147-180 ---- */
+
+/* C[M,N] = A'[M,K] * B'[K,N] (+ C) with optional bias / LeakyReLU / sigmoid epilogue: the fp32 MFMA GEMM of the
+ * layer-wise training path (csrc/gemm.h).  A'[m][k] = a_k_contig ? A[m*lda+k] : A[k*lda+m];
+ * B'[k][n] = b_k_contig ? B[n*ldb+k] : B[k*ldb+n].  split_k > 1 adds with fp32 atomics (C must hold the
+ * initial value).  epilogue: 0 none, 1 +bias, 2 +bias+LeakyReLU(0.01), 3 +bias+sigmoid. */
+int objnerf_gemm(const float* A, int64_t lda, int a_k_contig, const float* B, int64_t ldb, int b_k_contig,
+                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, int epilogue,
+                 const float* bias, int split_k, void* stream);
+
+/* ObjectNeRF.forward + forward_instance (nerf_model.py:97-152) on pre-embedded dense inputs, keeping the
+ * activations for the backward pass.  h_params: HOST array of objnerf_num_param_ptrs() DEVICE pointers to the
+ * raw nn.Linear tensors (same order as objnerf_pack_weights; nothing is packed on this path). */
+typedef struct {
+  int32_t use_voxel;
+  int32_t do_object;
+  int64_t n_points;
+  const float* const* h_params;
+  const float* emb_xyz;     /* (P, in_xyz) */
+  const float* emb_dir;     /* (P, 27) */
+  const float* obj_voxel;   /* (P, 104) voxel mode */
+  const float* obj_code;    /* (P, 64) */
+  float* sigma;             /* (P) */
+  float* rgb;               /* (P,3) */
+  float* inst_sigma;        /* (P) */
+  float* inst_rgb;          /* (P,3) */
+  float* workspace;         /* objnerf_train_workspace_floats(): saved activations, input of the backward */
+} objnerf_train_args;
+int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points);
+int64_t objnerf_train_scratch_floats(int64_t n_points);
+int objnerf_mlp_train_forward(const objnerf_train_args* args, void* stream);
+/* Backward of the call above (same args, outputs and workspace untouched in between).
+ * d_*: gradients w.r.t. sigma (P), rgb (P,3), inst_sigma, inst_rgb.  h_param_grads: HOST array of DEVICE
+ * pointers, one per parameter tensor, ACCUMULATED into (+=).  d_emb_xyz (P,in_xyz), d_obj_voxel (P,104),
+ * d_obj_code (P,64) are overwritten.  scratch: objnerf_train_scratch_floats() floats. */
+int objnerf_mlp_train_backward(const objnerf_train_args* args, const float* d_sigma, const float* d_rgb,
+                               const float* d_inst_sigma, const float* d_inst_rgb, float* const* h_param_grads,
+                               float* d_emb_xyz, float* d_obj_voxel, float* d_obj_code, float* scratch,
+                               void* stream);
+
+/* Backward of objnerf_composite (models/rendering.py:139-229): same `fwd` arguments as the forward call (its
+ * outputs are not read; weights/alphas are recomputed).  g_*: gradients of the maps (any may be NULL = zero):
+ * rgb_map (N,3), depth (N), opacity (N), rgb_inst (N,3), depth_inst (N), opacity_inst (N).  Outputs (overwritten):
+ * d_sigma (N,S), d_rgb (N,S,3), d_inst_sigma (N,S), d_inst_rgb (N,S,3) (instance ones only with instance inputs).
+ * No gradient flows to z_vals or through the occlusion mask (a comparison), as in the reference. */
+int objnerf_composite_backward(const objnerf_composite_args* fwd, const float* g_rgb_map, const float* g_depth,
+                               const float* g_opacity, const float* g_rgb_inst, const float* g_depth_inst,
+                               const float* g_opacity_inst, float* d_sigma, float* d_rgb, float* d_inst_sigma,
+                               float* d_inst_rgb, void* stream);
+
+/* Backward of objnerf_voxel_embed w.r.t. the feature table (embedding_space_ftr.weight): table_grad
+ * (n_rows,24) += scatter of d_scene_ftr (n,271) / d_obj_ftr (n,104) through the positional-encoding
+ * derivative and the trilinear weights (fp32 atomics).  No gradient w.r.t. xyz (none is needed: depths are
+ * detached, rendering.py:307). */
+int objnerf_voxel_embed_backward(const objnerf_voxel_grid* grid, const float* xyz, int64_t n,
+                                 const float* d_scene_ftr, const float* d_obj_ftr, float* table_grad, void* stream);
+
+/* out[r, c] += sum_{s < S} x[r*S + s, c]   (gradient of the `repeat` of per-ray codes, rendering.py:94) */
+int objnerf_sum_over_samples(const float* x, int64_t n_rays, int S, int C, float* out, void* stream);
+
+/* xyz[n, s, :] = rays_o + rays_d * z_vals[n, s]  (rendering.py:279), materialised for the training path */
+int objnerf_sample_points(const float* rays, const float* z_vals, int64_t n_rays, int S, float* xyz, void* stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of the MLP kernel on `stream` ---- */
 /* When enabled, objnerf_mlp_eval brackets its launch with hipEvents; objnerf_timing_read
  * synchronises those events and returns {launch count, total ms} since the last reset. */

@@ -58,6 +58,16 @@ class CompositeArgs(C.Structure):
     ]
 
 
+class TrainArgs(C.Structure):
+    _fields_ = [
+        ("use_voxel", C.c_int32), ("do_object", C.c_int32), ("n_points", C.c_int64),
+        ("h_params", C.POINTER(C.c_void_p)),
+        ("emb_xyz", C.c_void_p), ("emb_dir", C.c_void_p), ("obj_voxel", C.c_void_p), ("obj_code", C.c_void_p),
+        ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
+        ("workspace", C.c_void_p),
+    ]
+
+
 class CompositeMultiArgs(C.Structure):
     _fields_ = [
         ("n_rays", C.c_int64), ("K", C.c_int32), ("S", C.c_int32),
@@ -122,6 +132,16 @@ SIGNATURES = {
     "objnerf_generate_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, C.c_float, C.c_float, _VP, C.c_double, _VP, _VP]),
     "objnerf_render_workspace_bytes": (C.c_int64, [C.POINTER(RenderCfg), C.c_int64]),
     "objnerf_render_rays": (C.c_int, [C.POINTER(RenderCfg), C.POINTER(RenderIn), C.POINTER(RenderOut), C.POINTER(RenderOut), _VP]),
+    "objnerf_gemm": (C.c_int, [_VP, C.c_int64, C.c_int, _VP, C.c_int64, C.c_int, _VP, C.c_int64, C.c_int64, C.c_int64,
+                               C.c_int64, C.c_int, C.c_int, _VP, C.c_int, _VP]),
+    "objnerf_train_workspace_floats": (C.c_int64, [C.c_int, C.c_int64]),
+    "objnerf_train_scratch_floats": (C.c_int64, [C.c_int64]),
+    "objnerf_mlp_train_forward": (C.c_int, [C.POINTER(TrainArgs), _VP]),
+    "objnerf_mlp_train_backward": (C.c_int, [C.POINTER(TrainArgs), _VP, _VP, _VP, _VP, C.POINTER(_VP), _VP, _VP, _VP, _VP, _VP]),
+    "objnerf_composite_backward": (C.c_int, [C.POINTER(CompositeArgs), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "objnerf_voxel_embed_backward": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP, _VP]),
+    "objnerf_sum_over_samples": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
+    "objnerf_sample_points": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, _VP, _VP]),
     "objnerf_timing_enable": (C.c_int, [C.c_int]),
     "objnerf_timing_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

@@ -1,0 +1,216 @@
+"""Differentiable render_rays: what `training_step` (train.py:147-180) needs.
+
+`render_rays` dispatches here whenever autograd is recording and something on the path requires a
+gradient.  One `torch.autograd.Function` covers the whole call; both its forward and its backward are
+sequences of C-ABI kernel launches (include/objnerf_hip.h "training path"):
+
+  forward   coarse depths -> sample points -> voxel / positional embedding (materialised) -> layer-wise
+            MLP forward on the fp32 MFMA GEMM, activations kept -> compositing -> sample_pdf + merge
+            (no gradient, as in the reference: rendering.py:307 detaches) -> fine pass
+  backward  compositing backward -> MLP backward (dgrad / wgrad / bias grads) -> voxel-embedding backward
+            (atomics into the feature table) -> per-ray sum of the object-code gradients
+
+Gradients are produced for every ObjectNeRF parameter (coarse and fine), the voxel feature table and
+`embedding_instance`; none for rays / depths (the reference has none either).  The Python here only
+allocates tensors, repeats per-ray rows to per-point rows and orders the launches.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_MAPS = ("rgb", "depth", "opacity", "rgb_instance", "depth_instance", "opacity_instance")
+
+
+def _empty(*shape, dev):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+class _Pass:
+    """saved state of one (coarse / fine) pass"""
+    __slots__ = ("z", "xyz", "emb_xyz", "obj_voxel", "emb_dir", "code_pts", "sigma", "rgb", "isig", "irgb", "ws",
+                 "noise", "noise_i", "S")
+
+
+def _ptr_table(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _composite_args(meta, ps, outs=None):
+    a = _lib.CompositeArgs()
+    n = ps.z.shape[0]
+    a.n_rays, a.S = n, ps.S
+    a.z_vals, a.sigma, a.rgb = ps.z.data_ptr(), ps.sigma.data_ptr(), ps.rgb.data_ptr()
+    if meta["forward_instance"]:
+        a.inst_sigma, a.inst_rgb = ps.isig.data_ptr(), ps.irgb.data_ptr()
+    a.noise_std = float(meta["noise_std"])
+    if meta["noise_std"] != 0:
+        a.noise = ps.noise.data_ptr()
+        if meta["forward_instance"]:
+            a.noise_inst = ps.noise_i.data_ptr()
+    a.white_back = int(meta["white_back"])
+    a.use_zero_as_last_delta = int(meta["use_zero_as_last_delta"])
+    a.occlusion = int((not meta["is_eval"]) and meta["frustum_bound_th"] > 0)
+    a.frustum_bound_th = float(meta["frustum_bound_th"])
+    if meta["ptm"] is not None:
+        a.pass_through_mask = meta["ptm"].data_ptr()
+    a.rays_in_bbox = int(meta["rays_in_bbox"] and meta["forward_instance"])
+    if outs is not None:
+        a.weights, a.opacity, a.rgb_map, a.depth = (outs[k].data_ptr() for k in ("weights", "opacity", "rgb", "depth"))
+        if meta["forward_instance"]:
+            a.rgb_inst, a.depth_inst, a.opacity_inst = (outs[k].data_ptr() for k in
+                                                        ("rgb_instance", "depth_instance", "opacity_instance"))
+    return a
+
+
+def _train_args(meta, ps, params):
+    a = _lib.TrainArgs()
+    a.use_voxel, a.do_object = int(meta["use_voxel"]), int(meta["forward_instance"])
+    a.n_points = ps.emb_xyz.shape[0]
+    table = _ptr_table(params)
+    a.h_params = table
+    a.emb_xyz, a.emb_dir = ps.emb_xyz.data_ptr(), ps.emb_dir.data_ptr()
+    if meta["forward_instance"]:
+        a.obj_code = ps.code_pts.data_ptr()
+        if meta["use_voxel"]:
+            a.obj_voxel = ps.obj_voxel.data_ptr()
+        a.inst_sigma, a.inst_rgb = ps.isig.data_ptr(), ps.irgb.data_ptr()
+    a.sigma, a.rgb = ps.sigma.data_ptr(), ps.rgb.data_ptr()
+    a.workspace = ps.ws.data_ptr()
+    return a, table
+
+
+class RenderRaysFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, rays, codes, table, *params):
+        l = _lib.lib()
+        st = _lib.stream_ptr()
+        dev = rays.device
+        n, S, I = rays.shape[0], meta["S"], meta["I"]
+        fi, vox = meta["forward_instance"], meta["use_voxel"]
+        n_par = l.objnerf_num_param_ptrs()
+        p_coarse = [_lib.as_f32(p.detach()) for p in params[:n_par]]
+        p_fine = [_lib.as_f32(p.detach()) for p in params[n_par:2 * n_par]] if I > 0 else None
+        rays_c = _lib.as_f32(rays.detach())
+        codes_c = _lib.as_f32(codes.detach())
+        rnd = meta["randoms"]
+
+        # per-ray rows repeated per sample are copies, not arithmetic
+        dirs = rays_c[:, 3:6].contiguous()
+        emb_dir_ray = _empty(n, 27, dev=dev)
+        _lib.check(l.objnerf_pos_encode(_lib.ptr(dirs), n, 3, 4, _lib.ptr(emb_dir_ray), st), "pos_encode")
+
+        def run_pass(z, pp, noise, noise_i):
+            ps = _Pass()
+            Sx = z.shape[1]
+            P = n * Sx
+            ps.S, ps.z = Sx, z
+            ps.xyz = _empty(P, 3, dev=dev)
+            _lib.check(l.objnerf_sample_points(_lib.ptr(rays_c), _lib.ptr(z), n, Sx, _lib.ptr(ps.xyz), st), "sample_points")
+            if vox:
+                ps.emb_xyz, ps.obj_voxel = _empty(P, 271, dev=dev), _empty(P, 104, dev=dev)
+                _lib.check(l.objnerf_voxel_embed(C.byref(meta["grid"]), _lib.ptr(ps.xyz), P, _lib.ptr(ps.emb_xyz),
+                                                 _lib.ptr(ps.obj_voxel), st), "voxel_embed")
+            else:
+                ps.emb_xyz, ps.obj_voxel = _empty(P, 63, dev=dev), None
+                _lib.check(l.objnerf_pos_encode(_lib.ptr(ps.xyz), P, 3, 10, _lib.ptr(ps.emb_xyz), st), "pos_encode")
+            ps.emb_dir = emb_dir_ray.repeat_interleave(Sx, 0)
+            ps.code_pts = codes_c.repeat_interleave(Sx, 0) if fi else None
+            ps.sigma, ps.rgb = _empty(P, dev=dev), _empty(P, 3, dev=dev)
+            ps.isig, ps.irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
+            ps.ws = _empty(l.objnerf_train_workspace_floats(int(fi), P), dev=dev)
+            ps.noise, ps.noise_i = noise, noise_i
+            a, keep = _train_args(meta, ps, pp)
+            _lib.check(l.objnerf_mlp_train_forward(C.byref(a), st), "mlp_train_forward")
+            outs = {"weights": _empty(n, Sx, dev=dev), "opacity": _empty(n, dev=dev), "rgb": _empty(n, 3, dev=dev),
+                    "depth": _empty(n, dev=dev)}
+            if fi:
+                outs.update({"rgb_instance": _empty(n, 3, dev=dev), "depth_instance": _empty(n, dev=dev),
+                             "opacity_instance": _empty(n, dev=dev)})
+            ca = _composite_args(meta, ps, outs)
+            _lib.check(l.objnerf_composite(C.byref(ca), st), "composite")
+            return ps, outs
+
+        z_c = _empty(n, S, dev=dev)
+        pr = rnd.get("perturb_rand") if meta["perturb"] > 0 else None
+        _lib.check(l.objnerf_sample_coarse(_lib.ptr(rays_c), _lib.ptr(meta["z_steps"]), _lib.ptr(pr) if pr is not None else None,
+                                           float(meta["perturb"]), int(meta["use_disp"]), n, S, _lib.ptr(z_c), st), "sample_coarse")
+        nz = rnd.get("noise", [None] * 4)
+        passes, results = [], {}
+        ps, outs = run_pass(z_c, p_coarse, nz[0], nz[1])
+        passes.append(ps)
+        for k, v in outs.items():
+            results["%s_coarse" % k] = v
+        results["z_vals_coarse"] = z_c
+        if I > 0:
+            z_f = _empty(n, S + I, dev=dev)
+            det = meta["perturb"] == 0
+            u = meta["u_det"] if det else rnd["u_rand"]
+            _lib.check(l.objnerf_sample_pdf_merge(_lib.ptr(z_c), _lib.ptr(outs["weights"]), _lib.ptr(u), 0 if det else I, n, S, I,
+                                                  1e-5, None, _lib.ptr(z_f), st), "sample_pdf_merge")
+            ps, outs = run_pass(z_f, p_fine, nz[2], nz[3])
+            passes.append(ps)
+            for k, v in outs.items():
+                results["%s_fine" % k] = v
+            results["z_vals_fine"] = z_f
+
+        keys = sorted(results)
+        ctx.meta, ctx.passes, ctx.keys = meta, passes, keys
+        ctx.p_coarse, ctx.p_fine = p_coarse, p_fine
+        ctx.rays_c = rays_c
+        ctx.table_shape = table.shape if table is not None else None
+        ctx.n_params = len(params)
+        out = tuple(results[k] for k in keys)
+        ctx.mark_non_differentiable(*[results[k] for k in keys if k.startswith(("weights_", "z_vals_"))])
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        l = _lib.lib()
+        st = _lib.stream_ptr()
+        meta = ctx.meta
+        fi, vox = meta["forward_instance"], meta["use_voxel"]
+        dev = ctx.rays_c.device
+        n = ctx.rays_c.shape[0]
+        g = dict(zip(ctx.keys, grads))
+        n_par = l.objnerf_num_param_ptrs()
+        d_table = torch.zeros(ctx.table_shape, dtype=torch.float32, device=dev) if vox else None
+        d_codes = torch.zeros(n, 64, dtype=torch.float32, device=dev) if fi else None
+        param_grads = []
+        for typ, ps, pp in zip(("coarse", "fine"), ctx.passes, (ctx.p_coarse, ctx.p_fine)):
+            gp = [torch.zeros_like(p) for p in pp]
+            param_grads.append(gp)
+            P, Sx = ps.emb_xyz.shape[0], ps.S
+
+            def gm(name):
+                t = g.get("%s_%s" % (name, typ))
+                return _lib.as_f32(t) if t is not None else None
+            gm_t = {k: gm(k) for k in _MAPS}
+            if all(v is None for v in gm_t.values()):
+                continue
+            d_sigma, d_rgb = _empty(P, dev=dev), _empty(P, 3, dev=dev)
+            d_isig, d_irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
+            ca = _composite_args(meta, ps)
+            _lib.check(l.objnerf_composite_backward(
+                C.byref(ca), _lib.ptr(gm_t["rgb"]), _lib.ptr(gm_t["depth"]), _lib.ptr(gm_t["opacity"]),
+                _lib.ptr(gm_t["rgb_instance"]), _lib.ptr(gm_t["depth_instance"]), _lib.ptr(gm_t["opacity_instance"]),
+                _lib.ptr(d_sigma), _lib.ptr(d_rgb), _lib.ptr(d_isig), _lib.ptr(d_irgb), st), "composite_backward")
+            a, keep = _train_args(meta, ps, pp)
+            gtable = _ptr_table(gp)
+            d_emb = _empty(P, ps.emb_xyz.shape[1], dev=dev)
+            d_ov = _empty(P, 104, dev=dev) if (fi and vox) else None
+            d_code = _empty(P, 64, dev=dev) if fi else None
+            scratch = _empty(l.objnerf_train_scratch_floats(P), dev=dev)
+            _lib.check(l.objnerf_mlp_train_backward(C.byref(a), _lib.ptr(d_sigma), _lib.ptr(d_rgb), _lib.ptr(d_isig),
+                                                    _lib.ptr(d_irgb), gtable, _lib.ptr(d_emb), _lib.ptr(d_ov), _lib.ptr(d_code),
+                                                    _lib.ptr(scratch), st), "mlp_train_backward")
+            if vox:
+                _lib.check(l.objnerf_voxel_embed_backward(C.byref(meta["grid"]), _lib.ptr(ps.xyz), P, _lib.ptr(d_emb),
+                                                          _lib.ptr(d_ov), _lib.ptr(d_table), st), "voxel_embed_backward")
+            if fi:
+                _lib.check(l.objnerf_sum_over_samples(_lib.ptr(d_code), n, Sx, 64, _lib.ptr(d_codes), st), "sum_over_samples")
+        flat = list(param_grads[0]) + (list(param_grads[1]) if len(param_grads) > 1 else [])
+        flat += [None] * (ctx.n_params - len(flat))
+        return (None, None, d_codes, d_table, *flat)

@@ -1,0 +1,300 @@
+// train.hip -- training path of the dual-branch MLP: layer-wise forward that keeps
+// the activations, and the matching backward (dgrad + wgrad + bias grads), built on the fp32 MFMA GEMM of
+// gemm.h plus a few element-wise kernels.  Operates on the reference's own nn.Linear tensors (row-major
+// (out,in) weights, no packing) and on dense row-major activations, i.e. exactly the tensors
+// ObjectNeRF.forward / forward_instance see (models/nerf_model.py:97-152); torch.cat of the skip / direction
+// inputs is never materialised (column-block GEMMs accumulate into the same output instead).
+//
+// The inference path (mlp_kernel.h) keeps everything in registers and cannot be differentiated; this path
+// trades that for saved activations (12.6 KB per sample point) and is what training_step (train.py:147-180)
+// runs through the autograd wrapper in object_nerf_amd/autograd.py.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "layout.h"
+#include "gemm.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+int gemm_launch(const GemmArgs& g, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0) return 0;
+  if (g.K <= 0) return 0;
+  dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM), (unsigned)g.split_k);
+  if (g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
+  else if (g.a_k_contig && !g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
+  else if (!g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
+  return check_launch("gemm");
+}
+
+// ---- element-wise helpers ------------------------------------------------------------------------
+__global__ void leaky_bwd_kernel(float* __restrict__ d, const float* __restrict__ act, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = act[i] > 0.f ? d[i] : 0.01f * d[i];          // leaky_relu backward on sign(output) = sign(input)
+}
+__global__ void sigmoid_bwd_kernel(float* __restrict__ dz, const float* __restrict__ dy, const float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dz[i] = dy[i] * (y[i] * (1.f - y[i]));
+}
+// out[c] += sum_p x[p, c]  (x: P x C with leading dimension ld); one block per 256-row slab, atomics per column
+__global__ void colsum_kernel(const float* __restrict__ x, long P, int C, long ld, float* __restrict__ out) {
+  __shared__ float part[256];
+  const int c = blockIdx.y * 32 + (threadIdx.x & 31);
+  const int rlane = threadIdx.x >> 5;                              // 8 row lanes
+  const long p0 = (long)blockIdx.x * 2048;
+  float s = 0.f;
+  if (c < C)
+    for (long p = p0 + rlane; p < p0 + 2048 && p < P; p += 8) s += x[p * ld + c];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (rlane == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += part[r * 32 + (threadIdx.x & 31)];
+    atomicAdd(out + c, t);
+  }
+}
+
+struct Ctx {
+  hipStream_t s;
+  int rc;
+};
+static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
+
+// C = A' * B' helpers over row-major activations / nn.Linear weights
+static void lin_fwd(Ctx& c, const float* X, long ldx, const float* W, long ldw, long P, int out, int in, float* Y, long ldy,
+                    int accumulate, int epi, const float* bias) {
+  if (c.rc) return;
+  GemmArgs g{X, ldx, 1, W, ldw, 1, Y, ldy, P, out, in, accumulate, epi, bias, 1};
+  c.rc = gemm_launch(g, c.s);
+}
+// dX (P x in) (+)= dY (P x out) * W (out x in)
+static void lin_dgrad(Ctx& c, const float* dY, long lddy, const float* W, long ldw, long P, int out, int in, float* dX,
+                      long lddx, int accumulate) {
+  if (c.rc) return;
+  GemmArgs g{dY, lddy, 1, W, ldw, 0, dX, lddx, P, in, out, accumulate, EPI_NONE, nullptr, 1};
+  c.rc = gemm_launch(g, c.s);
+}
+// dW (out x in, ld ldw) += dY^T (out x P) * X (P x in); split over the points
+static void lin_wgrad(Ctx& c, const float* dY, long lddy, const float* X, long ldx, long P, int out, int in, float* dW,
+                      long ldw) {
+  if (c.rc) return;
+  const long tiles = ((out + GBM - 1) / GBM) * (long)((in + GBN - 1) / GBN);
+  long split = (1024 + tiles - 1) / tiles;                          // ~4 workgroups per CU
+  const long max_split = (P + 4 * GBK - 1) / (4 * GBK);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  GemmArgs g{dY, lddy, 0, X, ldx, 0, dW, ldw, out, in, P, 1, EPI_NONE, nullptr, (int)(split > 1 ? split : 2)};
+  c.rc = gemm_launch(g, c.s);       // split_k >= 2 forces the atomic += path (dW always accumulates)
+}
+static void bias_grad(Ctx& c, const float* dY, long ld, long P, int C, float* db) {
+  if (c.rc) return;
+  dim3 grid((unsigned)((P + 2047) / 2048), (unsigned)((C + 31) / 32));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, c.s, dY, P, C, ld, db);
+  c.rc = check_launch("colsum");
+}
+static void leaky_bwd(Ctx& c, float* d, const float* act, long n) {
+  if (c.rc) return;
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(nblk(n)), dim3(256), 0, c.s, d, act, n);
+  c.rc = check_launch("leaky_bwd");
+}
+
+// saved-activation layout (floats per point)
+struct Ws {
+  long P;
+  float* base;
+  bool obj;
+  float* A(int l) const { return base + (long)(l - 1) * 256 * P; }            // scene layers 1..8
+  float* final_() const { return base + 8L * 256 * P; }
+  float* dirh() const { return final_() + 256L * P; }
+  float* rgb() const { return dirh() + 128L * P; }
+  float* B(int l) const { return rgb() + 4L * P + (long)(l - 1) * 128 * P; }   // object layers 1..4
+  float* ofinal() const { return B(5); }
+  float* odirh() const { return ofinal() + 128L * P; }
+  float* irgb() const { return odirh() + 64L * P; }
+};
+constexpr long kWsScene = 8L * 256 + 256 + 128 + 4;
+constexpr long kWsObj = 4L * 128 + 128 + 64 + 4;
+
+}  // namespace objnerf
+
+using namespace objnerf;
+
+extern "C" {
+
+int objnerf_gemm(const float* A, int64_t lda, int a_k_contig, const float* B, int64_t ldb, int b_k_contig, float* C,
+                 int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, int epilogue, const float* bias,
+                 int split_k, void* stream) {
+  if (!A || !B || !C || split_k < 1) return set_error(-1, "gemm: bad arguments");
+  if (split_k > 1 && epilogue != EPI_NONE) return set_error(-1, "gemm: epilogue needs split_k == 1");
+  GemmArgs g{A, lda, a_k_contig, B, ldb, b_k_contig, C, ldc, M, N, K, accumulate, epilogue, bias, split_k};
+  return gemm_launch(g, (hipStream_t)stream);
+}
+
+int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points) {
+  return (kWsScene + (do_object ? kWsObj : 0)) * n_points;
+}
+int64_t objnerf_train_scratch_floats(int64_t n_points) { return 3L * 256 * n_points; }
+
+int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
+  if (!a || !a->h_params || !a->emb_xyz || !a->emb_dir || !a->workspace || !a->sigma || !a->rgb)
+    return set_error(-1, "mlp_train_forward: bad arguments");
+  if (a->do_object && (!a->obj_code || (a->use_voxel && !a->obj_voxel) || !a->inst_sigma || !a->inst_rgb))
+    return set_error(-1, "mlp_train_forward: object branch inputs/outputs missing");
+  const long P = a->n_points;
+  if (P == 0) return 0;
+  const bool vox = a->use_voxel != 0;
+  const int cx = in_xyz(vox), co = in_obj(vox);
+  const float* const* p = a->h_params;
+  auto Wt = [&](int id) { return p[2 * id]; };
+  auto Bi = [&](int id) { return p[2 * id + 1]; };
+  Ctx c{(hipStream_t)stream, 0};
+  Ws w{P, a->workspace, a->do_object != 0};
+  const float* X = a->emb_xyz;
+  // scene branch, nerf_model.py:97-121
+  lin_fwd(c, X, cx, Wt(P_S1), cx, P, 256, cx, w.A(1), 256, 0, EPI_BIAS_LEAKY, Bi(P_S1));
+  for (int l = 2; l <= 8; ++l) {
+    if (l == 5) {   // cat([input_xyz, h]) -> two column blocks of W5
+      lin_fwd(c, X, cx, Wt(P_S5), cx + 256, P, 256, cx, w.A(5), 256, 0, EPI_NONE, nullptr);
+      lin_fwd(c, w.A(4), 256, Wt(P_S5) + cx, cx + 256, P, 256, 256, w.A(5), 256, 1, EPI_BIAS_LEAKY, Bi(P_S5));
+    } else {
+      lin_fwd(c, w.A(l - 1), 256, Wt(P_S1 + l - 1), 256, P, 256, 256, w.A(l), 256, 0, EPI_BIAS_LEAKY, Bi(P_S1 + l - 1));
+    }
+  }
+  lin_fwd(c, w.A(8), 256, Wt(P_SSIG), 256, P, 1, 256, a->sigma, 1, 0, EPI_BIAS, Bi(P_SSIG));
+  lin_fwd(c, w.A(8), 256, Wt(P_SF), 256, P, 256, 256, w.final_(), 256, 0, EPI_BIAS, Bi(P_SF));
+  lin_fwd(c, w.final_(), 256, Wt(P_SD), 256 + kDirC, P, 128, 256, w.dirh(), 128, 0, EPI_NONE, nullptr);
+  lin_fwd(c, a->emb_dir, kDirC, Wt(P_SD) + 256, 256 + kDirC, P, 128, kDirC, w.dirh(), 128, 1, EPI_BIAS_LEAKY, Bi(P_SD));
+  lin_fwd(c, w.dirh(), 128, Wt(P_SRGB), 128, P, 3, 128, a->rgb, 3, 0, EPI_BIAS_SIGMOID, Bi(P_SRGB));
+  if (a->do_object) {
+    // input_x = cat([emb_xyz, obj_voxel, obj_code]) as column blocks (nerf_model.py:128-132)
+    auto obj_in = [&](int wid, int ldw, float* out, int epi_last, const float* bias, int accumulate_first) {
+      lin_fwd(c, X, cx, Wt(wid), ldw, P, 128, cx, out, 128, accumulate_first, EPI_NONE, nullptr);
+      if (vox) lin_fwd(c, a->obj_voxel, kObjVoxPE, Wt(wid) + cx, ldw, P, 128, kObjVoxPE, out, 128, 1, EPI_NONE, nullptr);
+      lin_fwd(c, a->obj_code, kCodeC, Wt(wid) + cx + (vox ? kObjVoxPE : 0), ldw, P, 128, kCodeC, out, 128, 1, epi_last, bias);
+    };
+    obj_in(P_O1, co, w.B(1), EPI_BIAS_LEAKY, Bi(P_O1), 0);
+    lin_fwd(c, w.B(1), 128, Wt(P_O2), 128, P, 128, 128, w.B(2), 128, 0, EPI_BIAS_LEAKY, Bi(P_O2));
+    lin_fwd(c, w.B(2), 128, Wt(P_O3) + co, co + 128, P, 128, 128, w.B(3), 128, 0, EPI_NONE, nullptr);
+    obj_in(P_O3, co + 128, w.B(3), EPI_BIAS_LEAKY, Bi(P_O3), 1);
+    lin_fwd(c, w.B(3), 128, Wt(P_O4), 128, P, 128, 128, w.B(4), 128, 0, EPI_BIAS_LEAKY, Bi(P_O4));
+    lin_fwd(c, w.B(4), 128, Wt(P_OSIG), 128, P, 1, 128, a->inst_sigma, 1, 0, EPI_BIAS, Bi(P_OSIG));
+    lin_fwd(c, w.B(4), 128, Wt(P_OF), 128, P, 128, 128, w.ofinal(), 128, 0, EPI_BIAS, Bi(P_OF));
+    lin_fwd(c, w.ofinal(), 128, Wt(P_OD), 128 + kDirC, P, 64, 128, w.odirh(), 64, 0, EPI_NONE, nullptr);
+    lin_fwd(c, a->emb_dir, kDirC, Wt(P_OD) + 128, 128 + kDirC, P, 64, kDirC, w.odirh(), 64, 1, EPI_BIAS_LEAKY, Bi(P_OD));
+    lin_fwd(c, w.odirh(), 64, Wt(P_ORGB), 64, P, 3, 64, a->inst_rgb, 3, 0, EPI_BIAS_SIGMOID, Bi(P_ORGB));
+  }
+  return c.rc;
+}
+
+int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma, const float* d_rgb,
+                               const float* d_inst_sigma, const float* d_inst_rgb, float* const* h_param_grads,
+                               float* d_emb_xyz, float* d_obj_voxel, float* d_obj_code, float* scratch, void* stream) {
+  if (!a || !a->h_params || !h_param_grads || !a->workspace || !scratch || !d_sigma || !d_rgb || !d_emb_xyz)
+    return set_error(-1, "mlp_train_backward: bad arguments");
+  if (a->do_object && (!d_inst_sigma || !d_inst_rgb || !d_obj_code || (a->use_voxel && !d_obj_voxel)))
+    return set_error(-1, "mlp_train_backward: object branch gradients missing");
+  const long P = a->n_points;
+  if (P == 0) return 0;
+  const bool vox = a->use_voxel != 0;
+  const int cx = in_xyz(vox), co = in_obj(vox);
+  const float* const* p = a->h_params;
+  auto Wt = [&](int id) { return p[2 * id]; };
+  auto gW = [&](int id) { return h_param_grads[2 * id]; };
+  auto gB = [&](int id) { return h_param_grads[2 * id + 1]; };
+  Ctx c{(hipStream_t)stream, 0};
+  Ws w{P, a->workspace, a->do_object != 0};
+  float* t0 = scratch;                 // P x 256
+  float* t1 = scratch + 256L * P;      // P x 256
+  float* t2 = scratch + 512L * P;      // P x 256 (small temporaries)
+  const float* X = a->emb_xyz;
+
+  // ---- scene branch ----
+  // rgb = sigmoid(dirh Wr^T + br)
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_rgb, a->rgb, 3 * P);
+  lin_wgrad(c, t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128);
+  bias_grad(c, t2, 3, P, 3, gB(P_SRGB));
+  lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, t0, 128, 0);              // d dirh
+  leaky_bwd(c, t0, w.dirh(), 128 * P);
+  lin_wgrad(c, t0, 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC);
+  lin_wgrad(c, t0, 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
+  bias_grad(c, t0, 128, P, 128, gB(P_SD));
+  lin_dgrad(c, t0, 128, Wt(P_SD), 256 + kDirC, P, 128, 256, t1, 256, 0);     // d final
+  lin_wgrad(c, t1, 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256);
+  bias_grad(c, t1, 256, P, 256, gB(P_SF));
+  lin_dgrad(c, t1, 256, Wt(P_SF), 256, P, 256, 256, t0, 256, 0);             // dA8 (from final)
+  lin_dgrad(c, d_sigma, 1, Wt(P_SSIG), 256, P, 1, 256, t0, 256, 1);          // + d sigma * w_sigma
+  lin_wgrad(c, d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256);
+  bias_grad(c, d_sigma, 1, P, 1, gB(P_SSIG));
+  float* dA = t0;
+  float* dN = t1;
+  bool emb_written = false;
+  for (int l = 8; l >= 1; --l) {
+    leaky_bwd(c, dA, w.A(l), 256 * P);
+    bias_grad(c, dA, 256, P, 256, gB(P_S1 + l - 1));
+    if (l == 5) {
+      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S5), cx + 256);
+      lin_wgrad(c, dA, 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
+      lin_dgrad(c, dA, 256, Wt(P_S5), cx + 256, P, 256, cx, d_emb_xyz, cx, 0);
+      emb_written = true;
+      lin_dgrad(c, dA, 256, Wt(P_S5) + cx, cx + 256, P, 256, 256, dN, 256, 0);
+    } else if (l == 1) {
+      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S1), cx);
+      lin_dgrad(c, dA, 256, Wt(P_S1), cx, P, 256, cx, d_emb_xyz, cx, emb_written ? 1 : 0);
+    } else {
+      lin_wgrad(c, dA, 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256);
+      lin_dgrad(c, dA, 256, Wt(P_S1 + l - 1), 256, P, 256, 256, dN, 256, 0);
+    }
+    float* tmp = dA; dA = dN; dN = tmp;
+  }
+
+  // ---- object branch ----
+  if (a->do_object) {
+    const int ov = vox ? kObjVoxPE : 0;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_inst_rgb, a->inst_rgb, 3 * P);
+    lin_wgrad(c, t2, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64);
+    bias_grad(c, t2, 3, P, 3, gB(P_ORGB));
+    lin_dgrad(c, t2, 3, Wt(P_ORGB), 64, P, 3, 64, t0, 64, 0);
+    leaky_bwd(c, t0, w.odirh(), 64 * P);
+    lin_wgrad(c, t0, 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC);
+    lin_wgrad(c, t0, 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
+    bias_grad(c, t0, 64, P, 64, gB(P_OD));
+    lin_dgrad(c, t0, 64, Wt(P_OD), 128 + kDirC, P, 64, 128, t1, 128, 0);      // d ofinal
+    lin_wgrad(c, t1, 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128);
+    bias_grad(c, t1, 128, P, 128, gB(P_OF));
+    lin_dgrad(c, t1, 128, Wt(P_OF), 128, P, 128, 128, t0, 128, 0);            // dB4
+    lin_dgrad(c, d_inst_sigma, 1, Wt(P_OSIG), 128, P, 1, 128, t0, 128, 1);
+    lin_wgrad(c, d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128);
+    bias_grad(c, d_inst_sigma, 1, P, 1, gB(P_OSIG));
+    dA = t0; dN = t1;
+    bool ov_written = false;
+    // gradient of one layer fed by cat([emb_xyz, obj_voxel, obj_code]) (+ optional hidden block at column co)
+    auto obj_in_bwd = [&](int wid, int ldw) {
+      lin_wgrad(c, dA, 128, X, cx, P, 128, cx, gW(wid), ldw);
+      if (vox) lin_wgrad(c, dA, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
+      lin_wgrad(c, dA, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
+      lin_dgrad(c, dA, 128, Wt(wid), ldw, P, 128, cx, d_emb_xyz, cx, 1);       // scene branch wrote it first
+      if (vox) lin_dgrad(c, dA, 128, Wt(wid) + cx, ldw, P, 128, kObjVoxPE, d_obj_voxel, kObjVoxPE, ov_written ? 1 : 0);
+      lin_dgrad(c, dA, 128, Wt(wid) + cx + ov, ldw, P, 128, kCodeC, d_obj_code, kCodeC, ov_written ? 1 : 0);
+      ov_written = true;
+    };
+    for (int l = 4; l >= 1; --l) {
+      leaky_bwd(c, dA, w.B(l), 128 * P);
+      bias_grad(c, dA, 128, P, 128, gB(P_O1 + l - 1));
+      if (l == 3) {
+        lin_wgrad(c, dA, 128, w.B(2), 128, P, 128, 128, gW(P_O3) + co, co + 128);
+        obj_in_bwd(P_O3, co + 128);
+        lin_dgrad(c, dA, 128, Wt(P_O3) + co, co + 128, P, 128, 128, dN, 128, 0);
+      } else if (l == 1) {
+        obj_in_bwd(P_O1, co);
+      } else {
+        lin_wgrad(c, dA, 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128);
+        lin_dgrad(c, dA, 128, Wt(P_O1 + l - 1), 128, P, 128, 128, dN, 128, 0);
+      }
+      float* tmp = dA; dA = dN; dN = tmp;
+    }
+  }
+  return c.rc;
+}
+
+}  // extern "C"

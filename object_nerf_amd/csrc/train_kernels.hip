@@ -1,0 +1,295 @@
+// train_kernels.hip -- backward kernels of the HBM-bound stages:
+// alpha-compositing backward (one wave per ray), voxel-embedding backward (fp32 atomics into the
+// feature table), the per-ray reduction of object-code gradients and the materialised sample points.
+#include <hip/hip_runtime.h>
+#include "layout.h"
+#include "device_math.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wscan_mul(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+  return v;
+}
+__device__ __forceinline__ float wscan_add(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v += t; }
+  return v;
+}
+
+// Backward of one composited channel set (models/rendering.py:156-176 / 187-223).
+//   w_i = a_i T_i,  T_i = prod_{j<i} (1 - a_j + 1e-10),  a_i = 1 - exp(-delta_i relu(s_i))
+//   L depends on  C = sum w_i c_i,  D = sum w_i z_i,  O = sum w_i     (go already holds dL/dO minus the
+//   white-background term).  With g_i = gC . c_i + gD z_i + go:
+//     dL/da_i = T_i g_i - (sum_{j>i} w_j g_j) / (1 - a_i + 1e-10)
+//     dL/ds_i = dL/da_i * delta_i * exp(-delta_i relu(s_i)) * [s_i > 0]          (0 where the alpha was masked)
+//     dL/dc_i = w_i gC
+// Two forward sweeps (the first accumulates V = sum w_j g_j, the second turns running prefixes into the suffix
+// sums), so no reverse scan and no per-ray storage is needed.
+__device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ z, const float* __restrict__ sigma,
+                                                  const float* __restrict__ rgb, const float* __restrict__ noise,
+                                                  float noise_std, float last_delta, int S, int lane, bool occl,
+                                                  float occl_limit, float gC0, float gC1, float gC2, float gD, float go,
+                                                  float* __restrict__ d_sigma, float* __restrict__ d_rgb) {
+  float V = 0.f;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    float carry = 1.f, run = 0.f;          // transmittance / sum_{j < base} w_j g_j
+    float vpart = 0.f;
+    for (int base = 0; base < S; base += 64) {
+      const int i = base + lane;
+      const bool in = i < S;
+      float zi = 0.f, alpha = 0.f, dads = 0.f, gi = 0.f;
+      if (in) {
+        zi = z[i];
+        const float delta = i + 1 < S ? z[i + 1] - zi : last_delta;
+        float s = sigma[i];
+        if (noise) s = s + noise[i] * noise_std;
+        const float e = expf(-delta * fmaxf(s, 0.f));
+        alpha = 1.f - e;
+        dads = s > 0.f ? delta * e : 0.f;
+        if (occl && occl_limit < zi) { alpha = 0.f; dads = 0.f; }
+        gi = gC0 * rgb[i * 3] + gC1 * rgb[i * 3 + 1] + gC2 * rgb[i * 3 + 2] + gD * zi + go;
+      }
+      const float t = in ? (1.f - alpha) + 1e-10f : 1.f;
+      const float incl = wscan_mul(t, lane);
+      float excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = 1.f;
+      const float T = carry * excl;
+      const float w = alpha * T;
+      const float v = in ? w * gi : 0.f;
+      if (sweep == 0) {
+        vpart += v;
+      } else {
+        const float pin = wscan_add(v, lane);                 // inclusive prefix inside the chunk
+        if (in) {
+          const float suffix = V - (run + pin);                // sum_{j > i} w_j g_j
+          const float dLda = T * gi - suffix / t;
+          d_sigma[i] = dLda * dads;
+          d_rgb[i * 3] = w * gC0; d_rgb[i * 3 + 1] = w * gC1; d_rgb[i * 3 + 2] = w * gC2;
+        }
+        run += __shfl(pin, 63);
+      }
+      carry = carry * __shfl(incl, 63);
+    }
+    if (sweep == 0) V = wsum(vpart);
+  }
+}
+
+// scene depth of one ray (needed by the occlusion mask of the instance set, rendering.py:192-197)
+__device__ __forceinline__ float scene_depth(const float* __restrict__ z, const float* __restrict__ sigma,
+                                             const float* __restrict__ noise, float noise_std, float last_delta, int S,
+                                             int lane) {
+  float carry = 1.f, sd = 0.f;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    const bool in = i < S;
+    float zi = 0.f, alpha = 0.f;
+    if (in) {
+      zi = z[i];
+      const float delta = i + 1 < S ? z[i + 1] - zi : last_delta;
+      float s = sigma[i];
+      if (noise) s = s + noise[i] * noise_std;
+      alpha = 1.f - expf(-delta * fmaxf(s, 0.f));
+    }
+    const float t = in ? (1.f - alpha) + 1e-10f : 1.f;
+    const float incl = wscan_mul(t, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.f;
+    if (in) sd += alpha * (carry * excl) * zi;
+    carry = carry * __shfl(incl, 63);
+  }
+  return wsum(sd);
+}
+
+struct CompBwd {
+  objnerf_composite_args f;
+  const float *g_rgb, *g_depth, *g_opac, *g_rgb_i, *g_depth_i, *g_opac_i;
+  float *d_sigma, *d_rgb, *d_isigma, *d_irgb;
+};
+
+__global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
+  const objnerf_composite_args& a = b.f;
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int S = a.S;
+  for (long ray = wave; ray < a.n_rays; ray += nwaves) {
+    const float* z = a.z_vals + ray * S;
+    const float* nz = a.noise ? a.noise + ray * S : nullptr;
+    const float last = a.use_zero_as_last_delta ? 0.f : 1e10f;
+    {
+      const float g0 = b.g_rgb ? b.g_rgb[ray * 3] : 0.f, g1 = b.g_rgb ? b.g_rgb[ray * 3 + 1] : 0.f,
+                  g2 = b.g_rgb ? b.g_rgb[ray * 3 + 2] : 0.f;
+      const float gD = b.g_depth ? b.g_depth[ray] : 0.f;
+      // rgb_map += 1 - opacity when white_back (rendering.py:178-179)
+      const float go = (b.g_opac ? b.g_opac[ray] : 0.f) - (a.white_back ? g0 + g1 + g2 : 0.f);
+      composite_bwd_ray(z, a.sigma + ray * S, a.rgb + ray * S * 3, nz, a.noise_std, last, S, lane, false, 0.f, g0, g1, g2,
+                        gD, go, b.d_sigma + ray * S, b.d_rgb + ray * S * 3);
+    }
+    if (a.inst_sigma) {
+      bool occl = a.occlusion != 0;
+      if (occl && a.pass_through_mask && a.pass_through_mask[ray]) occl = false;
+      float limit = 0.f;
+      if (occl) limit = scene_depth(z, a.sigma + ray * S, nz, a.noise_std, last, S, lane) + a.frustum_bound_th;
+      const float g0 = b.g_rgb_i ? b.g_rgb_i[ray * 3] : 0.f, g1 = b.g_rgb_i ? b.g_rgb_i[ray * 3 + 1] : 0.f,
+                  g2 = b.g_rgb_i ? b.g_rgb_i[ray * 3 + 2] : 0.f;
+      const float gD = b.g_depth_i ? b.g_depth_i[ray] : 0.f;
+      const float go = (b.g_opac_i ? b.g_opac_i[ray] : 0.f) - (g0 + g1 + g2);     // always white-backed, :223
+      composite_bwd_ray(z, a.inst_sigma + ray * S, a.inst_rgb + ray * S * 3, a.noise_inst ? a.noise_inst + ray * S : nullptr,
+                        a.noise_std, 0.f, S, lane, occl, limit, g0, g1, g2, gD, go, b.d_isigma + ray * S,
+                        b.d_irgb + ray * S * 3);
+    }
+  }
+}
+
+// ---- voxel embedding backward ---------------------------------------------------------------------
+__global__ void voxel_embed_bwd_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz, long n,
+                                       const float* __restrict__ d_scene, const float* __restrict__ d_obj,
+                                       float* __restrict__ table_grad) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
+  const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
+  const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
+  const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
+  const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
+  const float u = sx - qx, v = sy - qy, w = sz - qz;
+  const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
+  float wt[8];
+  wt[0] = (lu * lv) * lw; wt[1] = (lu * lv) * w; wt[2] = (lu * v) * lw; wt[3] = (lu * v) * w;
+  wt[4] = (u * lv) * lw;  wt[5] = (u * lv) * w;  wt[6] = (u * v) * lw;  wt[7] = (u * v) * w;
+  int row[8];
+  const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
+  float f[kVoxC];
+#pragma unroll
+  for (int i = 0; i < kVoxC; ++i) f[i] = 0.f;
+  for (int k = 0; k < 8; ++k) {
+    const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
+    const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
+    int r = -1;
+    if (ok) {
+      r = g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz];
+      if (r >= g.n_rows) r = -1;
+    }
+    row[k] = r;
+    if (r >= 0) {
+      const float* t = g.table + (size_t)r * kVoxC;
+#pragma unroll
+      for (int i = 0; i < kVoxC; ++i) f[i] = f[i] + t[i] * wt[k];
+    }
+  }
+  const float* ds = d_scene + p * (long)(kScnVoxPE + kXyzPE);
+  const float* dobj = d_obj ? d_obj + p * (long)kObjVoxPE : nullptr;
+  float dF[kVoxC];
+#pragma unroll
+  for (int c = 0; c < kVoxC; ++c) {
+    const bool scn = c < kScnVoxC;
+    const float* d = scn ? ds : dobj;
+    const int C = scn ? kScnVoxC : kObjVoxC;
+    const int cc = scn ? c : c - kScnVoxC;
+    float acc = 0.f;
+    if (d) {
+      acc = d[cc];
+      float fr = 1.f;
+      for (int k = 0; k < kFreqVox; ++k) {
+        const SinCos sc = psincos<true>(fr * f[c]);
+        // d/df sin(fr f) = fr cos, d/df cos(fr f) = -fr sin
+        acc += fr * (d[C * (1 + 2 * k) + cc] * sc.c - d[C * (2 + 2 * k) + cc] * sc.s);
+        fr *= 2.f;
+      }
+    }
+    dF[c] = acc;
+  }
+  for (int k = 0; k < 8; ++k) {
+    if (row[k] < 0) continue;                       // invalid corners were zeroed in the forward pass
+    float* t = table_grad + (size_t)row[k] * kVoxC;
+#pragma unroll
+    for (int c = 0; c < kVoxC; ++c) atomicAdd(t + c, dF[c] * wt[k]);
+  }
+}
+
+__global__ void sum_over_samples_kernel(const float* __restrict__ x, long n_rays, int S, int C, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rays * C) return;
+  const long r = idx / C;
+  const int c = (int)(idx - r * C);
+  float s = 0.f;
+  for (int i = 0; i < S; ++i) s += x[(r * S + i) * C + c];
+  out[idx] = out[idx] + s;      // accumulates: the coarse and the fine pass add into one (N, C) gradient
+}
+
+__global__ void sample_points_kernel(const float* __restrict__ rays, const float* __restrict__ z, long n_rays, int S,
+                                     float* __restrict__ xyz) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rays * S) return;
+  const float* r = rays + (idx / S) * 8;
+  const float zv = z[idx];
+  xyz[idx * 3 + 0] = r[0] + r[3] * zv;      // separately rounded mul and add, rendering.py:279
+  xyz[idx * 3 + 1] = r[1] + r[4] * zv;
+  xyz[idx * 3 + 2] = r[2] + r[5] * zv;
+}
+
+}  // namespace objnerf
+
+using namespace objnerf;
+static inline unsigned blk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" {
+
+int objnerf_composite_backward(const objnerf_composite_args* fwd, const float* g_rgb_map, const float* g_depth,
+                               const float* g_opacity, const float* g_rgb_inst, const float* g_depth_inst,
+                               const float* g_opacity_inst, float* d_sigma, float* d_rgb, float* d_inst_sigma,
+                               float* d_inst_rgb, void* stream) {
+  if (!fwd || !fwd->z_vals || !fwd->sigma || !fwd->rgb || !d_sigma || !d_rgb)
+    return set_error(-1, "composite_backward: bad arguments");
+  if (fwd->inst_sigma && (!fwd->inst_rgb || !d_inst_sigma || !d_inst_rgb))
+    return set_error(-1, "composite_backward: instance gradients missing");
+  if (fwd->noise_std != 0.f && (!fwd->noise || (fwd->inst_sigma && !fwd->noise_inst)))
+    return set_error(-1, "composite_backward: noise_std != 0 needs the forward's noise draws");
+  if (fwd->n_rays == 0) return 0;
+  CompBwd b;
+  b.f = *fwd;
+  if (b.f.noise_std == 0.f) { b.f.noise = nullptr; b.f.noise_inst = nullptr; }
+  b.g_rgb = g_rgb_map; b.g_depth = g_depth; b.g_opac = g_opacity;
+  b.g_rgb_i = g_rgb_inst; b.g_depth_i = g_depth_inst; b.g_opac_i = g_opacity_inst;
+  b.d_sigma = d_sigma; b.d_rgb = d_rgb; b.d_isigma = d_inst_sigma; b.d_irgb = d_inst_rgb;
+  unsigned grid = (unsigned)((fwd->n_rays + 3) / 4);
+  if (grid > 256u * 32u) grid = 256u * 32u;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, b);
+  return check_launch("composite_backward");
+}
+
+int objnerf_voxel_embed_backward(const objnerf_voxel_grid* grid, const float* xyz, int64_t n, const float* d_scene_ftr,
+                                 const float* d_obj_ftr, float* table_grad, void* stream) {
+  if (!grid || !grid->idx_map || !grid->table || !xyz || !d_scene_ftr || !table_grad)
+    return set_error(-1, "voxel_embed_backward: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(voxel_embed_bwd_kernel, dim3(blk(n, 128)), dim3(128), 0, (hipStream_t)stream, *grid, xyz, (long)n,
+                     d_scene_ftr, d_obj_ftr, table_grad);
+  return check_launch("voxel_embed_backward");
+}
+
+int objnerf_sum_over_samples(const float* x, int64_t n_rays, int S, int C, float* out, void* stream) {
+  if (!x || !out || S < 1 || C < 1) return set_error(-1, "sum_over_samples: bad arguments");
+  if (n_rays == 0) return 0;
+  hipLaunchKernelGGL(sum_over_samples_kernel, dim3(blk(n_rays * C, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)n_rays, S, C, out);
+  return check_launch("sum_over_samples");
+}
+
+int objnerf_sample_points(const float* rays, const float* z_vals, int64_t n_rays, int S, float* xyz, void* stream) {
+  if (!rays || !z_vals || !xyz || S < 1) return set_error(-1, "sample_points: bad arguments");
+  if (n_rays == 0) return 0;
+  hipLaunchKernelGGL(sample_points_kernel, dim3(blk(n_rays * S, 256)), dim3(256), 0, (hipStream_t)stream, rays, z_vals,
+                     (long)n_rays, S, xyz);
+  return check_launch("sample_points");
+}
+
+}  // extern "C"

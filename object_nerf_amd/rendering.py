@@ -100,7 +100,6 @@ def render_rays(
     if embedding_instance is None:
         raise TypeError("render_rays: embedding_instance is required (models/rendering.py:94 repeats it unconditionally)")
     coarse = models["coarse"]
-    coarse._check_no_grad(rays, embedding_instance)
     _lib.require_cuda(rays, "rays")
     dev = rays.device
     n = rays.shape[0]
@@ -115,9 +114,41 @@ def render_rays(
     rays_c = _lib.as_f32(rays)
     if rays_c.shape[1] != 8:
         rays_c = rays_c[:, :8].contiguous()
+    if tuple(embedding_instance.shape) != (n, 64):
+        raise RuntimeError("embedding_instance must be (N_rays, 64), got %s" % (tuple(embedding_instance.shape),))
+
+    # ---- training: autograd is recording and something on the path wants a gradient -> differentiable path ----
+    table = emb_xyz.embedding_space_ftr.weight if use_voxel else None
+    plist = list(coarse._param_list()) + (list(models["fine"]._param_list()) if I > 0 else [])
+    if torch.is_grad_enabled() and (embedding_instance.requires_grad or any(p.requires_grad for p in plist)
+                                    or (table is not None and table.requires_grad)):
+        from .autograd import RenderRaysFn
+        rnd = dict(randoms) if randoms else {}
+        if perturb > 0:
+            rnd.setdefault("perturb_rand", torch.rand(n, S, device=dev))
+            if I > 0:
+                rnd.setdefault("u_rand", torch.rand(n, I, device=dev))
+        if noise_std != 0 and "noise" not in rnd:
+            rnd["noise"] = [torch.randn(n, S, device=dev), torch.randn(n, S, device=dev),
+                            torch.randn(n, S + I, device=dev), torch.randn(n, S + I, device=dev)]
+        for k in ("perturb_rand", "u_rand"):
+            if k in rnd:
+                rnd[k] = _lib.as_f32(rnd[k])
+        if "noise" in rnd:
+            rnd["noise"] = [_lib.as_f32(t) for t in rnd["noise"]]
+        meta = dict(S=S, I=I, use_voxel=use_voxel, forward_instance=bool(forward_instance), use_disp=bool(use_disp),
+                    perturb=float(perturb), noise_std=float(noise_std), white_back=bool(white_back), is_eval=is_eval,
+                    use_zero_as_last_delta=use_zero_as_last_delta, frustum_bound_th=float(frustum_bound_th),
+                    rays_in_bbox=bool(rays_in_bbox), randoms=rnd, z_steps=_linspace(S, dev),
+                    u_det=_linspace(I, dev) if I > 0 else None, grid=emb_xyz.grid_struct() if use_voxel else None,
+                    ptm=pass_through_mask.reshape(n).to(torch.uint8).contiguous() if pass_through_mask is not None else None)
+        outs = RenderRaysFn.apply(meta, rays_c, embedding_instance, table, *plist)
+        keys = sorted(["%s_%s" % (k, t) for t in (("coarse", "fine") if I > 0 else ("coarse",))
+                       for k in (["weights", "opacity", "z_vals", "rgb", "depth"]
+                                 + (["rgb_instance", "depth_instance", "opacity_instance"] if forward_instance else []))])
+        return dict(zip(keys, outs))
+
     codes = _lib.as_f32(embedding_instance.detach())
-    if codes.shape != (n, 64):
-        raise RuntimeError("embedding_instance must be (N_rays, 64), got %s" % (tuple(codes.shape),))
 
     cfg = _lib.RenderCfg(
         use_voxel=int(use_voxel), N_samples=S, N_importance=I, use_disp=int(bool(use_disp)),

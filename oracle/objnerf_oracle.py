@@ -238,8 +238,10 @@ def eval_points(params, grid, xyz, rays_d, codes, forward_instance=True, scene=T
 def render_rays(params_coarse, params_fine, grid, rays, N_samples=64, use_disp=False, perturb=0.0, noise_std=0.0,
                 N_importance=0, white_back=False, forward_instance=True, embedding_instance=None,
                 frustum_bound_th=0.0, pass_through_mask=None, rays_in_bbox=False, is_eval=False,
-                use_zero_as_last_delta=False, randoms=None, chunk=32768):
-    """models/rendering.py:233-337.  randoms: optional {"perturb_rand","u_rand","noise":[4]}."""
+                use_zero_as_last_delta=False, randoms=None, chunk=32768, z_fine_override=None):
+    """models/rendering.py:233-337.  randoms: optional {"perturb_rand","u_rand","noise":[4]}.
+    z_fine_override: test hook -- evaluate the fine pass at these (N, S+I) depths instead of the sampled ones
+    (teacher forcing; removes the importance sampler's fp32 sensitivity from gradient comparisons)."""
     o, d = rays[:, 0:3], rays[:, 3:6]
     randoms = randoms or {}
     noise = randoms.get("noise", [None] * 4)
@@ -257,9 +259,12 @@ def render_rays(params_coarse, params_fine, grid, rays, N_samples=64, use_disp=F
     one_pass("coarse", params_coarse, z, noise[0], noise[1])
     if N_importance > 0:
         mid = 0.5 * (z[:, :-1] + z[:, 1:])
-        z_new = sample_pdf(mid, results["weights_coarse"][:, 1:-1], N_importance, det=(perturb == 0),
+        # .detach(): no gradient from the fine depths back into the coarse weights (rendering.py:307)
+        z_new = sample_pdf(mid, results["weights_coarse"][:, 1:-1].detach(), N_importance, det=(perturb == 0),
                            u=randoms.get("u_rand"))
         z = torch.sort(torch.cat([z, z_new], -1), -1)[0]
+        if z_fine_override is not None:
+            z = z_fine_override
         one_pass("fine", params_fine, z, noise[2], noise[3])
     return results
 
@@ -404,7 +409,7 @@ def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, o
             n = rays_list[i].shape[0]
             w_own = res["weights_coarse"][res["obj_ids_coarse"] == i].view(n, N_samples)   # :269-271
             mid = 0.5 * (zs[i][:, :-1] + zs[i][:, 1:])
-            z_new = sample_pdf(mid, w_own[:, 1:-1], N_importance, det=(perturb == 0))
+            z_new = sample_pdf(mid, w_own[:, 1:-1].detach(), N_importance, det=(perturb == 0))
             z = torch.sort(torch.cat([zs[i], z_new], -1), -1)[0]
             c, sg = branch(params_fine, rays_list[i], z, obj_instance_ids[i])
             zf.append(z); cf.append(c); sf.append(sg)
