@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Times one training step of the reference's batch shape (train.py:147-180: 2048 rays, 64 coarse + 64 fine,
+perturb = 1, noise_std = 1, scene + object branches, voxel embedding) on the HIP training path:
+render_rays forward + backward (+ Adam step).  Not the headline metric; recorded in DESIGN.md."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import object_nerf_amd as A  # noqa: E402
+from object_nerf_amd import synth  # noqa: E402
+
+
+def main(n_rays=2048, steps=5):
+    dev = "cuda"
+    sc = synth.build_scene(A, True, preset=synth.SCANNET_LIKE, max_voxels=800_000, device=dev)
+    rays_all = synth.camera_rays(640, 480).to(dev)
+    params = [p for m in (sc.models["coarse"], sc.models["fine"], sc.code_library, sc.embeddings["xyz"]) for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    g = torch.Generator(device=dev).manual_seed(0)
+    target = torch.rand(n_rays, 3, device=dev, generator=g)
+
+    def step():
+        idx = torch.randint(0, rays_all.shape[0], (n_rays,), device=dev, generator=g)
+        rays = rays_all[idx].contiguous()
+        ids = synth.per_ray_ids(n_rays).to(dev)
+        opt.zero_grad(set_to_none=True)
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        r = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                          embedding_instance=codes, frustum_bound_th=0.025, pass_through_mask=(ids == 1).view(-1, 1))
+        loss = sum(((r["rgb_%s" % t] - target) ** 2).mean() + ((r["rgb_instance_%s" % t] - target) ** 2).mean()
+                   + 0.1 * (r["depth_%s" % t] ** 2).mean() + (r["opacity_instance_%s" % t] ** 2).mean() for t in ("coarse", "fine"))
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        opt.step()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        return loss.item(), t1, t2, t3
+
+    step()
+    rows = []
+    for _ in range(steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        loss, t1, t2, t3 = step()
+        rows.append((t1 - t0, t2 - t1, t3 - t2, loss))
+    fw, bw, op = (sorted(r[i] for r in rows)[len(rows) // 2] for i in range(3))
+    evals = n_rays * 192
+    flop = evals * 1776128 * 3.0          # forward + dgrad + wgrad
+    print("train step %d rays: forward %.1f ms, backward %.1f ms, Adam %.1f ms -> %.2f M ray-samples/s, "
+          "%.1f TFLOP/s (3x forward FLOP), loss %.4f -> %.4f"
+          % (n_rays, fw * 1e3, bw * 1e3, op * 1e3, evals / (fw + bw + op) / 1e6, flop / (fw + bw) / 1e12, rows[0][3], rows[-1][3]))
+
+
+if __name__ == "__main__":
+    main()
