@@ -24,9 +24,25 @@ __all__ = ["render_rays_multi"]
 
 def _mlp_one_branch(model, use_voxel, grid, rays, z, oid, code_library, l):
     """sigma (N,S), rgb (N,S,3) of one ray set: scene branch for id 0, object branch otherwise
-    (multi_rendering.py:45-51, 63-72)."""
-    n, S = z.shape
+    (multi_rendering.py:45-51, 63-72).
+
+    Rays whose last depth is 0 (they missed the object's box: near = far = 0, editable_renderer.py:175-176) get
+    sigma = -1e5 afterwards (multi_rendering.py:40,83,92), i.e. exactly zero weight, so their MLP evaluation cannot
+    influence any output.  The reference evaluates them anyway; here they are compacted away before the kernel
+    (index gather / scatter only) -- for the editing demo's object ray sets that is most of the image."""
+    n_all, S = z.shape
     dev = rays.device
+    active = (z[:, -1] != 0).nonzero().squeeze(1) if oid > 0 else None
+    if active is not None and active.numel() < n_all:
+        sigma_all = torch.full((n_all, S), -1e5, dtype=torch.float32, device=dev)
+        rgb_all = torch.zeros(n_all, S, 3, dtype=torch.float32, device=dev)
+        if active.numel() > 0:
+            sg, c = _mlp_one_branch(model, use_voxel, grid, rays.index_select(0, active).contiguous(),
+                                    z.index_select(0, active).contiguous(), oid, code_library, l)
+            sigma_all.index_copy_(0, active, sg)
+            rgb_all.index_copy_(0, active, c)
+        return sigma_all, rgb_all
+    n = n_all
     blob, aux = model.packed()
     a = _lib.MlpArgs()
     a.use_voxel = int(use_voxel)
