@@ -232,6 +232,7 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
 int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* coarse,
                         const objnerf_render_out* fine, void* stream) {
   if (!cfg || !in || !coarse) return set_error(-1, "render_rays: null argument");
+  if (in->n_rays == 0) return 0;          // empty batch: nothing to enqueue (zero-size tensors have null pointers)
   if (!in->rays || !in->workspace || !in->blob_coarse || !in->aux_coarse || !in->z_steps)
     return set_error(-1, "render_rays: missing input");
   if (!in->codes) return set_error(-1, "render_rays: embedding_instance is mandatory (rendering.py:94)");

@@ -1,0 +1,95 @@
+"""GPU: ragged / extreme sizes through the drop-in API against the oracle (which is bit-exact with the
+reference on CPU): single ray, empty batch, minimal and large sample counts, five ray sets."""
+import pytest
+import torch
+
+import cases
+import helpers as H
+import object_nerf_amd as A
+from object_nerf_amd import synth
+from object_nerf_amd.multi_rendering import render_rays_multi
+from oracle import objnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+_scenes = {}
+
+
+def scene(name):
+    if name not in _scenes:
+        _scenes[name] = cases.scene_for(A, name, device=DEV)
+    return _scenes[name]
+
+
+def run_both(sc, use_voxel, rays, ids, **kw):
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": ids.to(DEV)})["embedding_instance"].reshape(-1, 64)
+        out = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, perturb=0, noise_std=0, **kw)
+        grid = H.oracle_grid(sc.embeddings["xyz"]) if use_voxel else None
+        ref = O.render_rays(H.state(sc.models["coarse"]), H.state(sc.models["fine"]), grid, rays,
+                            embedding_instance=codes.cpu(), **kw)
+    return out, ref
+
+
+@pytest.mark.parametrize("S,I", [(3, 1), (5, 0), (64, 1), (33, 31), (200, 300), (1025, 64)])
+def test_sample_count_extremes(S, I):
+    sc = scene("plain")
+    n = 5 if S > 500 else 11
+    rays = H.test_rays(n, stride=131)
+    out, ref = run_both(sc, False, rays, synth.per_ray_ids(n), N_samples=S, N_importance=I, is_eval=True)
+    assert sorted(out) == sorted(ref)
+    for k in ref:
+        assert out[k].shape == ref[k].shape, k
+        tol = 1e-4 if k.endswith("coarse") else 5e-2
+        assert H.normwise(out[k], ref[k]) <= tol, "%s S=%d I=%d: %.3e" % (k, S, I, H.normwise(out[k], ref[k]))
+    if I > 0:
+        z = out["z_vals_fine"]
+        assert (z[:, 1:] >= z[:, :-1]).all()
+
+
+def test_single_ray_and_empty_batch():
+    sc = scene("voxel")
+    rays = H.test_rays(1)
+    out, ref = run_both(sc, True, rays, torch.tensor([3]), N_samples=64, N_importance=64, is_eval=True)
+    for k in ref:
+        assert out[k].shape == ref[k].shape
+        if k.endswith("coarse"):
+            assert H.normwise(out[k], ref[k]) <= 1e-4, k
+    with torch.no_grad():
+        e = A.render_rays(sc.models, sc.embeddings, torch.zeros(0, 8, device=DEV), N_samples=64, N_importance=64, perturb=0,
+                          noise_std=0, embedding_instance=torch.zeros(0, 64, device=DEV), is_eval=True)
+    assert e["rgb_fine"].shape == (0, 3) and e["weights_fine"].shape == (0, 128)
+
+
+def test_too_many_samples_is_an_error_not_a_crash():
+    sc = scene("plain")
+    rays = H.test_rays(2).to(DEV)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="sample_pdf_merge"):
+        A.render_rays(sc.models, sc.embeddings, rays, N_samples=1500, N_importance=700, perturb=0, noise_std=0,
+                      embedding_instance=torch.zeros(2, 64, device=DEV), is_eval=True)
+
+
+def test_five_ray_sets_like_the_toydesk_demo():
+    """render_rays_multi with K = 5 ray sets [0,1,2,3,5] (test/config/edit_toy_desk_2.yaml:9-11): composite width 640"""
+    sc = scene("voxel")
+    base, boxes = cases.multi_inputs()
+    sets = [base[0]] + [base[1 + (i % 2)].clone() for i in range(4)]
+    for i, s in enumerate(sets[1:]):
+        live = s[:, 7] > 0
+        s[live, 6] += 0.011 * (i + 1)            # distinct depths per set: no cross-set ties
+        s[live, 7] += 0.017 * (i + 1)
+    ids = [0, 1, 2, 3, 5]
+    with torch.no_grad():
+        r = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.to(DEV) for s in sets], ids, N_samples=64,
+                              N_importance=64, perturb=0, noise_std=0, background_skip_bbox={4: boxes[0]})
+        ref = O.render_rays_multi(H.state(sc.models["coarse"]), H.state(sc.models["fine"]), H.oracle_grid(sc.embeddings["xyz"]),
+                                  sc.code_library.embedding_instance.weight.detach().cpu(), sets, ids, N_samples=64,
+                                  N_importance=64, skip_boxes=boxes)
+    assert r["weights_coarse"].shape == (40, 320) and r["weights_fine"].shape == (40, 640)
+    for k in ref:
+        if k == "obj_ids_coarse":
+            nz = ref["z_vals_coarse"] != 0
+            assert torch.equal(r[k].cpu()[nz], ref[k][nz])
+        else:
+            tol = 1e-4 if k.endswith("coarse") else 3e-2
+            assert H.normwise(r[k], ref[k]) <= tol, k
