@@ -90,9 +90,12 @@ def main():
     kw = dict(N_samples=S, N_importance=I, perturb=0, noise_std=0, white_back=False, forward_instance=True,
               embedding_instance=codes, frustum_bound_th=preset["frustum_bound_th"], is_eval=True)
 
+    last = {}
+
     def step():
         with torch.no_grad():
             r = A.render_rays(sc.models, sc.embeddings, rays, **kw)
+            last["rgb_fine"] = r["rgb_fine"]
             if dist is not None:
                 return gather_pixels(r["rgb_fine"])
             return r["rgb_fine"]
@@ -151,7 +154,9 @@ def main():
                          "flop_per_eval": FLOP_PER_EVAL_BOTH_VOXEL, "mlp_time_frac_of_step": mlp_s / elapsed},
         }
         if world == 1 and args.cpu_rays > 0:
-            res["cpu_baseline"] = cpu_baseline(sc, rays, codes, kw, args.cpu_rays, evals_per_ray)
+            res["cpu_baseline"], psnr = cpu_baseline(sc, rays, codes, kw, args.cpu_rays, evals_per_ray, last["rgb_fine"])
+            # second half of BASELINE.json's metric ("+ PSNR vs ref"): utils/metrics.py:5-15 on the baseline's rays
+            res["psnr_vs_cpu_oracle_db"] = psnr
         chk = float(out.float().mean().item())
         res["config"]["mean_rgb_fine"] = chk
         print(json.dumps(res), flush=True)
@@ -177,9 +182,10 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(sc, rays, codes, kw, n_sample, evals_per_ray):
+def cpu_baseline(sc, rays, codes, kw, n_sample, evals_per_ray, gpu_rgb_fine):
     """Times the oracle (CPU restatement of the reference's PyTorch path; bit-exact with the
-    reference on CPU, tests/test_oracle_vs_reference.py) on `n_sample` rays spread over the frame."""
+    reference on CPU, tests/test_oracle_vs_reference.py) on `n_sample` rays spread over the frame, and
+    returns PSNR(GPU rgb_fine, oracle rgb_fine) on those rays."""
     from oracle import objnerf_oracle as O
     # host cores actually available to this process (cgroup/affinity aware), not the machine total
     try:
@@ -189,6 +195,7 @@ def cpu_baseline(sc, rays, codes, kw, n_sample, evals_per_ray):
     idx = torch.linspace(0, rays.shape[0] - 1, n_sample).long()
     r_cpu = rays[idx.to(rays.device)].cpu()
     c_cpu = codes[idx.to(rays.device)].cpu()
+    g_cpu = gpu_rgb_fine[idx.to(rays.device)].cpu()
     ev = sc.embeddings["xyz"]
     grid = dict(voxel_idx_map=ev.voxel_idx_map.cpu(), table=ev.embedding_space_ftr.weight.detach().cpu(),
                 voxel_offset=ev.voxel_offset.cpu(), voxel_size=ev.voxel_size.cpu(), voxel_shape=ev.voxel_shape.cpu())
@@ -217,16 +224,19 @@ def cpu_baseline(sc, rays, codes, kw, n_sample, evals_per_ray):
         if n_fit < n_sample:
             log("cpu_baseline: shrinking sample %d -> %d rays (%.1f ms/ray)" % (n_sample, n_fit, per_ray * 1e3))
             n_sample = n_fit
-            r_cpu, c_cpu = r_cpu[:n_sample], c_cpu[:n_sample]
+            r_cpu, c_cpu, g_cpu = r_cpu[:n_sample], c_cpu[:n_sample], g_cpu[:n_sample]
             okw["embedding_instance"] = c_cpu
         for _ in range(3):
             t0 = time.perf_counter()
-            O.render_rays(pc, pf, grid, r_cpu, **okw)
+            o_cpu = O.render_rays(pc, pf, grid, r_cpu, **okw)
             times.append(time.perf_counter() - t0)
     med = sorted(times)[1]
+    mse = ((g_cpu.double() - o_cpu["rgb_fine"].double()) ** 2).mean().item()
+    import math
+    psnr = -10.0 * math.log10(max(mse, 1e-30))
     return {"value": n_sample * evals_per_ray / med, "unit": "ray-samples/s", "cores": ncpu, "cores_available": avail, "kind": "port",
             "sample": "%d rays evenly spread over the frame, same weights/grid/codes, median of 3 (%.2f s each)"
-                      % (n_sample, med)}
+                      % (n_sample, med)}, psnr
 
 
 if __name__ == "__main__":

@@ -36,26 +36,22 @@ struct GemmArgs {
 
 constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = 36;
 
+// Staging is split in two (issue-early / write-late): the 16 floats a thread contributes to the next A' and B'
+// tiles are fetched into registers BEFORE the MFMAs of the current tile and written to LDS after them, so the
+// global-load latency hides under 32 MFMAs per wave.
 template <bool K_CONTIG>
-__device__ __forceinline__ void gemm_stage(float* lds, const float* src, long ld, long row0, long k0, long rows,
+__device__ __forceinline__ void gemm_fetch(float (&v)[16], const float* src, long ld, long row0, long k0, long rows,
                                            long kend, int tid) {
-  // fills lds[r][perm(k)] for r in [0,128), k in [0,32): 4096 floats, 16 per thread
   if (K_CONTIG) {
     // thread -> (row = tid/8 + 32*i, 4 consecutive k = (tid%8)*4)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (tid >> 3) + 32 * i, kk = (tid & 7) * 4;
       const long gr = row0 + r;
-      float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const long gk = k0 + kk + j;
-        v[j] = (gr < rows && gk < kend) ? src[gr * ld + gk] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = kk + j;
-        lds[r * GLD + (k & 1) * 16 + (k >> 1)] = v[j];
+        v[i * 4 + j] = (gr < rows && gk < kend) ? src[gr * ld + gk] : 0.f;
       }
     }
   } else {
@@ -67,9 +63,30 @@ __device__ __forceinline__ void gemm_stage(float* lds, const float* src, long ld
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const long gr = row0 + rr + j;
-        const float v = (gr < rows && gk < kend) ? src[gk * ld + gr] : 0.f;
-        lds[(rr + j) * GLD + (k & 1) * 16 + (k >> 1)] = v;
+        v[i * 4 + j] = (gr < rows && gk < kend) ? src[gk * ld + gr] : 0.f;
       }
+    }
+  }
+}
+template <bool K_CONTIG>
+__device__ __forceinline__ void gemm_put(float* lds, const float (&v)[16], int tid) {
+  // lds[r][perm(k)], perm(k) = (k & 1) * 16 + (k >> 1)
+  if (K_CONTIG) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (tid >> 3) + 32 * i, kk = (tid & 7) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kk + j;
+        lds[r * GLD + (k & 1) * 16 + (k >> 1)] = v[i * 4 + j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = (tid >> 5) + 8 * i, rr = (tid & 31) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds[(rr + j) * GLD + (k & 1) * 16 + (k >> 1)] = v[i * 4 + j];
     }
   }
 }
@@ -94,12 +111,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float va[16], vb[16];
+  if (kbeg < kend) {
+    gemm_fetch<A_KC>(va, g.A, g.lda, m0, kbeg, g.M, kend, tid);
+    gemm_fetch<B_KC>(vb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);     // B'[k][n]: "row" of the staged tile = n
+  }
   for (long k0 = kbeg; k0 < kend; k0 += GBK) {
+    __syncthreads();                       // every wave is done reading the previous tile
+    gemm_put<A_KC>(As, va, tid);
+    gemm_put<B_KC>(Bs, vb, tid);
     __syncthreads();
-    gemm_stage<A_KC>(As, g.A, g.lda, m0, k0, g.M, kend, tid);
-    // B'[k][n]: "row" of the staged tile = n
-    gemm_stage<B_KC>(Bs, g.B, g.ldb, n0, k0, g.N, kend, tid);
-    __syncthreads();
+    if (k0 + GBK < kend) {                 // next tile's global loads fly under this tile's MFMAs
+      gemm_fetch<A_KC>(va, g.A, g.lda, m0, k0 + GBK, g.M, kend, tid);
+      gemm_fetch<B_KC>(vb, g.B, g.ldb, n0, k0 + GBK, g.N, kend, tid);
+    }
     const int half = lane >> 5, rl = lane & 31;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {       // 4 MFMA steps (k pairs) per 16-byte read
