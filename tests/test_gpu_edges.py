@@ -93,3 +93,21 @@ def test_five_ray_sets_like_the_toydesk_demo():
         else:
             tol = 1e-4 if k.endswith("coarse") else 3e-2
             assert H.normwise(r[k], ref[k]) <= tol, k
+
+
+def test_non_contiguous_and_float64_inputs_are_accepted():
+    """callers hand over slices / other dtypes (train.py:77-83 slices every tensor); the wrapper normalises them"""
+    sc = scene("plain")
+    n = 16
+    wide = torch.zeros(n, 12, dtype=torch.float64)
+    wide[:, 2:10] = H.test_rays(n).double()
+    rays_view = wide[:, 2:10].to(DEV)                    # float64, non-contiguous after the slice on device
+    ids = synth.per_ray_ids(n)
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": ids.to(DEV)})["embedding_instance"]
+        a = A.render_rays(sc.models, sc.embeddings, rays_view, N_samples=32, N_importance=32, perturb=0, noise_std=0,
+                          embedding_instance=codes.double(), is_eval=True, chunk=7)
+        b = A.render_rays(sc.models, sc.embeddings, H.test_rays(n).to(DEV), N_samples=32, N_importance=32, perturb=0,
+                          noise_std=0, embedding_instance=codes, is_eval=True)
+    for k in a:
+        assert a[k].dtype == torch.float32 and torch.equal(a[k], b[k]), k
