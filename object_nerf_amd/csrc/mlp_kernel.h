@@ -42,6 +42,9 @@
 #ifndef OBJ_OCTAVE_DOUBLING
 #define OBJ_OCTAVE_DOUBLING 1   // sin/cos of 2a from (sin a, cos a) for 2 of every 3 octaves of one argument
 #endif
+#ifndef OBJ_PREFETCH_TILE
+#define OBJ_PREFETCH_TILE 1  // gather prologue of the NEXT tile staged between the object-branch layers
+#endif
 #ifndef OBJ_CODE_REGS
 #define OBJ_CODE_REGS 1      // object code (32 floats per lane half) loaded once per pass into VGPRs
 #endif
@@ -500,6 +503,104 @@ __device__ __forceinline__ VoxelCell voxel_cell(const objnerf_voxel_grid& g, flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-tile gather prologue, in stages.  Run back to back it is the plain prologue; with OBJ_PREFETCH_TILE the
+// stages of the NEXT tile are placed between the object-branch layers of the current one, so that each level
+// of its dependent loads (ray row + depth -> 8 index-map reads -> 24 feature-row reads) has a whole layer of
+// MFMAs to land (the chain cost 1.5 % of the kernel when it ran at the top of every pass).
+// Arithmetic and its order are identical in both placements.
+// ---------------------------------------------------------------------------------------------
+template <bool VOXEL>
+struct TilePrologue {
+  long p, ray;
+  bool valid;
+  float rw[8];         // ray row [o, d, near, far]
+  float zv;
+  float pos[3], dir[3];
+  float w[8];          // trilinear corner weights
+  int idx[8];          // index-map entries (or -1: out of the grid)
+  f32x4 rows[12];      // feature rows in flight: 4 corners x {scene lo, scene hi, object} quarter rows of this half
+  float vf[12];
+
+  __device__ __forceinline__ void stage_a(const objnerf_mlp_args& a, long tile, long P, int wave, int lane) {
+    const long p_raw = tile * 128 + wave * 32 + (lane & 31);
+    valid = p_raw < P;
+    p = valid ? p_raw : P - 1;
+    ray = p / a.S;
+    const float* r = a.rays + ray * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rw[i] = r[i];
+    zv = a.z_vals[p];
+  }
+  __device__ __forceinline__ void stage_b(const objnerf_voxel_grid& g) {
+    // xyz = rays_o + rays_d * z  (rendering.py:279): separately rounded mul and add
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dir[c] = rw[3 + c];
+      pos[c] = rw[c] + dir[c] * zv;
+    }
+    if constexpr (VOXEL) {
+      const float sx = __fdiv_rn(pos[0] + g.offset[0], g.voxel_size);
+      const float sy = __fdiv_rn(pos[1] + g.offset[1], g.voxel_size);
+      const float sz = __fdiv_rn(pos[2] + g.offset[2], g.voxel_size);
+      const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
+      const float u = sx - qx, v = sy - qy, ww = sz - qz;
+      const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - ww;
+      w[0] = (lu * lv) * lw; w[1] = (lu * lv) * ww; w[2] = (lu * v) * lw; w[3] = (lu * v) * ww;
+      w[4] = (u * lv) * lw;  w[5] = (u * lv) * ww;  w[6] = (u * v) * lw;  w[7] = (u * v) * ww;
+      const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
+        const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
+        idx[k] = ok ? g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz] : -1;
+      }
+    }
+  }
+  // issue the feature-row reads of corners [4*H, 4*H+4)
+  template <int H>
+  __device__ __forceinline__ void stage_rows(const objnerf_voxel_grid& g, int half) {
+    if constexpr (VOXEL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = idx[4 * H + j];
+        const int row = (r < 0 || r >= g.n_rows) ? -1 : r;
+        idx[4 * H + j] = row;
+        const float* t = g.table + (size_t)(row < 0 ? 0 : row) * kVoxC;
+        rows[3 * j + 0] = *(const f32x4*)(t + half * 8);
+        rows[3 * j + 1] = *(const f32x4*)(t + half * 8 + 4);
+        rows[3 * j + 2] = *(const f32x4*)(t + kScnVoxC + half * 4);
+      }
+    }
+  }
+  // voxel_ftr[invalid] = 0 ; (voxel_ftr * weights).sum(0)   (embedding_helper.py:351,387-389), corners in order
+  template <int H>
+  __device__ __forceinline__ void stage_acc() {
+    if constexpr (VOXEL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * H + j;
+        const bool bad = idx[k] < 0;
+        const float wk = w[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float f0 = bad ? 0.f : rows[3 * j][i], f1 = bad ? 0.f : rows[3 * j + 1][i], f2 = bad ? 0.f : rows[3 * j + 2][i];
+          if (k == 0) { vf[i] = f0 * wk; vf[4 + i] = f1 * wk; vf[8 + i] = f2 * wk; }
+          else { vf[i] = vf[i] + f0 * wk; vf[4 + i] = vf[4 + i] + f1 * wk; vf[8 + i] = vf[8 + i] + f2 * wk; }
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void run_all(const objnerf_mlp_args& a, long tile, long P, int wave, int lane, int half) {
+    stage_a(a, tile, P, wave, lane);
+    stage_b(a.grid);
+    stage_rows<0>(a.grid, half);
+    stage_acc<0>();
+    stage_rows<1>(a.grid, half);
+    stage_acc<1>();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false>
@@ -535,57 +636,54 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   constexpr int NE = ks_emb(VOXEL);
   constexpr int NO = ks_objin(VOXEL);
 
+  constexpr bool PREFETCH = OBJ_PREFETCH_TILE && FUSED && DO_OBJ;
+  TilePrologue<VOXEL> pre;
+  if constexpr (FUSED) {
+#ifdef OBJ_ABL_PROLOGUE     // timing ablation only: no voxel gather
+    pre.stage_a(a, blockIdx.x, P, wave, lane);
+    pre.stage_b(a.grid);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pre.vf[i] = pre.pos[i % 3];
+#else
+    pre.run_all(a, blockIdx.x, P, wave, lane, half);
+#endif
+  }
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long p_raw = tile * 128 + wave * 32 + (lane & 31);
-    const bool valid = p_raw < P;
-    const long p = valid ? p_raw : P - 1;
-
+    long p;
+    bool valid;
     Src src;
     src.half = half;
     if constexpr (FUSED) {
-      const long ray = p / a.S;
-      const float* r = a.rays + ray * 8;
-      const float zv = a.z_vals[p];
-      // xyz = rays_o + rays_d * z  (rendering.py:279): separately rounded mul and add
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        src.dir[c] = r[3 + c];
-        src.pos[c] = r[c] + src.dir[c] * zv;
-      }
-      src.fscale = half ? 32.f : 1.f;
-      src.dscale = half ? 4.f : 1.f;
-      src.code = DO_OBJ ? a.codes + ray * a.code_stride + half * 32 : nullptr;
-#ifdef OBJ_ABL_PROLOGUE     // timing ablation only: no voxel gather
-      if constexpr (false) {
+      if constexpr (!PREFETCH) {
+        if (tile != (long)blockIdx.x) {
+#ifdef OBJ_ABL_PROLOGUE
+          pre.stage_a(a, tile, P, wave, lane);
+          pre.stage_b(a.grid);
 #else
-      if constexpr (VOXEL) {
+          pre.run_all(a, tile, P, wave, lane, half);
 #endif
-        const VoxelCell cell = voxel_cell(a.grid, src.pos[0], src.pos[1], src.pos[2]);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) src.vf[i] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int row = cell.row[k];
-          const float* t = a.grid.table + (size_t)(row < 0 ? 0 : row) * kVoxC;
-          f32x4 s0 = *(const f32x4*)(t + half * 8);
-          f32x4 s1 = *(const f32x4*)(t + half * 8 + 4);
-          f32x4 o0 = *(const f32x4*)(t + kScnVoxC + half * 4);
-          const float wk = cell.w[k];
-          // voxel_ftr[invalid] = 0 ; (voxel_ftr * weights).sum(0)   (embedding_helper.py:351,387-389)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float f0 = row < 0 ? 0.f : s0[i], f1 = row < 0 ? 0.f : s1[i], f2 = row < 0 ? 0.f : o0[i];
-            if (k == 0) { src.vf[i] = f0 * wk; src.vf[4 + i] = f1 * wk; src.vf[8 + i] = f2 * wk; }
-            else { src.vf[i] = src.vf[i] + f0 * wk; src.vf[4 + i] = src.vf[4 + i] + f1 * wk; src.vf[8 + i] = src.vf[8 + i] + f2 * wk; }
-          }
         }
       }
+      p = pre.p;
+      valid = pre.valid;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { src.dir[c] = pre.dir[c]; src.pos[c] = pre.pos[c]; }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) src.vf[i] = pre.vf[i];
+      src.fscale = half ? 32.f : 1.f;
+      src.dscale = half ? 4.f : 1.f;
+      src.code = DO_OBJ ? a.codes + pre.ray * a.code_stride + half * 32 : nullptr;
     } else {
+      const long p_raw = tile * 128 + wave * 32 + (lane & 31);
+      valid = p_raw < P;
+      p = valid ? p_raw : P - 1;
       src.exyz = a.emb_xyz + p * in_xyz(VOXEL);
       src.edir = a.emb_dir + p * kDirC;
       src.ovox = (VOXEL && DO_OBJ) ? a.obj_voxel + p * kObjVoxPE : nullptr;
       src.ocode = DO_OBJ ? a.obj_code + p * kCodeC : nullptr;
     }
+    // tile whose prologue is staged during this pass (the last pass re-stages its own tile: harmless)
+    const long tile_next = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
 
     if constexpr (DO_SCENE) {
       f32x16 acc[8], h[8];
@@ -641,21 +739,26 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
     if constexpr (DO_OBJ) {
       f32x16 acc[4], h[4];
       src.fetch_code();      // 8 x 16-B loads, consumed ~190 k-steps later: latency fully hidden
+      if constexpr (PREFETCH) pre.stage_a(a, tile_next, P, wave, lane);
       src.launder();
       load_bias<4>(acc, aux, L_O1, half);
       { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
       finish<4, true>(acc, h);
+      if constexpr (PREFETCH) pre.stage_b(a.grid);
       load_bias<4>(acc, aux, L_O2, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
       finish<4, true>(acc, h);
+      if constexpr (PREFETCH) pre.template stage_rows<0>(a.grid, half);
       src.launder();
       load_bias<4>(acc, aux, L_O3, half);
       { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s); }
       finish<4, true>(acc, h);
+      if constexpr (PREFETCH) { pre.template stage_acc<0>(); pre.template stage_rows<1>(a.grid, half); }
       load_bias<4>(acc, aux, L_O4, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
       finish<4, true>(acc, h);
       const float sg = head_dot<4>(h, aux + kAuxOSig, half) + aux[kAuxOSig + 4 * 32];
+      if constexpr (PREFETCH) pre.template stage_acc<1>();
       if constexpr (SIGMA_ONLY) {
         if (valid && half == 0) a.inst_sigma[p] = sg;
       } else {
