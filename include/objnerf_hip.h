@@ -260,7 +260,8 @@ int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* 
 /* C[M,N] = A'[M,K] * B'[K,N] (+ C) with optional bias / LeakyReLU / sigmoid epilogue: the fp32 MFMA GEMM of the
  * layer-wise training path (csrc/gemm.h).  A'[m][k] = a_k_contig ? A[m*lda+k] : A[k*lda+m];
  * B'[k][n] = b_k_contig ? B[n*ldb+k] : B[k*ldb+n].  split_k > 1 adds with fp32 atomics (C must hold the
- * initial value).  epilogue: 0 none, 1 +bias, 2 +bias+LeakyReLU(0.01), 3 +bias+sigmoid. */
+ * initial value).  epilogue: 0 none, 1 +bias, 2 +bias+LeakyReLU(0.01), 3 +bias+sigmoid, 4 LeakyReLU backward:
+ * `bias` then points at the layer's saved output Y[M,N] (leading dimension ldc) and C = Y > 0 ? C : 0.01 C. */
 int objnerf_gemm(const float* A, int64_t lda, int a_k_contig, const float* B, int64_t ldb, int b_k_contig,
                  float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, int epilogue,
                  const float* bias, int split_k, void* stream);

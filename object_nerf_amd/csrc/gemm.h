@@ -10,18 +10,18 @@
 //
 // 128 x 128 x 32 tile per 256-thread workgroup, 2 x 2 waves each owning 2 x 2 tiles of
 // v_mfma_f32_32x32x2_f32 (exact fp32 = an fmaf chain, so results are fp32-roundoff identical to any
-// other fp32 GEMM).  Operand tiles go through LDS with the k index stored as (k & 1) * 16 + (k >> 1), so
-// that the two lane halves of an MFMA (which contract k = 2s and 2s + 1) each read 16 contiguous floats
-// (4 x ds_read_b128 per 16 MFMA steps); rows are padded to 36 floats against bank conflicts.  Split-K with
-// fp32 atomics when the output has too few tiles to fill 256 CUs (wgrad: K = 10^5..10^6 points).
-// This is a correctness-first kernel for the non-headline training path, not a tuned SGEMM.
+// other fp32 GEMM).  Operand tiles are staged global -> registers -> LDS with 16-byte accesses, double
+// buffered (one barrier per k tile); a K-contiguous operand is stored [row][k] (rows padded to 36 floats) and
+// read with one ds_read_b128 per 4 MFMA steps, a row-contiguous one [k][row] and read with ds_read_b32 --
+// both conflict-free on the write and on the read side.  Split-K with fp32 atomics when the output has too
+// few tiles to fill 256 CUs (wgrad: K = 10^5..10^6 points).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_math.h"
 
 namespace objnerf {
 
-enum GemmEpilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_LEAKY = 2, EPI_BIAS_SIGMOID = 3 };
+enum GemmEpilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_LEAKY = 2, EPI_BIAS_SIGMOID = 3, EPI_LEAKY_BWD = 4 };
 
 struct GemmArgs {
   const float* A; long lda; int a_k_contig;   // A'[m][k] = a_k_contig ? A[m*lda + k] : A[k*lda + m]
@@ -30,71 +30,107 @@ struct GemmArgs {
   long M, N, K;
   int accumulate;        // C += (atomicAdd when split_k > 1)
   int epilogue;          // GemmEpilogue, applied to the complete sum (split_k must be 1)
-  const float* bias;     // N floats
+  const float* bias;     // N floats; EPI_LEAKY_BWD: the layer's saved output, M x N with leading dimension ldc
   int split_k;           // >= 1
+  float* rowsum;         // optional, row-contiguous A' only: rowsum[m] += sum_k A'[m][k] (a Linear layer's bias gradient
+                         // when A' = dY^T), accumulated with atomics by the workgroups of the first column of tiles
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = 36;
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+constexpr int GLDK = 36;      // K-contiguous operands sit in LDS as [row][k], rows padded to 36 floats against bank conflicts
+constexpr int GLDR = 128;     // row-contiguous operands sit in LDS as [k][row]
+constexpr int GTILE = GBM * GLDK;   // floats per staged operand tile (>= GBK * GLDR)
+#ifndef OBJ_GEMM_DOUBLE_BUFFER
+#define OBJ_GEMM_DOUBLE_BUFFER 0
+#endif
 
-// Staging is split in two (issue-early / write-late): the 16 floats a thread contributes to the next A' and B'
-// tiles are fetched into registers BEFORE the MFMAs of the current tile and written to LDS after them, so the
-// global-load latency hides under 32 MFMAs per wave.
+// One operand of a workgroup: 128 "rows" (m for A', n for B') x 32 k per tile.  Global -> registers (16-byte loads
+// whenever the operand allows it) -> LDS in the layout its MFMA reads want; the fetch of tile t+1 is issued before
+// the MFMAs of tile t and written to the other LDS buffer after them, so its latency hides under 64 MFMAs per wave.
+// Contraction index of MFMA step (s4, s) in lane half h is k = 16 h + 4 s4 + s for both operands (any bijection
+// is a valid summation order), which makes a K-contiguous row a plain copy: no shuffle on the way to LDS.
 template <bool K_CONTIG>
-__device__ __forceinline__ void gemm_fetch(float (&v)[16], const float* src, long ld, long row0, long k0, long rows,
-                                           long kend, int tid) {
-  if (K_CONTIG) {
-    // thread -> (row = tid/8 + 32*i, 4 consecutive k = (tid%8)*4)
+struct GemmOperand {
+  const float* p[4];     // this thread's four 16-byte pieces of the current tile
+  long step;             // pointer advance per k tile
+  long rows_left;        // row-contiguous: rows - (first of this thread's 4 rows); K-contiguous: unused
+  bool ok[4];            // K-contiguous: piece's row is inside the operand
+  bool fast;             // uniform: every full k tile can be fetched with unconditional 16-byte loads
+  f32x4 v[4];
+
+  __device__ __forceinline__ void init(const float* src, long ld, long row0, long rows, long kbeg, int tid) {
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    if (K_CONTIG) {
+      // thread -> rows tid/8 + 32 i, k = 4 (tid % 8) .. + 3.  Rows past the end are clamped, not zeroed: an output
+      // row depends only on its own operand row, and rows past the end are never stored.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (tid >> 3) + 32 * i, kk = (tid & 7) * 4;
-      const long gr = row0 + r;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const long gk = k0 + kk + j;
-        v[i * 4 + j] = (gr < rows && gk < kend) ? src[gr * ld + gk] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const long gr = row0 + (tid >> 3) + 32 * i;
+        ok[i] = gr < rows;
+        p[i] = src + (ok[i] ? gr : rows - 1) * ld + kbeg + 4 * (tid & 7);
       }
-    }
-  } else {
-    // row index contiguous in memory: thread -> (k = tid/32 + 8*i, 4 consecutive rows = (tid%32)*4)
+      step = GBK;
+      rows_left = 0;
+      fast = vec;
+    } else {
+      // thread -> k = tid/32 + 8 i, rows 4 (tid % 32) .. + 3
+      const long r = row0 + 4 * (tid & 31);
+      rows_left = rows - r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = (tid >> 5) + 8 * i, rr = (tid & 31) * 4;
-      const long gk = k0 + k;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const long gr = row0 + rr + j;
-        v[i * 4 + j] = (gr < rows && gk < kend) ? src[gk * ld + gr] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        ok[i] = true;
+        p[i] = src + (kbeg + (tid >> 5) + 8 * i) * ld + (rows_left > 0 ? r : 0);
       }
+      step = GBK * ld;
+      fast = vec && row0 + GBM <= rows;
     }
   }
-}
-template <bool K_CONTIG>
-__device__ __forceinline__ void gemm_put(float* lds, const float (&v)[16], int tid) {
-  // lds[r][perm(k)], perm(k) = (k & 1) * 16 + (k >> 1)
-  if (K_CONTIG) {
+  // k0: first k of the tile being fetched.  The contraction range must be zero-filled in BOTH operands
+  // (0 x garbage could be NaN), which only the last tile of a split needs.
+  __device__ __forceinline__ void fetch(long k0, long kend, int tid) {
+    if (fast && k0 + GBK <= kend) {            // uniform branch
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (tid >> 3) + 32 * i, kk = (tid & 7) * 4;
+      for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)p[i];
+    } else if (K_CONTIG) {
+      const long gk = k0 + 4 * (tid & 7);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = kk + j;
-        lds[r * GLD + (k & 1) * 16 + (k >> 1)] = v[i * 4 + j];
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (gk + j < kend) ? p[i][j] : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool kin = k0 + (tid >> 5) + 8 * i < kend;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (kin && j < rows_left) ? p[i][j] : 0.f;
       }
     }
-  } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = (tid >> 5) + 8 * i, rr = (tid & 31) * 4;
+    for (int i = 0; i < 4; ++i) p[i] += step;
+  }
+  __device__ __forceinline__ void put(float* lds, int tid) const {
+    if (K_CONTIG) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lds[(rr + j) * GLD + (k & 1) * 16 + (k >> 1)] = v[i * 4 + j];
+      for (int i = 0; i < 4; ++i) *(f32x4*)&lds[((tid >> 3) + 32 * i) * GLDK + 4 * (tid & 7)] = v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(f32x4*)&lds[((tid >> 5) + 8 * i) * GLDR + 4 * (tid & 31)] = v[i];
     }
   }
-}
+  // the four MFMA operands (steps s = 0..3 of group s4) of tile row `row` for lane half `half`
+  static __device__ __forceinline__ f32x4 frag(const float* lds, int row, int half, int s4) {
+    if (K_CONTIG) return *(const f32x4*)&lds[row * GLDK + 16 * half + 4 * s4];
+    f32x4 t;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t[s] = lds[(16 * half + 4 * s4 + s) * GLDR + row];
+    return t;
+  }
+};
 
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[GBM * GLD];
-  __shared__ __attribute__((aligned(16))) float Bs[GBN * GLD];
+  constexpr int NBUF = OBJ_GEMM_DOUBLE_BUFFER ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * 2 * GTILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const long m0 = (long)blockIdx.y * GBM, n0 = (long)blockIdx.x * GBN;
@@ -111,37 +147,66 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float va[16], vb[16];
-  if (kbeg < kend) {
-    gemm_fetch<A_KC>(va, g.A, g.lda, m0, kbeg, g.M, kend, tid);
-    gemm_fetch<B_KC>(vb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);     // B'[k][n]: "row" of the staged tile = n
-  }
-  for (long k0 = kbeg; k0 < kend; k0 += GBK) {
-    __syncthreads();                       // every wave is done reading the previous tile
-    gemm_put<A_KC>(As, va, tid);
-    gemm_put<B_KC>(Bs, vb, tid);
-    __syncthreads();
-    if (k0 + GBK < kend) {                 // next tile's global loads fly under this tile's MFMAs
-      gemm_fetch<A_KC>(va, g.A, g.lda, m0, k0 + GBK, g.M, kend, tid);
-      gemm_fetch<B_KC>(vb, g.B, g.ldb, n0, k0 + GBK, g.N, kend, tid);
-    }
+  float rsum = 0.f;
+  const bool want_rowsum = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;     // uniform
+  if (kbeg < kend) {          // uniform per workgroup
+    GemmOperand<A_KC> opa;
+    GemmOperand<B_KC> opb;    // B'[k][n]: "row" of the staged tile = n
+    opa.init(g.A, g.lda, m0, g.M, kbeg, tid);
+    opb.init(g.B, g.ldb, n0, g.N, kbeg, tid);
+    opa.fetch(kbeg, kend, tid);
+    opb.fetch(kbeg, kend, tid);
     const int half = lane >> 5, rl = lane & 31;
+    int buf = 0;
+    if (NBUF == 2) {
+      opa.put(lds, tid);
+      opb.put(lds + GTILE, tid);
+      __syncthreads();
+    }
+    for (long k0 = kbeg; k0 < kend; k0 += GBK) {
+      const bool more = k0 + GBK < kend;
+      float* As = lds + buf * 2 * GTILE;
+      float* Bs = As + GTILE;
+      if (NBUF == 1) {
+        __syncthreads();                     // every wave is done reading the previous tile
+        opa.put(As, tid);
+        opb.put(Bs, tid);
+        __syncthreads();
+      }
+      if (more) {                            // next tile's global loads fly under this tile's MFMAs
+        opa.fetch(k0 + GBK, kend, tid);
+        opb.fetch(k0 + GBK, kend, tid);
+      }
+      if (want_rowsum) {                     // A' tile is [k][row]: thread -> row tid % 128, 16 of the 32 k
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {       // 4 MFMA steps (k pairs) per 16-byte read
-      f32x4 a[2], b[2];
+        for (int kk = 0; kk < 16; ++kk) rsum += As[((tid >> 7) * 16 + kk) * GLDR + (tid & 127)];
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *(const f32x4*)&As[(wm * 64 + i * 32 + rl) * GLD + half * 16 + s4 * 4];
+      for (int s4 = 0; s4 < 4; ++s4) {       // 4 MFMA steps per fragment read
+        f32x4 a[2], b[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *(const f32x4*)&Bs[(wn * 64 + j * 32 + rl) * GLD + half * 16 + s4 * 4];
+        for (int i = 0; i < 2; ++i) a[i] = GemmOperand<A_KC>::frag(As, wm * 64 + i * 32 + rl, half, s4);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 2; ++j) b[j] = GemmOperand<B_KC>::frag(Bs, wn * 64 + j * 32 + rl, half, s4);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+      }
+      if (NBUF == 2) {
+        if (more) {                          // the other buffer was last read before the previous barrier
+          opa.put(lds + (buf ^ 1) * 2 * GTILE, tid);
+          opb.put(lds + (buf ^ 1) * 2 * GTILE + GTILE, tid);
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
     }
   }
+  if (want_rowsum && m0 + (tid & 127) < g.M) atomicAdd(g.rowsum + m0 + (tid & 127), rsum);
   // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -150,7 +215,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     for (int j = 0; j < 2; ++j) {
       const long n = n0 + wn * 64 + j * 32 + col;
       if (n >= g.N) continue;
-      const float bv = (g.epilogue != EPI_NONE && g.bias) ? g.bias[n] : 0.f;
+      const bool lbwd = g.epilogue == EPI_LEAKY_BWD;
+      const float bv = (g.epilogue != EPI_NONE && !lbwd && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
@@ -159,7 +225,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         float v = acc[i][j][r];
         if (g.split_k > 1) { atomicAdd(c, v); continue; }
         if (g.accumulate) v += *c;
-        if (g.epilogue != EPI_NONE) {
+        if (lbwd) {                  // leaky_relu backward on sign(output) = sign(input)
+          v = g.bias[m * g.ldc + n] > 0.f ? v : 0.01f * v;
+        } else if (g.epilogue != EPI_NONE) {
           v += bv;
           if (g.epilogue == EPI_BIAS_LEAKY) v = leaky(v);
           else if (g.epilogue == EPI_BIAS_SIGMOID) v = sigmoidf(v);

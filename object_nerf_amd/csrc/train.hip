@@ -28,33 +28,10 @@ int gemm_launch(const GemmArgs& g, hipStream_t s) {
 }
 
 // ---- element-wise helpers ------------------------------------------------------------------------
-__global__ void leaky_bwd_kernel(float* __restrict__ d, const float* __restrict__ act, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) d[i] = act[i] > 0.f ? d[i] : 0.01f * d[i];          // leaky_relu backward on sign(output) = sign(input)
-}
 __global__ void sigmoid_bwd_kernel(float* __restrict__ dz, const float* __restrict__ dy, const float* __restrict__ y, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dz[i] = dy[i] * (y[i] * (1.f - y[i]));
 }
-// out[c] += sum_p x[p, c]  (x: P x C with leading dimension ld); one block per 256-row slab, atomics per column
-__global__ void colsum_kernel(const float* __restrict__ x, long P, int C, long ld, float* __restrict__ out) {
-  __shared__ float part[256];
-  const int c = blockIdx.y * 32 + (threadIdx.x & 31);
-  const int rlane = threadIdx.x >> 5;                              // 8 row lanes
-  const long p0 = (long)blockIdx.x * 2048;
-  float s = 0.f;
-  if (c < C)
-    for (long p = p0 + rlane; p < p0 + 2048 && p < P; p += 8) s += x[p * ld + c];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (rlane == 0 && c < C) {
-    float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t += part[r * 32 + (threadIdx.x & 31)];
-    atomicAdd(out + c, t);
-  }
-}
-
 struct Ctx {
   hipStream_t s;
   int rc;
@@ -65,40 +42,31 @@ static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 static void lin_fwd(Ctx& c, const float* X, long ldx, const float* W, long ldw, long P, int out, int in, float* Y, long ldy,
                     int accumulate, int epi, const float* bias) {
   if (c.rc) return;
-  GemmArgs g{X, ldx, 1, W, ldw, 1, Y, ldy, P, out, in, accumulate, epi, bias, 1};
+  GemmArgs g{X, ldx, 1, W, ldw, 1, Y, ldy, P, out, in, accumulate, epi, bias, 1, nullptr};
   c.rc = gemm_launch(g, c.s);
 }
 // dX (P x in) (+)= dY (P x out) * W (out x in)
+// `act` (P x in, leading dimension lddx): the saved output of the LeakyReLU layer dX belongs to; the activation's
+// backward is then applied to the complete sum in the epilogue instead of in a pass of its own
 static void lin_dgrad(Ctx& c, const float* dY, long lddy, const float* W, long ldw, long P, int out, int in, float* dX,
-                      long lddx, int accumulate) {
+                      long lddx, int accumulate, const float* act = nullptr) {
   if (c.rc) return;
-  GemmArgs g{dY, lddy, 1, W, ldw, 0, dX, lddx, P, in, out, accumulate, EPI_NONE, nullptr, 1};
+  GemmArgs g{dY, lddy, 1, W, ldw, 0, dX, lddx, P, in, out, accumulate, act ? EPI_LEAKY_BWD : EPI_NONE, act, 1, nullptr};
   c.rc = gemm_launch(g, c.s);
 }
 // dW (out x in, ld ldw) += dY^T (out x P) * X (P x in); split over the points
+// db (optional): the layer's bias gradient, db[o] += sum_p dY[p, o], taken from the dY^T tiles this GEMM stages anyway
 static void lin_wgrad(Ctx& c, const float* dY, long lddy, const float* X, long ldx, long P, int out, int in, float* dW,
-                      long ldw) {
+                      long ldw, float* db = nullptr) {
   if (c.rc) return;
   const long tiles = ((out + GBM - 1) / GBM) * (long)((in + GBN - 1) / GBN);
   long split = (1024 + tiles - 1) / tiles;                          // ~4 workgroups per CU
   const long max_split = (P + 4 * GBK - 1) / (4 * GBK);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
-  GemmArgs g{dY, lddy, 0, X, ldx, 0, dW, ldw, out, in, P, 1, EPI_NONE, nullptr, (int)(split > 1 ? split : 2)};
+  GemmArgs g{dY, lddy, 0, X, ldx, 0, dW, ldw, out, in, P, 1, EPI_NONE, nullptr, (int)(split > 1 ? split : 2), db};
   c.rc = gemm_launch(g, c.s);       // split_k >= 2 forces the atomic += path (dW always accumulates)
 }
-static void bias_grad(Ctx& c, const float* dY, long ld, long P, int C, float* db) {
-  if (c.rc) return;
-  dim3 grid((unsigned)((P + 2047) / 2048), (unsigned)((C + 31) / 32));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, c.s, dY, P, C, ld, db);
-  c.rc = check_launch("colsum");
-}
-static void leaky_bwd(Ctx& c, float* d, const float* act, long n) {
-  if (c.rc) return;
-  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(nblk(n)), dim3(256), 0, c.s, d, act, n);
-  c.rc = check_launch("leaky_bwd");
-}
-
 // saved-activation layout (floats per point)
 struct Ws {
   long P;
@@ -127,7 +95,7 @@ int objnerf_gemm(const float* A, int64_t lda, int a_k_contig, const float* B, in
                  int split_k, void* stream) {
   if (!A || !B || !C || split_k < 1) return set_error(-1, "gemm: bad arguments");
   if (split_k > 1 && epilogue != EPI_NONE) return set_error(-1, "gemm: epilogue needs split_k == 1");
-  GemmArgs g{A, lda, a_k_contig, B, ldb, b_k_contig, C, ldc, M, N, K, accumulate, epilogue, bias, split_k};
+  GemmArgs g{A, lda, a_k_contig, B, ldb, b_k_contig, C, ldc, M, N, K, accumulate, epilogue, bias, split_k, nullptr};
   return gemm_launch(g, (hipStream_t)stream);
 }
 
@@ -212,38 +180,32 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   // ---- scene branch ----
   // rgb = sigmoid(dirh Wr^T + br)
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_rgb, a->rgb, 3 * P);
-  lin_wgrad(c, t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128);
-  bias_grad(c, t2, 3, P, 3, gB(P_SRGB));
-  lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, t0, 128, 0);              // d dirh
-  leaky_bwd(c, t0, w.dirh(), 128 * P);
-  lin_wgrad(c, t0, 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC);
+  lin_wgrad(c, t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128, gB(P_SRGB));
+  lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, t0, 128, 0, w.dirh());    // d dirh (pre-activation)
+  lin_wgrad(c, t0, 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC, gB(P_SD));
   lin_wgrad(c, t0, 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
-  bias_grad(c, t0, 128, P, 128, gB(P_SD));
   lin_dgrad(c, t0, 128, Wt(P_SD), 256 + kDirC, P, 128, 256, t1, 256, 0);     // d final
-  lin_wgrad(c, t1, 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256);
-  bias_grad(c, t1, 256, P, 256, gB(P_SF));
+  lin_wgrad(c, t1, 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256, gB(P_SF));
   lin_dgrad(c, t1, 256, Wt(P_SF), 256, P, 256, 256, t0, 256, 0);             // dA8 (from final)
-  lin_dgrad(c, d_sigma, 1, Wt(P_SSIG), 256, P, 1, 256, t0, 256, 1);          // + d sigma * w_sigma
-  lin_wgrad(c, d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256);
-  bias_grad(c, d_sigma, 1, P, 1, gB(P_SSIG));
+  lin_dgrad(c, d_sigma, 1, Wt(P_SSIG), 256, P, 1, 256, t0, 256, 1, w.A(8));  // + d sigma * w_sigma, then leaky
+  lin_wgrad(c, d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256, gB(P_SSIG));
   float* dA = t0;
   float* dN = t1;
   bool emb_written = false;
-  for (int l = 8; l >= 1; --l) {
-    leaky_bwd(c, dA, w.A(l), 256 * P);
-    bias_grad(c, dA, 256, P, 256, gB(P_S1 + l - 1));
+  for (int l = 8; l >= 1; --l) {      // dA = gradient w.r.t. layer l's pre-activation
+    float* db = gB(P_S1 + l - 1);
     if (l == 5) {
-      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S5), cx + 256);
+      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S5), cx + 256, db);
       lin_wgrad(c, dA, 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
       lin_dgrad(c, dA, 256, Wt(P_S5), cx + 256, P, 256, cx, d_emb_xyz, cx, 0);
       emb_written = true;
-      lin_dgrad(c, dA, 256, Wt(P_S5) + cx, cx + 256, P, 256, 256, dN, 256, 0);
+      lin_dgrad(c, dA, 256, Wt(P_S5) + cx, cx + 256, P, 256, 256, dN, 256, 0, w.A(4));
     } else if (l == 1) {
-      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S1), cx);
+      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S1), cx, db);
       lin_dgrad(c, dA, 256, Wt(P_S1), cx, P, 256, cx, d_emb_xyz, cx, emb_written ? 1 : 0);
     } else {
-      lin_wgrad(c, dA, 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256);
-      lin_dgrad(c, dA, 256, Wt(P_S1 + l - 1), 256, P, 256, 256, dN, 256, 0);
+      lin_wgrad(c, dA, 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256, db);
+      lin_dgrad(c, dA, 256, Wt(P_S1 + l - 1), 256, P, 256, 256, dN, 256, 0, w.A(l - 1));
     }
     float* tmp = dA; dA = dN; dN = tmp;
   }
@@ -252,25 +214,20 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   if (a->do_object) {
     const int ov = vox ? kObjVoxPE : 0;
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_inst_rgb, a->inst_rgb, 3 * P);
-    lin_wgrad(c, t2, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64);
-    bias_grad(c, t2, 3, P, 3, gB(P_ORGB));
-    lin_dgrad(c, t2, 3, Wt(P_ORGB), 64, P, 3, 64, t0, 64, 0);
-    leaky_bwd(c, t0, w.odirh(), 64 * P);
-    lin_wgrad(c, t0, 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC);
+    lin_wgrad(c, t2, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64, gB(P_ORGB));
+    lin_dgrad(c, t2, 3, Wt(P_ORGB), 64, P, 3, 64, t0, 64, 0, w.odirh());
+    lin_wgrad(c, t0, 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC, gB(P_OD));
     lin_wgrad(c, t0, 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
-    bias_grad(c, t0, 64, P, 64, gB(P_OD));
     lin_dgrad(c, t0, 64, Wt(P_OD), 128 + kDirC, P, 64, 128, t1, 128, 0);      // d ofinal
-    lin_wgrad(c, t1, 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128);
-    bias_grad(c, t1, 128, P, 128, gB(P_OF));
+    lin_wgrad(c, t1, 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128, gB(P_OF));
     lin_dgrad(c, t1, 128, Wt(P_OF), 128, P, 128, 128, t0, 128, 0);            // dB4
-    lin_dgrad(c, d_inst_sigma, 1, Wt(P_OSIG), 128, P, 1, 128, t0, 128, 1);
-    lin_wgrad(c, d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128);
-    bias_grad(c, d_inst_sigma, 1, P, 1, gB(P_OSIG));
+    lin_dgrad(c, d_inst_sigma, 1, Wt(P_OSIG), 128, P, 1, 128, t0, 128, 1, w.B(4));
+    lin_wgrad(c, d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128, gB(P_OSIG));
     dA = t0; dN = t1;
     bool ov_written = false;
     // gradient of one layer fed by cat([emb_xyz, obj_voxel, obj_code]) (+ optional hidden block at column co)
-    auto obj_in_bwd = [&](int wid, int ldw) {
-      lin_wgrad(c, dA, 128, X, cx, P, 128, cx, gW(wid), ldw);
+    auto obj_in_bwd = [&](int wid, int ldw, float* db) {
+      lin_wgrad(c, dA, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
       if (vox) lin_wgrad(c, dA, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
       lin_wgrad(c, dA, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
       lin_dgrad(c, dA, 128, Wt(wid), ldw, P, 128, cx, d_emb_xyz, cx, 1);       // scene branch wrote it first
@@ -279,17 +236,16 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
       ov_written = true;
     };
     for (int l = 4; l >= 1; --l) {
-      leaky_bwd(c, dA, w.B(l), 128 * P);
-      bias_grad(c, dA, 128, P, 128, gB(P_O1 + l - 1));
+      float* db = gB(P_O1 + l - 1);
       if (l == 3) {
         lin_wgrad(c, dA, 128, w.B(2), 128, P, 128, 128, gW(P_O3) + co, co + 128);
-        obj_in_bwd(P_O3, co + 128);
-        lin_dgrad(c, dA, 128, Wt(P_O3) + co, co + 128, P, 128, 128, dN, 128, 0);
+        obj_in_bwd(P_O3, co + 128, db);
+        lin_dgrad(c, dA, 128, Wt(P_O3) + co, co + 128, P, 128, 128, dN, 128, 0, w.B(2));
       } else if (l == 1) {
-        obj_in_bwd(P_O1, co);
+        obj_in_bwd(P_O1, co, db);
       } else {
-        lin_wgrad(c, dA, 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128);
-        lin_dgrad(c, dA, 128, Wt(P_O1 + l - 1), 128, P, 128, 128, dN, 128, 0);
+        lin_wgrad(c, dA, 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128, db);
+        lin_dgrad(c, dA, 128, Wt(P_O1 + l - 1), 128, P, 128, 128, dN, 128, 0, w.B(l - 1));
       }
       float* tmp = dA; dA = dN; dN = tmp;
     }

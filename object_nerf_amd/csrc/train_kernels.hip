@@ -150,11 +150,24 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
 }
 
 // ---- voxel embedding backward ---------------------------------------------------------------------
-__global__ void voxel_embed_bwd_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz, long n,
-                                       const float* __restrict__ d_scene, const float* __restrict__ d_obj,
-                                       float* __restrict__ table_grad) {
+// A workgroup holds 128 consecutive sample points = consecutive depths of one or two rays, and neighbouring depths
+// fall into the same voxel cell: sent straight to memory, their 8 x 24 atomics per point pile up on a few table rows
+// (the fine pass, whose samples cluster at surfaces, ran 8x slower per point than the coarse pass).  The workgroup
+// therefore first sums its contributions per table row in an LDS hash (row id -> 24 floats, ds_add_f32), then sends
+// each row it touched to memory once; contributions that find no slot within 8 probes go to memory directly.
+constexpr int kVbSlots = 512;               // power of two
+constexpr int kVbStride = kVoxC + 1;        // odd stride: spreads the rows over the LDS banks
+__global__ void __launch_bounds__(128) voxel_embed_bwd_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz,
+                                                               long n, const float* __restrict__ d_scene,
+                                                               const float* __restrict__ d_obj,
+                                                               float* __restrict__ table_grad) {
+  __shared__ int keys[kVbSlots];
+  __shared__ float vals[kVbSlots * kVbStride];
+  for (int i = threadIdx.x; i < kVbSlots; i += 128) keys[i] = -1;
+  for (int i = threadIdx.x; i < kVbSlots * kVbStride; i += 128) vals[i] = 0.f;
+  __syncthreads();
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
+  if (p < n) {
   const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
   const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
   const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
@@ -209,9 +222,31 @@ __global__ void voxel_embed_bwd_kernel(const objnerf_voxel_grid g, const float* 
   }
   for (int k = 0; k < 8; ++k) {
     if (row[k] < 0) continue;                       // invalid corners were zeroed in the forward pass
-    float* t = table_grad + (size_t)row[k] * kVoxC;
+    unsigned h = ((unsigned)row[k] * 2654435761u) >> 23;       // 9 bits
+    int slot = -1;
+    for (int probe = 0; probe < 8; ++probe) {
+      const int prev = atomicCAS(&keys[h], -1, row[k]);
+      if (prev == -1 || prev == row[k]) { slot = (int)h; break; }
+      h = (h + 1) & (kVbSlots - 1);
+    }
+    if (slot >= 0) {
+      float* t = vals + slot * kVbStride;
 #pragma unroll
-    for (int c = 0; c < kVoxC; ++c) atomicAdd(t + c, dF[c] * wt[k]);
+      for (int c = 0; c < kVoxC; ++c) atomicAdd(t + c, dF[c] * wt[k]);
+    } else {
+      float* t = table_grad + (size_t)row[k] * kVoxC;
+#pragma unroll
+      for (int c = 0; c < kVoxC; ++c) atomicAdd(t + c, dF[c] * wt[k]);
+    }
+  }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kVbSlots * kVoxC; i += 128) {
+    const int slot = i / kVoxC, c = i - slot * kVoxC;
+    const int r = keys[slot];
+    if (r < 0) continue;
+    const float v = vals[slot * kVbStride + c];
+    if (v != 0.f) atomicAdd(table_grad + (size_t)r * kVoxC + c, v);
   }
 }
 
