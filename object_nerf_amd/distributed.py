@@ -7,10 +7,14 @@ with NO collective inside the renderer; the single exchange step is one
 over xGMI that is <0.5 MB per rank, latency-bound, so it is issued once per frame, never per
 chunk, and only for pixels (never the 1 KB/ray weights_/z_vals_ rows).
 
+Training (SURVEY.md §8 row f1 on N GPUs) is plain data parallelism like the reference's Lightning DDP
+(train.py:261-262): every rank draws its own ray batch, runs the differentiable `render_rays`, and
+`GradientSync` averages the gradients with a few large flat all-reduces.
+
 Backend: torch.distributed "nccl" (= RCCL on ROCm) for GPU tensors; the same functions work on
-"gloo" with CPU tensors, which is how tests/test_distributed.py covers world_size 2.
+"gloo" with CPU tensors, which is how tests/test_distributed_gloo.py covers world_size 2.
 """
-from typing import Dict, Iterable, Tuple
+from typing import Dict, Iterable, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -64,3 +68,76 @@ def render_rays_sharded(render_fn, rays: torch.Tensor, per_ray: Dict[str, torch.
     r_local, ex = shard_rays(rays, per_ray)
     res = render_fn(rays=r_local, **ex, **kwargs)
     return {k: gather_pixels(res[k], n) for k in gather_keys if k in res}
+
+
+class GradientSync:
+    """Averages `.grad` of a fixed parameter list over the process group: the collective behind data-parallel
+    training (what Lightning's DDP does for the reference, train.py:261-262).
+
+    The differentiable `render_rays` is ONE autograd node, so all gradients of a step appear together at the end of
+    its backward: there is nothing to overlap bucket by bucket, and the right shape for xGMI (point-to-point links,
+    ring all-reduce bound by the per-link rate, ~10 us of latency per launch) is few, large messages.  Parameters are
+    therefore packed, in order, into flat fp32 buckets of up to `bucket_bytes` (default 64 MiB: both MLPs and the
+    codes share one bucket, the 77 MB voxel table gets its own), each reduced by one asynchronous all-reduce; the
+    reduces are all in flight before the first is waited for.  Parameters whose gradient is None on this rank
+    (e.g. an object code no local ray used) contribute zeros, so ranks never disagree on the message layout.
+    """
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = group
+        self.buckets: List[List[int]] = []          # indices into self.params
+        cur, cur_bytes = [], 0
+        for i, p in enumerate(self.params):
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(i)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._flat: List[torch.Tensor] = [None] * len(self.buckets)
+
+    def _buffer(self, b: int) -> torch.Tensor:
+        idx = self.buckets[b]
+        n = sum(self.params[i].numel() for i in idx)
+        dev = self.params[idx[0]].device
+        if self._flat[b] is None or self._flat[b].device != dev:
+            self._flat[b] = torch.empty(n, dtype=torch.float32, device=dev)
+        return self._flat[b]
+
+    @torch.no_grad()
+    def sync(self) -> None:
+        """In place: every rank's `.grad` becomes the mean over ranks.  No-op without a process group."""
+        if not dist.is_initialized():
+            return
+        world = dist.get_world_size(self.group)
+        if world == 1:
+            return
+        works = []
+        for b, idx in enumerate(self.buckets):
+            flat = self._buffer(b)
+            off = 0
+            for i in idx:
+                p = self.params[i]
+                view = flat[off:off + p.numel()]
+                if p.grad is None:
+                    view.zero_()
+                else:
+                    view.copy_(p.grad.reshape(-1))
+                off += p.numel()
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        inv = 1.0 / world
+        for b, idx in enumerate(self.buckets):
+            works[b].wait()
+            flat = self._flat[b]
+            off = 0
+            for i in idx:
+                p = self.params[i]
+                g = flat[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.mul(inv)
+                else:
+                    torch.mul(g, inv, out=p.grad)
+                off += p.numel()

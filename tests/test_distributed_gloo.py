@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from object_nerf_amd.distributed import gather_pixels, render_rays_sharded, shard_rays
+from object_nerf_amd.distributed import GradientSync, gather_pixels, render_rays_sharded, shard_rays
 
 
 def _free_port():
@@ -60,3 +60,52 @@ def test_sharded_render_world2(n):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        shapes = [(256, 271), (256,), (64, 64), (1000, 24), (3, 128), (1,)]
+        params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+        frozen = torch.nn.Parameter(torch.randn(4), requires_grad=False)
+        grads = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(world)]     # same on every rank
+        for i, p in enumerate(params):
+            p.grad = grads[rank][i].clone()
+        params[2].grad = None if rank == 1 else params[2].grad        # e.g. codes no local ray used
+        # 64 KiB buckets: forces several buckets, one parameter larger than a bucket
+        sync = GradientSync(params + [frozen], bucket_bytes=64 << 10)
+        sync.sync()
+        ok = len(sync.buckets) >= 3 and frozen.grad is None
+        for i, p in enumerate(params):
+            want = sum(grads[r][i] for r in range(world)) / world
+            if i == 2:
+                want = grads[0][i] / world
+            ok = ok and torch.allclose(p.grad, want, atol=1e-6) and p.grad.shape == p.shape
+        sync.sync()                                                     # second step reuses the flat buffers
+        ok = ok and torch.allclose(params[0].grad, sum(grads[r][0] for r in range(world)) / world, atol=1e-6)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_sync_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_gradient_sync_without_process_group_is_a_noop():
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    GradientSync([p]).sync()
+    assert torch.equal(p.grad, torch.full((3,), 2.0))

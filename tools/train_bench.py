@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Times one training step of the reference's batch shape (train.py:147-180: 2048 rays, 64 coarse + 64 fine,
 perturb = 1, noise_std = 1, scene + object branches, voxel embedding) on the HIP training path:
-render_rays forward + backward (+ Adam step).  Not the headline metric; recorded in DESIGN.md."""
+render_rays forward + backward (+ Adam step).  Not the headline metric; recorded in DESIGN.md.
+Under torch.distributed.run (one rank per GPU, RCCL) every rank trains on its own ray batch and GradientSync averages
+the gradients before the optimizer step (data parallel, as the reference's Lightning DDP)."""
 import os
 import sys
 import time
@@ -15,12 +17,19 @@ from object_nerf_amd import synth  # noqa: E402
 
 
 def main(n_rays=2048, steps=5):
+    import torch.distributed as dist
+    from object_nerf_amd.distributed import GradientSync
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if "RANK" in os.environ:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = "cuda"
     sc = synth.build_scene(A, True, preset=synth.SCANNET_LIKE, max_voxels=800_000, device=dev)
     rays_all = synth.camera_rays(640, 480).to(dev)
     params = [p for m in (sc.models["coarse"], sc.models["fine"], sc.code_library, sc.embeddings["xyz"]) for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=1e-3)
-    g = torch.Generator(device=dev).manual_seed(0)
+    sync = GradientSync(params)
+    g = torch.Generator(device=dev).manual_seed(rank)
     target = torch.rand(n_rays, 3, device=dev, generator=g)
 
     def step():
@@ -35,6 +44,7 @@ def main(n_rays=2048, steps=5):
                    + 0.1 * (r["depth_%s" % t] ** 2).mean() + (r["opacity_instance_%s" % t] ** 2).mean() for t in ("coarse", "fine"))
         torch.cuda.synchronize(); t1 = time.perf_counter()
         loss.backward()
+        sync.sync()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         opt.step()
         torch.cuda.synchronize(); t3 = time.perf_counter()
@@ -47,11 +57,15 @@ def main(n_rays=2048, steps=5):
         loss, t1, t2, t3 = step()
         rows.append((t1 - t0, t2 - t1, t3 - t2, loss))
     fw, bw, op = (sorted(r[i] for r in rows)[len(rows) // 2] for i in range(3))
-    evals = n_rays * 192
+    evals = n_rays * 192 * world
     flop = evals * 1776128 * 3.0          # forward + dgrad + wgrad
-    print("train step %d rays: forward %.1f ms, backward %.1f ms, Adam %.1f ms -> %.2f M ray-samples/s, "
-          "%.1f TFLOP/s (3x forward FLOP), loss %.4f -> %.4f"
-          % (n_rays, fw * 1e3, bw * 1e3, op * 1e3, evals / (fw + bw + op) / 1e6, flop / (fw + bw) / 1e12, rows[0][3], rows[-1][3]))
+    if rank == 0:
+        print("train step %d rays/rank x %d ranks: forward %.1f ms, backward %.1f ms, Adam %.1f ms -> %.2f M ray-samples/s, "
+              "%.1f TFLOP/s (3x forward FLOP), loss %.4f -> %.4f"
+              % (n_rays, world, fw * 1e3, bw * 1e3, op * 1e3, evals / (fw + bw + op) / 1e6, flop / (fw + bw) / 1e12,
+                 rows[0][3], rows[-1][3]))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
