@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 1
+#define OBJNERF_ABI_VERSION 2
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -56,6 +56,13 @@ int objnerf_pack_index(int use_voxel, uint32_t* h_blob_idx, uint32_t* h_aux_idx)
  * h_param_ptrs: HOST array of objnerf_num_param_ptrs() DEVICE pointers. */
 int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx,
                          const float* const* h_param_ptrs, float* blob, float* aux, void* stream);
+
+/* Training only: the transposed weight stream of the hidden-to-hidden blocks, consumed by the fused backward of the
+ * hidden chain (objnerf_train_args.blob_bwd).  Same tile/chunk format as the forward stream with rows = input
+ * features and k = output features; the gradients w.r.t. the embeddings are not part of it. */
+int64_t objnerf_bwd_blob_floats(void);
+int objnerf_pack_index_bwd(int use_voxel, uint32_t* h_blob_idx);
+int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream);
 
 /* ---- stage entry points ---- */
 
@@ -283,6 +290,15 @@ typedef struct {
   float* inst_sigma;        /* (P) */
   float* inst_rgb;          /* (P,3) */
   float* workspace;         /* objnerf_train_workspace_floats(): saved activations, input of the backward */
+  /* optional (both or neither): the packed weight stream of the SAME parameter values (objnerf_pack_weights).  When
+   * given, the forward runs on the persistent MFMA kernel of objnerf_mlp_eval (memory form), which additionally
+   * writes every layer's activations -- one launch per branch instead of one GEMM per layer.  The backward is
+   * the same either way. */
+  const float* blob; const float* aux;
+  /* optional, read by objnerf_mlp_train_backward only (needs aux too): objnerf_pack_weights_bwd() of the same
+   * parameter values.  When given, the dgrad chain through the hidden layers runs in one persistent MFMA kernel
+   * (gradient tiles stay in registers from layer to layer) instead of one GEMM + activation-backward per layer. */
+  const float* blob_bwd;
 } objnerf_train_args;
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points);
 int64_t objnerf_train_scratch_floats(int64_t n_points);
@@ -290,7 +306,8 @@ int objnerf_mlp_train_forward(const objnerf_train_args* args, void* stream);
 /* Backward of the call above (same args, outputs and workspace untouched in between).
  * d_*: gradients w.r.t. sigma (P), rgb (P,3), inst_sigma, inst_rgb.  h_param_grads: HOST array of DEVICE
  * pointers, one per parameter tensor, ACCUMULATED into (+=).  d_emb_xyz (P,in_xyz), d_obj_voxel (P,104),
- * d_obj_code (P,64) are overwritten.  scratch: objnerf_train_scratch_floats() floats. */
+ * d_obj_code (P,64) are overwritten.  scratch: objnerf_train_scratch_floats() floats (holds the gradient w.r.t. every
+ * layer's pre-activation output, in the layout of the activation workspace). */
 int objnerf_mlp_train_backward(const objnerf_train_args* args, const float* d_sigma, const float* d_rgb,
                                const float* d_inst_sigma, const float* d_inst_rgb, float* const* h_param_grads,
                                float* d_emb_xyz, float* d_obj_voxel, float* d_obj_code, float* scratch,

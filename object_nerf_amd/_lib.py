@@ -10,6 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libobjnerf_hip.so")
+ABI_VERSION = 2     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -65,6 +66,7 @@ class TrainArgs(C.Structure):
         ("emb_xyz", C.c_void_p), ("emb_dir", C.c_void_p), ("obj_voxel", C.c_void_p), ("obj_code", C.c_void_p),
         ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
         ("workspace", C.c_void_p),
+        ("blob", C.c_void_p), ("aux", C.c_void_p), ("blob_bwd", C.c_void_p),
     ]
 
 
@@ -119,6 +121,9 @@ SIGNATURES = {
     "objnerf_param_numel": (C.c_int64, [C.c_int, C.c_int]),
     "objnerf_pack_index": (C.c_int, [C.c_int, _VP, _VP]),
     "objnerf_pack_weights": (C.c_int, [C.c_int, _VP, _VP, C.POINTER(_VP), _VP, _VP, _VP]),
+    "objnerf_bwd_blob_floats": (C.c_int64, []),
+    "objnerf_pack_index_bwd": (C.c_int, [C.c_int, _VP]),
+    "objnerf_pack_weights_bwd": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),
     "objnerf_sample_coarse": (C.c_int, [_VP, _VP, _VP, C.c_float, C.c_int, C.c_int64, C.c_int, _VP, _VP]),
     "objnerf_pos_encode": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
     "objnerf_voxel_embed": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP]),
@@ -162,8 +167,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the ABI header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if l.objnerf_abi_version() != 1:
-            raise RuntimeError("object_nerf_amd: ABI version mismatch")
+        if l.objnerf_abi_version() != ABI_VERSION:
+            raise RuntimeError("object_nerf_amd: ABI version mismatch (library %d, Python mirror %d): rebuild with "
+                               "`make -C object_nerf_amd/csrc`" % (l.objnerf_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

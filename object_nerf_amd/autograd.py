@@ -64,8 +64,10 @@ def _composite_args(meta, ps, outs=None):
     return a
 
 
-def _train_args(meta, ps, params):
+def _train_args(meta, ps, params, packed=None):
     a = _lib.TrainArgs()
+    if packed is not None:
+        a.blob, a.aux, a.blob_bwd = packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()
     a.use_voxel, a.do_object = int(meta["use_voxel"]), int(meta["forward_instance"])
     a.n_points = ps.emb_xyz.shape[0]
     table = _ptr_table(params)
@@ -95,13 +97,14 @@ class RenderRaysFn(torch.autograd.Function):
         rays_c = _lib.as_f32(rays.detach())
         codes_c = _lib.as_f32(codes.detach())
         rnd = meta["randoms"]
+        pk = meta.get("packed") or (None, None)
 
         # per-ray rows repeated per sample are copies, not arithmetic
         dirs = rays_c[:, 3:6].contiguous()
         emb_dir_ray = _empty(n, 27, dev=dev)
         _lib.check(l.objnerf_pos_encode(_lib.ptr(dirs), n, 3, 4, _lib.ptr(emb_dir_ray), st), "pos_encode")
 
-        def run_pass(z, pp, noise, noise_i):
+        def run_pass(z, pp, noise, noise_i, packed):
             ps = _Pass()
             Sx = z.shape[1]
             P = n * Sx
@@ -121,7 +124,7 @@ class RenderRaysFn(torch.autograd.Function):
             ps.isig, ps.irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
             ps.ws = _empty(l.objnerf_train_workspace_floats(int(fi), P), dev=dev)
             ps.noise, ps.noise_i = noise, noise_i
-            a, keep = _train_args(meta, ps, pp)
+            a, keep = _train_args(meta, ps, pp, packed)
             _lib.check(l.objnerf_mlp_train_forward(C.byref(a), st), "mlp_train_forward")
             outs = {"weights": _empty(n, Sx, dev=dev), "opacity": _empty(n, dev=dev), "rgb": _empty(n, 3, dev=dev),
                     "depth": _empty(n, dev=dev)}
@@ -138,7 +141,7 @@ class RenderRaysFn(torch.autograd.Function):
                                            float(meta["perturb"]), int(meta["use_disp"]), n, S, _lib.ptr(z_c), st), "sample_coarse")
         nz = rnd.get("noise", [None] * 4)
         passes, results = [], {}
-        ps, outs = run_pass(z_c, p_coarse, nz[0], nz[1])
+        ps, outs = run_pass(z_c, p_coarse, nz[0], nz[1], pk[0])
         passes.append(ps)
         for k, v in outs.items():
             results["%s_coarse" % k] = v
@@ -149,7 +152,7 @@ class RenderRaysFn(torch.autograd.Function):
             u = meta["u_det"] if det else rnd["u_rand"]
             _lib.check(l.objnerf_sample_pdf_merge(_lib.ptr(z_c), _lib.ptr(outs["weights"]), _lib.ptr(u), 0 if det else I, n, S, I,
                                                   1e-5, None, _lib.ptr(z_f), st), "sample_pdf_merge")
-            ps, outs = run_pass(z_f, p_fine, nz[2], nz[3])
+            ps, outs = run_pass(z_f, p_fine, nz[2], nz[3], pk[1])
             passes.append(ps)
             for k, v in outs.items():
                 results["%s_fine" % k] = v
@@ -179,7 +182,8 @@ class RenderRaysFn(torch.autograd.Function):
         d_table = torch.zeros(ctx.table_shape, dtype=torch.float32, device=dev) if vox else None
         d_codes = torch.zeros(n, 64, dtype=torch.float32, device=dev) if fi else None
         param_grads = []
-        for typ, ps, pp in zip(("coarse", "fine"), ctx.passes, (ctx.p_coarse, ctx.p_fine)):
+        pk = meta.get("packed") or (None, None)
+        for typ, ps, pp, packed in zip(("coarse", "fine"), ctx.passes, (ctx.p_coarse, ctx.p_fine), pk):
             gp = [torch.zeros_like(p) for p in pp]
             param_grads.append(gp)
             P, Sx = ps.emb_xyz.shape[0], ps.S
@@ -197,7 +201,7 @@ class RenderRaysFn(torch.autograd.Function):
                 C.byref(ca), _lib.ptr(gm_t["rgb"]), _lib.ptr(gm_t["depth"]), _lib.ptr(gm_t["opacity"]),
                 _lib.ptr(gm_t["rgb_instance"]), _lib.ptr(gm_t["depth_instance"]), _lib.ptr(gm_t["opacity_instance"]),
                 _lib.ptr(d_sigma), _lib.ptr(d_rgb), _lib.ptr(d_isig), _lib.ptr(d_irgb), st), "composite_backward")
-            a, keep = _train_args(meta, ps, pp)
+            a, keep = _train_args(meta, ps, pp, packed)
             gtable = _ptr_table(gp)
             d_emb = _empty(P, ps.emb_xyz.shape[1], dev=dev)
             d_ov = _empty(P, 104, dev=dev) if (fi and vox) else None

@@ -58,6 +58,15 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
 
 using namespace objnerf;
 
+namespace objnerf {
+unsigned mlp_grid(long ntiles) {
+  int dev = 0, cus = 256;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return (unsigned)(ntiles < cus ? ntiles : cus);   // persistent: 1 workgroup per CU
+}
+}  // namespace objnerf
+
 extern "C" {
 
 int objnerf_abi_version(void) { return OBJNERF_ABI_VERSION; }
@@ -120,6 +129,34 @@ int objnerf_pack_index(int use_voxel, uint32_t* blob_idx, uint32_t* aux_idx) {
   return 0;
 }
 
+int64_t objnerf_bwd_blob_floats(void) { return (int64_t)bwd_total_chunks() * kChunkFloats; }
+
+int objnerf_pack_index_bwd(int use_voxel, uint32_t* blob_idx) {
+  if (!blob_idx) return set_error(-1, "pack_index_bwd: null output");
+  const bool vox = use_voxel != 0;
+  const long nblob = objnerf_bwd_blob_floats();
+  for (long i = 0; i < nblob; ++i) blob_idx[i] = kPackZero;
+  for (int l = 0; l < BL_COUNT; ++l) {
+    const int nt = bwd_nt(l), kg = kChunkTiles / nt, ks_n = bwd_ks(l);
+    const int p = bwd_param(l);
+    const ParamShape sh = param_shape(vox, p);
+    const int col0 = bwd_col0(vox, l);
+    if (2 * ks_n != sh.out || col0 + 32 * nt > sh.in) return set_error(-3, "pack_index_bwd: layout self-check failed");
+    const long base = (long)bwd_chunk_start(l) * kChunkFloats;
+    for (int ks = 0; ks < ks_n; ++ks) {
+      const int chunk = ks / kg, kl = ks % kg, g4 = kl / 4, j = kl % 4;
+      for (int m = 0; m < nt; ++m)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int in_feat = col0 + 32 * m + (lane & 31);       // tile row: a feature of the layer's input block
+          const int out_feat = hid_feat(ks, lane >> 5);          // k: the feature whose gradient the lane half holds
+          const long o = base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j;
+          blob_idx[o] = enc(2 * p, (long)out_feat * sh.in + in_feat);
+        }
+    }
+  }
+  return 0;
+}
+
 int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (!a || !a->blob || !a->aux) return set_error(-1, "mlp_eval: null weights");
   if ((a->emb_xyz == nullptr ? a->n_rays * (int64_t)a->S : a->n_points) == 0) return 0;   // nothing to do
@@ -142,10 +179,7 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   }
   if (P == 0) return 0;
   const long ntiles = (P + 127) / 128;
-  int dev = 0, cus = 256;
-  hipGetDevice(&dev);
-  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);   // persistent: 1 workgroup per CU
+  const unsigned grid = mlp_grid(ntiles);
   hipStream_t s = (hipStream_t)stream;
 
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -215,4 +215,39 @@ static_assert(aux_bias_off(L_COUNT) == kAuxSSig, "aux layout");
 
 constexpr uint32_t kPackZero = 0xFFFFFFFFu;   // index-map entry meaning "0.0f"
 
+// ---- backward weight stream (training: dgrad of the hidden chain, mlp_bwd_kernel.h) ------------------
+// d(input of layer) = W^T * d(pre-activation output): the same A-tile/chunk format with the roles swapped --
+// tile row = INPUT feature 32 m + (lane & 31) of the streamed column block, k-step (ks, half) = OUTPUT feature
+// hid_feat(ks, half), i.e. the order in which a wave holds the incoming gradient in its D-layout registers.
+// Only hidden-to-hidden blocks are streamed (the gradients w.r.t. the embeddings are GEMMs, train.hip); in
+// execution order:
+enum BwdLayerId {
+  BL_SD = 0, BL_SF, BL_S8, BL_S7, BL_S6, BL_S5, BL_S4, BL_S3, BL_S2,     // scene: dir hidden -> ... -> layer 1 output
+  BL_OD, BL_OF, BL_O4, BL_O3, BL_O2, BL_COUNT                           // object
+};
+OBJ_HD constexpr int bwd_nt(int l) { return l < BL_OD ? 8 : 4; }               // tiles of the produced gradient
+OBJ_HD constexpr int bwd_ks(int l) { return l == BL_SD ? kIW / 2 : (l < BL_OD ? kW / 2 : (l == BL_OD ? kIW / 4 : kIW / 2)); }
+OBJ_HD constexpr int bwd_chunks(int l) {
+  int kg = kChunkTiles / bwd_nt(l);
+  return (bwd_ks(l) + kg - 1) / kg;
+}
+OBJ_HD constexpr int bwd_chunk_start(int l) {
+  int s = 0;
+  for (int i = 0; i < l; ++i) s += bwd_chunks(i);
+  return s;
+}
+OBJ_HD constexpr int bwd_scene_chunks() { return bwd_chunk_start(BL_OD); }
+OBJ_HD constexpr int bwd_total_chunks() { return bwd_chunk_start(BL_COUNT); }
+OBJ_HD constexpr int bwd_param(int l) {
+  switch (l) {
+    case BL_SD: return P_SD; case BL_SF: return P_SF;
+    case BL_S8: return P_S8; case BL_S7: return P_S7; case BL_S6: return P_S6; case BL_S5: return P_S5;
+    case BL_S4: return P_S4; case BL_S3: return P_S3; case BL_S2: return P_S2;
+    case BL_OD: return P_OD; case BL_OF: return P_OF; case BL_O4: return P_O4; case BL_O3: return P_O3;
+    default: return P_O2;
+  }
+}
+// first column of the streamed block inside the reference weight matrix (the hidden block of a skip layer)
+OBJ_HD constexpr int bwd_col0(bool voxel, int l) { return l == BL_S5 ? in_xyz(voxel) : (l == BL_O3 ? in_obj(voxel) : 0); }
+
 }  // namespace objnerf

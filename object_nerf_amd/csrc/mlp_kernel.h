@@ -601,11 +601,42 @@ struct TilePrologue {
 };
 
 // ---------------------------------------------------------------------------------------------
+// training forward (SAVE): every layer's output also goes to the row-major (P x width) activation matrices the
+// layer-wise backward reads (train.hip, struct Ws).  h[t][4g..4g+3] of lane half hf are features
+// 32 t + 8 g + 4 hf .. + 3 of one point: one 16-byte store; the four g of a tile complete a 128-byte line.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, long ld, long p, int half, bool valid) {
+  if (!valid) return;
+  float* row = mat + p * ld + 4 * half;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {h[t][4 * g], h[t][4 * g + 1], h[t][4 * g + 2], h[t][4 * g + 3]};
+      *(f32x4*)(row + 32 * t + 8 * g) = v;
+    }
+}
+// saved-activation matrices, floats per point: scene 8 x 256 | final 256 | dir hidden 128 | (4 unused) |
+// object 4 x 128 | final 128 | dir hidden 64 | (4 unused)   -- same arithmetic as train.hip's Ws
+struct SaveWs {
+  float* base;
+  long P;
+  __device__ __forceinline__ float* A(int l) const { return base + (long)(l - 1) * 256 * P; }     // l = 1..8
+  __device__ __forceinline__ float* sfinal() const { return base + 8L * 256 * P; }
+  __device__ __forceinline__ float* sdirh() const { return sfinal() + 256L * P; }
+  __device__ __forceinline__ float* B(int l) const { return sdirh() + 128L * P + 4L * P + (long)(l - 1) * 128 * P; }   // l = 1..4
+  __device__ __forceinline__ float* ofinal() const { return B(5); }
+  __device__ __forceinline__ float* odirh() const { return ofinal() + 128L * P; }
+};
+
+// ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false>
-__global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles) {
+template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false>
+__global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles, float* const save_ws = nullptr) {
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
+  static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");
   // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read of a glds
   // pipeline, guide §5 "three .s-level traps"): [2-slot weight ring | aux block]
   __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)];
@@ -622,6 +653,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
           (lds_char*)ring_mem, tid);
 
   const long P = FUSED ? a.n_rays * (long)a.S : a.n_points;
+  const SaveWs ws{save_ws, P};
 #if OBJ_AUX_LDS
   // biases + head weights (16 KiB) are read by every wave every pass: stage them once in LDS
   float* aux_lds = (float*)(ring_mem + kRingSlots * kChunkBytes);
@@ -692,23 +724,27 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<8>(acc, aux, L_S1, half);
       { EmbOnly<Src> s{src}; layer_mac<8, NE>(acc, st, s); }
       finish<8, true>(acc, h);
+      if constexpr (SAVE) save_tiles<8>(h, ws.A(1), 256, p, half, valid);
       // xyz_encoding_2..4
 #pragma unroll 1
       for (int l = L_S2; l <= L_S4; ++l) {
         load_bias<8>(acc, aux, l, half);
         { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
         finish<8, true>(acc, h);
+        if constexpr (SAVE) save_tiles<8>(h, ws.A(l - L_S1 + 1), 256, p, half, valid);
       }
       // xyz_encoding_5 (skip: cat([emb, h]))
       src.launder();
       load_bias<8>(acc, aux, L_S5, half);
       { EmbThenHid<Src, NE, 8> s{src, h}; layer_mac<8, NE + 128>(acc, st, s); }
       finish<8, true>(acc, h);
+      if constexpr (SAVE) save_tiles<8>(h, ws.A(5), 256, p, half, valid);
 #pragma unroll 1
       for (int l = L_S6; l <= L_S8; ++l) {
         load_bias<8>(acc, aux, l, half);
         { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
         finish<8, true>(acc, h);
+        if constexpr (SAVE) save_tiles<8>(h, ws.A(l - L_S1 + 1), 256, p, half, valid);
       }
       // sigma head (no activation, nerf_model.py:108)
       const float sg = head_dot<8>(h, aux + kAuxSSig, half) + aux[kAuxSSig + 8 * 32];
@@ -719,12 +755,14 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<8>(acc, aux, L_SF, half);
       { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
       finish<8, false>(acc, h);
+      if constexpr (SAVE) save_tiles<8>(h, ws.sfinal(), 256, p, half, valid);
       // dir_encoding: cat([final, dir]) -> W/2, LeakyReLU
       f32x16 acc4[4], hd[4];
       src.launder();
       load_bias<4>(acc4, aux, L_SD, half);
       { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s); }
       finish<4, true>(acc4, hd);
+      if constexpr (SAVE) save_tiles<4>(hd, ws.sdirh(), 128, p, half, valid);
       float col[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -744,19 +782,23 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<4>(acc, aux, L_O1, half);
       { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
       finish<4, true>(acc, h);
+      if constexpr (SAVE) save_tiles<4>(h, ws.B(1), 128, p, half, valid);
       if constexpr (PREFETCH) pre.stage_b(a.grid);
       load_bias<4>(acc, aux, L_O2, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
       finish<4, true>(acc, h);
+      if constexpr (SAVE) save_tiles<4>(h, ws.B(2), 128, p, half, valid);
       if constexpr (PREFETCH) pre.template stage_rows<0>(a.grid, half);
       src.launder();
       load_bias<4>(acc, aux, L_O3, half);
       { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s); }
       finish<4, true>(acc, h);
+      if constexpr (SAVE) save_tiles<4>(h, ws.B(3), 128, p, half, valid);
       if constexpr (PREFETCH) { pre.template stage_acc<0>(); pre.template stage_rows<1>(a.grid, half); }
       load_bias<4>(acc, aux, L_O4, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
       finish<4, true>(acc, h);
+      if constexpr (SAVE) save_tiles<4>(h, ws.B(4), 128, p, half, valid);
       const float sg = head_dot<4>(h, aux + kAuxOSig, half) + aux[kAuxOSig + 4 * 32];
       if constexpr (PREFETCH) pre.template stage_acc<1>();
       if constexpr (SIGMA_ONLY) {
@@ -765,11 +807,13 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<4>(acc, aux, L_OF, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
       finish<4, false>(acc, h);
+      if constexpr (SAVE) save_tiles<4>(h, ws.ofinal(), 128, p, half, valid);
       f32x16 acc2[2], hd[2];
       src.launder();
       load_bias<2>(acc2, aux, L_OD, half);
       { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s); }
       finish<2, true>(acc2, hd);
+      if constexpr (SAVE) save_tiles<2>(hd, ws.odirh(), 64, p, half, valid);
       float col[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)

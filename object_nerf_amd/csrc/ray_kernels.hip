@@ -666,4 +666,16 @@ int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t
   return check_launch("pack_weights");
 }
 
+int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream) {
+  if (!blob_idx || !h_param_ptrs || !blob) return set_error(-1, "pack_weights_bwd: bad arguments");
+  ParamPtrs pp;
+  for (int i = 0; i < kNumParamPtrs; ++i) {
+    if (!h_param_ptrs[i]) return set_error(-1, "pack_weights_bwd: null parameter pointer");
+    pp.p[i] = h_param_ptrs[i];
+  }
+  const long nb = objnerf_bwd_blob_floats();
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, pp, blob);
+  return check_launch("pack_weights_bwd");
+}
+
 }  // extern "C"

@@ -102,7 +102,7 @@ int objnerf_gemm(const float* A, int64_t lda, int a_k_contig, const float* B, in
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points) {
   return (kWsScene + (do_object ? kWsObj : 0)) * n_points;
 }
-int64_t objnerf_train_scratch_floats(int64_t n_points) { return 3L * 256 * n_points; }
+int64_t objnerf_train_scratch_floats(int64_t n_points) { return (kWsScene + kWsObj) * n_points; }
 
 int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
   if (!a || !a->h_params || !a->emb_xyz || !a->emb_dir || !a->workspace || !a->sigma || !a->rgb)
@@ -116,6 +116,27 @@ int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
   const float* const* p = a->h_params;
   auto Wt = [&](int id) { return p[2 * id]; };
   auto Bi = [&](int id) { return p[2 * id + 1]; };
+  if ((a->blob != nullptr) != (a->aux != nullptr)) return set_error(-1, "mlp_train_forward: blob and aux go together");
+  if (a->blob) {
+    // persistent MFMA kernel (mlp_kernel.h, memory form) that also writes the activation matrices: one launch per
+    // branch; same workspace layout (struct Ws here = struct SaveWs there)
+    objnerf_mlp_args m;
+    memset(&m, 0, sizeof(m));
+    m.use_voxel = a->use_voxel;
+    m.blob = a->blob; m.aux = a->aux;
+    m.emb_xyz = a->emb_xyz; m.emb_dir = a->emb_dir; m.obj_voxel = a->obj_voxel; m.obj_code = a->obj_code;
+    m.n_points = P;
+    m.sigma = a->sigma; m.rgb = a->rgb; m.inst_sigma = a->inst_sigma; m.inst_rgb = a->inst_rgb;
+    const long ntiles = (P + 127) / 128;
+    const unsigned grid = mlp_grid(ntiles);
+    m.do_scene = 1; m.do_object = 0;
+    int rc = launch_mlp_memory(m, ntiles, grid, (hipStream_t)stream, a->workspace);
+    if (rc == 0 && a->do_object) {
+      m.do_scene = 0; m.do_object = 1;
+      rc = launch_mlp_memory(m, ntiles, grid, (hipStream_t)stream, a->workspace);
+    }
+    return rc;
+  }
   Ctx c{(hipStream_t)stream, 0};
   Ws w{P, a->workspace, a->do_object != 0};
   const float* X = a->emb_xyz;
@@ -162,92 +183,99 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     return set_error(-1, "mlp_train_backward: bad arguments");
   if (a->do_object && (!d_inst_sigma || !d_inst_rgb || !d_obj_code || (a->use_voxel && !d_obj_voxel)))
     return set_error(-1, "mlp_train_backward: object branch gradients missing");
+  if (a->blob_bwd && !a->aux) return set_error(-1, "mlp_train_backward: blob_bwd needs aux");
   const long P = a->n_points;
   if (P == 0) return 0;
-  const bool vox = a->use_voxel != 0;
+  const bool vox = a->use_voxel != 0, obj = a->do_object != 0;
   const int cx = in_xyz(vox), co = in_obj(vox);
   const float* const* p = a->h_params;
   auto Wt = [&](int id) { return p[2 * id]; };
   auto gW = [&](int id) { return h_param_grads[2 * id]; };
   auto gB = [&](int id) { return h_param_grads[2 * id + 1]; };
   Ctx c{(hipStream_t)stream, 0};
-  Ws w{P, a->workspace, a->do_object != 0};
-  float* t0 = scratch;                 // P x 256
-  float* t1 = scratch + 256L * P;      // P x 256
-  float* t2 = scratch + 512L * P;      // P x 256 (small temporaries)
+  const Ws w{P, a->workspace, obj};       // saved activations
+  const Ws d{P, scratch, obj};            // gradients w.r.t. the pre-activation outputs, same layout
   const float* X = a->emb_xyz;
+  float* t2 = d.rgb();                    // (P,3) gradient w.r.t. the rgb heads' pre-sigmoid outputs
+  float* t2i = d.irgb();
 
-  // ---- scene branch ----
-  // rgb = sigmoid(dirh Wr^T + br)
+  // ---- phase A: the dgrad chain through the hidden layers -> d.* ----
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_rgb, a->rgb, 3 * P);
-  lin_wgrad(c, t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128, gB(P_SRGB));
-  lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, t0, 128, 0, w.dirh());    // d dirh (pre-activation)
-  lin_wgrad(c, t0, 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC, gB(P_SD));
-  lin_wgrad(c, t0, 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
-  lin_dgrad(c, t0, 128, Wt(P_SD), 256 + kDirC, P, 128, 256, t1, 256, 0);     // d final
-  lin_wgrad(c, t1, 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256, gB(P_SF));
-  lin_dgrad(c, t1, 256, Wt(P_SF), 256, P, 256, 256, t0, 256, 0);             // dA8 (from final)
-  lin_dgrad(c, d_sigma, 1, Wt(P_SSIG), 256, P, 1, 256, t0, 256, 1, w.A(8));  // + d sigma * w_sigma, then leaky
-  lin_wgrad(c, d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256, gB(P_SSIG));
-  float* dA = t0;
-  float* dN = t1;
-  bool emb_written = false;
-  for (int l = 8; l >= 1; --l) {      // dA = gradient w.r.t. layer l's pre-activation
-    float* db = gB(P_S1 + l - 1);
-    if (l == 5) {
-      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S5), cx + 256, db);
-      lin_wgrad(c, dA, 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
-      lin_dgrad(c, dA, 256, Wt(P_S5), cx + 256, P, 256, cx, d_emb_xyz, cx, 0);
-      emb_written = true;
-      lin_dgrad(c, dA, 256, Wt(P_S5) + cx, cx + 256, P, 256, 256, dN, 256, 0, w.A(4));
-    } else if (l == 1) {
-      lin_wgrad(c, dA, 256, X, cx, P, 256, cx, gW(P_S1), cx, db);
-      lin_dgrad(c, dA, 256, Wt(P_S1), cx, P, 256, cx, d_emb_xyz, cx, emb_written ? 1 : 0);
-    } else {
-      lin_wgrad(c, dA, 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256, db);
-      lin_dgrad(c, dA, 256, Wt(P_S1 + l - 1), 256, P, 256, 256, dN, 256, 0, w.A(l - 1));
+  if (obj) hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2i, d_inst_rgb, a->inst_rgb, 3 * P);
+  c.rc = check_launch("sigmoid_bwd");
+  if (a->blob_bwd) {
+    // one persistent MFMA kernel, gradient tiles stay in registers from layer to layer (mlp_bwd.hip)
+    if (!c.rc) c.rc = launch_mlp_bwd(a->blob_bwd, a->aux, P, a->workspace, scratch, d_sigma, t2, d_inst_sigma, t2i, obj, c.s);
+  } else {
+    // layer by layer: dX = dY W as a GEMM with the LeakyReLU backward in its epilogue
+    lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, d.dirh(), 128, 0, w.dirh());
+    lin_dgrad(c, d.dirh(), 128, Wt(P_SD), 256 + kDirC, P, 128, 256, d.final_(), 256, 0);
+    lin_dgrad(c, d.final_(), 256, Wt(P_SF), 256, P, 256, 256, d.A(8), 256, 0);
+    lin_dgrad(c, d_sigma, 1, Wt(P_SSIG), 256, P, 1, 256, d.A(8), 256, 1, w.A(8));      // + d sigma * w_sigma, then leaky
+    for (int l = 8; l >= 2; --l) {
+      const float* Wl = l == 5 ? Wt(P_S5) + cx : Wt(P_S1 + l - 1);                      // hidden block of the skip layer
+      lin_dgrad(c, d.A(l), 256, Wl, l == 5 ? cx + 256 : 256, P, 256, 256, d.A(l - 1), 256, 0, w.A(l - 1));
     }
-    float* tmp = dA; dA = dN; dN = tmp;
+    if (obj) {
+      lin_dgrad(c, t2i, 3, Wt(P_ORGB), 64, P, 3, 64, d.odirh(), 64, 0, w.odirh());
+      lin_dgrad(c, d.odirh(), 64, Wt(P_OD), 128 + kDirC, P, 64, 128, d.ofinal(), 128, 0);
+      lin_dgrad(c, d.ofinal(), 128, Wt(P_OF), 128, P, 128, 128, d.B(4), 128, 0);
+      lin_dgrad(c, d_inst_sigma, 1, Wt(P_OSIG), 128, P, 1, 128, d.B(4), 128, 1, w.B(4));
+      for (int l = 4; l >= 2; --l) {
+        const float* Wl = l == 3 ? Wt(P_O3) + co : Wt(P_O1 + l - 1);
+        lin_dgrad(c, d.B(l), 128, Wl, l == 3 ? co + 128 : 128, P, 128, 128, d.B(l - 1), 128, 0, w.B(l - 1));
+      }
+    }
   }
 
-  // ---- object branch ----
-  if (a->do_object) {
+  // ---- phase B: weight / bias gradients (dW = dY^T X, split over the points) and the gradients w.r.t. the inputs ----
+  // scene heads and the direction layer (cat([final, emb_dir]) as column blocks)
+  lin_wgrad(c, t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128, gB(P_SRGB));
+  lin_wgrad(c, d.dirh(), 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC, gB(P_SD));
+  lin_wgrad(c, d.dirh(), 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
+  lin_wgrad(c, d.final_(), 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256, gB(P_SF));
+  lin_wgrad(c, d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256, gB(P_SSIG));
+  for (int l = 8; l >= 1; --l) {
+    float* db = gB(P_S1 + l - 1);
+    if (l == 5) {          // cat([input_xyz, h])
+      lin_wgrad(c, d.A(5), 256, X, cx, P, 256, cx, gW(P_S5), cx + 256, db);
+      lin_wgrad(c, d.A(5), 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
+      lin_dgrad(c, d.A(5), 256, Wt(P_S5), cx + 256, P, 256, cx, d_emb_xyz, cx, 0);
+    } else if (l == 1) {
+      lin_wgrad(c, d.A(1), 256, X, cx, P, 256, cx, gW(P_S1), cx, db);
+      lin_dgrad(c, d.A(1), 256, Wt(P_S1), cx, P, 256, cx, d_emb_xyz, cx, 1);          // layer 5 wrote it first
+    } else {
+      lin_wgrad(c, d.A(l), 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256, db);
+    }
+  }
+  if (obj) {
     const int ov = vox ? kObjVoxPE : 0;
-    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_inst_rgb, a->inst_rgb, 3 * P);
-    lin_wgrad(c, t2, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64, gB(P_ORGB));
-    lin_dgrad(c, t2, 3, Wt(P_ORGB), 64, P, 3, 64, t0, 64, 0, w.odirh());
-    lin_wgrad(c, t0, 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC, gB(P_OD));
-    lin_wgrad(c, t0, 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
-    lin_dgrad(c, t0, 64, Wt(P_OD), 128 + kDirC, P, 64, 128, t1, 128, 0);      // d ofinal
-    lin_wgrad(c, t1, 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128, gB(P_OF));
-    lin_dgrad(c, t1, 128, Wt(P_OF), 128, P, 128, 128, t0, 128, 0);            // dB4
-    lin_dgrad(c, d_inst_sigma, 1, Wt(P_OSIG), 128, P, 1, 128, t0, 128, 1, w.B(4));
+    lin_wgrad(c, t2i, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64, gB(P_ORGB));
+    lin_wgrad(c, d.odirh(), 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC, gB(P_OD));
+    lin_wgrad(c, d.odirh(), 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
+    lin_wgrad(c, d.ofinal(), 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128, gB(P_OF));
     lin_wgrad(c, d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128, gB(P_OSIG));
-    dA = t0; dN = t1;
     bool ov_written = false;
-    // gradient of one layer fed by cat([emb_xyz, obj_voxel, obj_code]) (+ optional hidden block at column co)
-    auto obj_in_bwd = [&](int wid, int ldw, float* db) {
-      lin_wgrad(c, dA, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
-      if (vox) lin_wgrad(c, dA, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
-      lin_wgrad(c, dA, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
-      lin_dgrad(c, dA, 128, Wt(wid), ldw, P, 128, cx, d_emb_xyz, cx, 1);       // scene branch wrote it first
-      if (vox) lin_dgrad(c, dA, 128, Wt(wid) + cx, ldw, P, 128, kObjVoxPE, d_obj_voxel, kObjVoxPE, ov_written ? 1 : 0);
-      lin_dgrad(c, dA, 128, Wt(wid) + cx + ov, ldw, P, 128, kCodeC, d_obj_code, kCodeC, ov_written ? 1 : 0);
+    // one layer fed by cat([emb_xyz, obj_voxel, obj_code]): three column blocks of its weight
+    auto obj_in_bwd = [&](const float* dY, int wid, int ldw, float* db) {
+      lin_wgrad(c, dY, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
+      if (vox) lin_wgrad(c, dY, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
+      lin_wgrad(c, dY, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
+      lin_dgrad(c, dY, 128, Wt(wid), ldw, P, 128, cx, d_emb_xyz, cx, 1);             // the scene branch wrote it first
+      if (vox) lin_dgrad(c, dY, 128, Wt(wid) + cx, ldw, P, 128, kObjVoxPE, d_obj_voxel, kObjVoxPE, ov_written ? 1 : 0);
+      lin_dgrad(c, dY, 128, Wt(wid) + cx + ov, ldw, P, 128, kCodeC, d_obj_code, kCodeC, ov_written ? 1 : 0);
       ov_written = true;
     };
     for (int l = 4; l >= 1; --l) {
       float* db = gB(P_O1 + l - 1);
-      if (l == 3) {
-        lin_wgrad(c, dA, 128, w.B(2), 128, P, 128, 128, gW(P_O3) + co, co + 128);
-        obj_in_bwd(P_O3, co + 128, db);
-        lin_dgrad(c, dA, 128, Wt(P_O3) + co, co + 128, P, 128, 128, dN, 128, 0, w.B(2));
+      if (l == 3) {        // cat([input_x, x_])
+        lin_wgrad(c, d.B(3), 128, w.B(2), 128, P, 128, 128, gW(P_O3) + co, co + 128);
+        obj_in_bwd(d.B(3), P_O3, co + 128, db);
       } else if (l == 1) {
-        obj_in_bwd(P_O1, co, db);
+        obj_in_bwd(d.B(1), P_O1, co, db);
       } else {
-        lin_wgrad(c, dA, 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128, db);
-        lin_dgrad(c, dA, 128, Wt(P_O1 + l - 1), 128, P, 128, 128, dN, 128, 0, w.B(l - 1));
+        lin_wgrad(c, d.B(l), 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128, db);
       }
-      float* tmp = dA; dA = dN; dN = tmp;
     }
   }
   return c.rc;

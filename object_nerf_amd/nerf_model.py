@@ -43,6 +43,16 @@ def _pack_index(use_voxel, device):
     return _index_cache[key]
 
 
+def _pack_index_bwd(use_voxel, device):
+    key = ("bwd", bool(use_voxel), str(device))
+    if key not in _index_cache:
+        l = _lib.lib()
+        bi = torch.empty(l.objnerf_bwd_blob_floats(), dtype=torch.int32)
+        _lib.check(l.objnerf_pack_index_bwd(int(use_voxel), C.c_void_p(bi.data_ptr())), "pack_index_bwd")
+        _index_cache[key] = bi.to(device)
+    return _index_cache[key]
+
+
 def _linear_act(i, o, act):
     return nn.Sequential(nn.Linear(i, o), act)
 
@@ -104,6 +114,8 @@ class ObjectNeRF(nn.Module):
 
         self._packed = None
         self._packed_key = None
+        self._packed_bwd = None
+        self._packed_bwd_key = None
 
     # ---- weight stream ---------------------------------------------------------------------
     def _param_list(self):
@@ -141,6 +153,24 @@ class ObjectNeRF(nn.Module):
                                           _lib.stream_ptr()), "pack_weights")
         self._packed, self._packed_key = (blob, aux), key
         return self._packed
+
+    def packed_bwd(self):
+        """Training only: device tensor with the transposed hidden-block weight stream of the fused backward
+        (objnerf_pack_weights_bwd), re-gathered like `packed()` when a parameter changed."""
+        params = self._param_list()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed_bwd is not None and key == self._packed_bwd_key:
+            return self._packed_bwd
+        dev = params[0].device
+        _lib.require_cuda(params[0], "ObjectNeRF parameters")
+        l = _lib.lib()
+        srcs = [_lib.as_f32(p.detach()) for p in params]
+        idx = _pack_index_bwd(int(self.use_voxel_embedding), dev)
+        blob = torch.empty(l.objnerf_bwd_blob_floats(), dtype=torch.float32, device=dev)
+        table = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+        _lib.check(l.objnerf_pack_weights_bwd(_lib.ptr(idx), table, _lib.ptr(blob), _lib.stream_ptr()), "pack_weights_bwd")
+        self._packed_bwd, self._packed_bwd_key = blob, key
+        return blob
 
     # ---- reference-compatible forward passes (pre-embedded inputs) -------------------------------
     def _check_no_grad(self, *tensors):

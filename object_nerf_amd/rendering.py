@@ -12,6 +12,7 @@ rendering.py:75-76), result keys and quirks are the reference's:
   * with rays_in_bbox the returned `weights_*` are the instance weights (rendering.py:228-229).
 """
 import ctypes as C
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -141,7 +142,12 @@ def render_rays(
                     use_zero_as_last_delta=use_zero_as_last_delta, frustum_bound_th=float(frustum_bound_th),
                     rays_in_bbox=bool(rays_in_bbox), randoms=rnd, z_steps=_linspace(S, dev),
                     u_det=_linspace(I, dev) if I > 0 else None, grid=emb_xyz.grid_struct() if use_voxel else None,
-                    ptm=pass_through_mask.reshape(n).to(torch.uint8).contiguous() if pass_through_mask is not None else None)
+                    ptm=pass_through_mask.reshape(n).to(torch.uint8).contiguous() if pass_through_mask is not None else None,
+                    # packed weight streams (forward, aux, transposed hidden blocks): forward and the hidden dgrad chain run on
+                    # the persistent MFMA kernels; OBJNERF_TRAIN_LAYERWISE=1 keeps the layer-by-layer GEMM path instead
+                    packed=None if os.environ.get("OBJNERF_TRAIN_LAYERWISE") == "1" else
+                    (coarse.packed() + (coarse.packed_bwd(),),
+                     models["fine"].packed() + (models["fine"].packed_bwd(),) if I > 0 else None))
         outs = RenderRaysFn.apply(meta, rays_c, embedding_instance, table, *plist)
         keys = sorted(["%s_%s" % (k, t) for t in (("coarse", "fine") if I > 0 else ("coarse",))
                        for k in (["weights", "opacity", "z_vals", "rgb", "depth"]

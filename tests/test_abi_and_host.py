@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "missing export: " + name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     l = _lib.lib()
-    assert l.objnerf_abi_version() == 1
+    version = int(re.search(r"#define OBJNERF_ABI_VERSION (\d+)", hdr).group(1))
+    assert l.objnerf_abi_version() == version == _lib.ABI_VERSION
     assert l.objnerf_blob_floats(1) == 111 * 8192 and l.objnerf_blob_floats(0) == 87 * 8192
     assert l.objnerf_num_param_ptrs() == 2 * len(PARAM_LAYERS) == 40
 
