@@ -299,6 +299,12 @@ typedef struct {
    * parameter values.  When given, the dgrad chain through the hidden layers runs in one persistent MFMA kernel
    * (gradient tiles stay in registers from layer to layer) instead of one GEMM + activation-backward per layer. */
   const float* blob_bwd;
+  /* optional, forward only, with blob/aux: the un-embedded inputs of the same points (points = rays x S in ray-major
+   * order, exactly what emb_xyz / emb_dir / obj_voxel / obj_code were computed from).  When rays != NULL the forward
+   * computes the embeddings in registers like objnerf_mlp_eval's fused form instead of reading them back. */
+  const float* rays; const float* z_vals; int64_t n_rays; int32_t S; int32_t _pad;
+  const float* codes; int64_t code_stride;
+  objnerf_voxel_grid grid;
 } objnerf_train_args;
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points);
 int64_t objnerf_train_scratch_floats(int64_t n_points);

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libobjnerf_hip.so")
+# OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
+LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
 ABI_VERSION = 2     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
@@ -67,6 +68,9 @@ class TrainArgs(C.Structure):
         ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
         ("workspace", C.c_void_p),
         ("blob", C.c_void_p), ("aux", C.c_void_p), ("blob_bwd", C.c_void_p),
+        ("rays", C.c_void_p), ("z_vals", C.c_void_p), ("n_rays", C.c_int64), ("S", C.c_int32), ("_pad", C.c_int32),
+        ("codes", C.c_void_p), ("code_stride", C.c_int64),
+        ("grid", VoxelGrid),
     ]
 
 

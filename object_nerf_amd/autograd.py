@@ -64,10 +64,16 @@ def _composite_args(meta, ps, outs=None):
     return a
 
 
-def _train_args(meta, ps, params, packed=None):
+def _train_args(meta, ps, params, packed=None, rays=None, codes=None):
     a = _lib.TrainArgs()
     if packed is not None:
         a.blob, a.aux, a.blob_bwd = packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()
+        if rays is not None:      # forward: embeddings recomputed in registers from the un-embedded inputs
+            a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), ps.z.data_ptr(), rays.shape[0], ps.S
+            if codes is not None:
+                a.codes, a.code_stride = codes.data_ptr(), codes.stride(0)
+            if meta["use_voxel"]:
+                a.grid = meta["grid"]
     a.use_voxel, a.do_object = int(meta["use_voxel"]), int(meta["forward_instance"])
     a.n_points = ps.emb_xyz.shape[0]
     table = _ptr_table(params)
@@ -124,7 +130,7 @@ class RenderRaysFn(torch.autograd.Function):
             ps.isig, ps.irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
             ps.ws = _empty(l.objnerf_train_workspace_floats(int(fi), P), dev=dev)
             ps.noise, ps.noise_i = noise, noise_i
-            a, keep = _train_args(meta, ps, pp, packed)
+            a, keep = _train_args(meta, ps, pp, packed, rays_c, codes_c if fi else None)
             _lib.check(l.objnerf_mlp_train_forward(C.byref(a), st), "mlp_train_forward")
             outs = {"weights": _empty(n, Sx, dev=dev), "opacity": _empty(n, dev=dev), "rgb": _empty(n, 3, dev=dev),
                     "depth": _empty(n, dev=dev)}

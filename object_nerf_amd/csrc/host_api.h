@@ -10,8 +10,8 @@ int set_error(int code, const char* msg);
 int check_launch(const char* what);
 
 // MLP kernel launchers, one translation unit per input form (compile time)
-int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);
 // save_ws != nullptr: training forward, every layer's activations are also written to the train.hip workspace
+int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
 int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
 // training: fused dgrad chain through the hidden layers (mlp_bwd.hip); act / dz in the workspace layout of train.hip
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,

@@ -29,6 +29,10 @@ struct BwdArgs {
 
 template <int NT>
 __device__ __forceinline__ void load_tiles(f32x16 (&v)[NT], const float* mat, long ld, long p, int half) {
+#ifdef OBJ_ABL_BWD_NOLOAD     // timing ablation only
+  for (int t = 0; t < NT; ++t) for (int r = 0; r < 16; ++r) v[t][r] = 1.f;
+  return;
+#endif
   const float* row = mat + p * ld + 4 * half;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -86,6 +90,9 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
     const bool valid = p_raw < P;
     const long p = valid ? p_raw : P - 1;
 
+    // Stores of a layer's result and the fetch of the activation that masks the NEXT result are issued from the
+    // after-barrier hook of the layer that consumes the former (layer_mac): they then have a chunk of MFMAs to land
+    // instead of being drained by the very next barrier.
     // ---------------- scene branch ----------------
     {
       f32x16 acc[8], h[8], av[8];
@@ -97,29 +104,41 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
 #pragma unroll
         for (int c = 0; c < 3; ++c) add_head<4>(hd, aux + kAuxSRgb + c * 4 * 32, half, a.t2[p * 3 + c]);
         mask_tiles<4>(hd, ad, hd);
-        save_tiles<4>(hd, dz.sdirh(), 128, p, half, valid);
         // BL_SD: -> d(xyz_encoding_final output), no activation there
         zero_tiles<8>(acc);
-        { HidSrc<4> s{hd}; layer_mac<8, bwd_ks(BL_SD)>(acc, st, s); }
+        {
+          HidSrc<4> s{hd};
+          layer_mac<8, bwd_ks(BL_SD)>(acc, st, s, [&]() __attribute__((always_inline)) {
+            save_tiles<4>(hd, dz.sdirh(), 128, p, half, valid);
+          });
+        }
       }
       finish<8, false>(acc, h);
-      save_tiles<8>(h, dz.sfinal(), 256, p, half, valid);
       // BL_SF: -> dA8, plus the density head's contribution, then layer 8's mask
-      load_tiles<8>(av, act.A(8), 256, p, half);
       zero_tiles<8>(acc);
-      { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+      {
+        HidSrc<8> s{h};
+        layer_mac<8, 128>(acc, st, s, [&]() __attribute__((always_inline)) {
+          save_tiles<8>(h, dz.sfinal(), 256, p, half, valid);
+          load_tiles<8>(av, act.A(8), 256, p, half);
+        });
+      }
       add_head<8>(acc, aux + kAuxSSig, half, a.d_sigma[p]);
       mask_tiles<8>(acc, av, h);
-      save_tiles<8>(h, dz.A(8), 256, p, half, valid);
       // BL_S8 .. BL_S2 (BL_S5 streams the hidden block of the skip layer): dZ_l -> dZ_{l-1}
 #pragma unroll 1
       for (int l = 8; l >= 2; --l) {
-        load_tiles<8>(av, act.A(l - 1), 256, p, half);
         zero_tiles<8>(acc);
-        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+        {
+          HidSrc<8> s{h};
+          layer_mac<8, 128>(acc, st, s, [&]() __attribute__((always_inline)) {
+            save_tiles<8>(h, dz.A(l), 256, p, half, valid);
+            load_tiles<8>(av, act.A(l - 1), 256, p, half);
+          });
+        }
         mask_tiles<8>(acc, av, h);
-        save_tiles<8>(h, dz.A(l - 1), 256, p, half, valid);
       }
+      save_tiles<8>(h, dz.A(1), 256, p, half, valid);
     }
 
     // ---------------- object branch ----------------
@@ -132,26 +151,38 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
 #pragma unroll
         for (int c = 0; c < 3; ++c) add_head<2>(hd, aux + kAuxORgb + c * 2 * 32, half, a.t2i[p * 3 + c]);
         mask_tiles<2>(hd, ad, hd);
-        save_tiles<2>(hd, dz.odirh(), 64, p, half, valid);
         zero_tiles<4>(acc);
-        { HidSrc<2> s{hd}; layer_mac<4, bwd_ks(BL_OD)>(acc, st, s); }
+        {
+          HidSrc<2> s{hd};
+          layer_mac<4, bwd_ks(BL_OD)>(acc, st, s, [&]() __attribute__((always_inline)) {
+            save_tiles<2>(hd, dz.odirh(), 64, p, half, valid);
+          });
+        }
       }
       finish<4, false>(acc, h);
-      save_tiles<4>(h, dz.ofinal(), 128, p, half, valid);
-      load_tiles<4>(av, act.B(4), 128, p, half);
       zero_tiles<4>(acc);
-      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+      {
+        HidSrc<4> s{h};
+        layer_mac<4, 64>(acc, st, s, [&]() __attribute__((always_inline)) {
+          save_tiles<4>(h, dz.ofinal(), 128, p, half, valid);
+          load_tiles<4>(av, act.B(4), 128, p, half);
+        });
+      }
       add_head<4>(acc, aux + kAuxOSig, half, a.d_isigma[p]);
       mask_tiles<4>(acc, av, h);
-      save_tiles<4>(h, dz.B(4), 128, p, half, valid);
 #pragma unroll 1
       for (int l = 4; l >= 2; --l) {
-        load_tiles<4>(av, act.B(l - 1), 128, p, half);
         zero_tiles<4>(acc);
-        { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+        {
+          HidSrc<4> s{h};
+          layer_mac<4, 64>(acc, st, s, [&]() __attribute__((always_inline)) {
+            save_tiles<4>(h, dz.B(l), 128, p, half, valid);
+            load_tiles<4>(av, act.B(l - 1), 128, p, half);
+          });
+        }
         mask_tiles<4>(acc, av, h);
-        save_tiles<4>(h, dz.B(l - 1), 128, p, half, valid);
       }
+      save_tiles<4>(h, dz.B(1), 128, p, half, valid);
     }
   }
 }

@@ -6,11 +6,28 @@ namespace objnerf {
 
 template <bool VOXEL, bool SC, bool OB>
 static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
 }
+#ifndef OBJ_TUNE_ONLY_MAIN
+// training forward: scene (+ object) branch, every layer's activations also written to save_ws
+template <bool VOXEL, bool OB>
+static void launch_save(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws) {
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, true, OB, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, save_ws);
+}
+#endif
 
-int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws) {
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
+#ifdef OBJ_TUNE_ONLY_MAIN
+  if (save_ws) return set_error(-9, "tuning build: training kernels are not compiled");
+#else
+  if (save_ws) {
+    if (!sc) return set_error(-1, "mlp_eval(fused, training): the scene branch is always evaluated");
+    if (a.use_voxel) { if (ob) launch_save<true, true>(a, ntiles, grid, s, save_ws); else launch_save<true, false>(a, ntiles, grid, s, save_ws); }
+    else { if (ob) launch_save<false, true>(a, ntiles, grid, s, save_ws); else launch_save<false, false>(a, ntiles, grid, s, save_ws); }
+    return check_launch("mlp_train_forward(fused)");
+  }
+#endif
 #ifdef OBJ_TUNE_ONLY_MAIN   // tuning builds (tools/tune_mlp.py): only the bench instantiation, to compile fast
   if (!(a.use_voxel && sc && ob)) return set_error(-9, "tuning build: only voxel scene+object is compiled");
   launch<true, true, true>(a, ntiles, grid, s);

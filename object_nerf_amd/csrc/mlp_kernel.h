@@ -185,11 +185,16 @@ __device__ __forceinline__ void load_group(ATiles<NT>& a, WeightStream& st) {
 // read from LDS (after the chunk barrier when g+1 opens a new chunk) before the MFMAs of group g
 // issue.  sched_barrier(0) between stages keeps the compiler from hoisting the embedding
 // arithmetic of later groups (it would otherwise keep hundreds of sin/cos values live and spill).
-template <int NT, int KS, class Src>
-__device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, Src& src) {
+// `after_barrier` runs right behind the layer's first chunk barrier.  The barrier drains vmcnt (LDS-DMA), so global
+// loads/stores issued just BEFORE it are waited for in full, while ones issued just AFTER it have a whole chunk of
+// MFMAs to complete: the training kernels put their activation stores and prefetches there.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NT, int KS, class Src, class Hook = NoHook>
+__device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, Src& src, Hook after_barrier = Hook{}) {
   constexpr int NG4 = (KS + 3) / 4;
   ATiles<NT> abuf[2];
   load_group<NT, 0>(abuf[0], st);
+  after_barrier();
 #if OBJ_EMB_PIPE
   float b_next = src.template get<0>();
 #endif
@@ -607,6 +612,9 @@ struct TilePrologue {
 // ---------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, long ld, long p, int half, bool valid) {
+#ifdef OBJ_ABL_NOSAVE         // timing ablation only
+  return;
+#endif
   if (!valid) return;
   float* row = mat + p * ld + 4 * half;
 #pragma unroll
@@ -617,6 +625,17 @@ __device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, lo
       *(f32x4*)(row + 32 * t + 8 * g) = v;
     }
 }
+template <bool ON, int NT>
+struct SaveHook {      // layer_mac after-barrier hook: write h (the layer's input = the previous layer's output)
+  const f32x16 (&h)[NT];
+  float* mat;
+  long ld, p;
+  int half;
+  bool valid;
+  __device__ __forceinline__ void operator()() const {
+    if constexpr (ON) save_tiles<NT>(h, mat, ld, p, half, valid);
+  }
+};
 // saved-activation matrices, floats per point: scene 8 x 256 | final 256 | dir hidden 128 | (4 unused) |
 // object 4 x 128 | final 128 | dir hidden 64 | (4 unused)   -- same arithmetic as train.hip's Ws
 struct SaveWs {
@@ -724,27 +743,26 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<8>(acc, aux, L_S1, half);
       { EmbOnly<Src> s{src}; layer_mac<8, NE>(acc, st, s); }
       finish<8, true>(acc, h);
-      if constexpr (SAVE) save_tiles<8>(h, ws.A(1), 256, p, half, valid);
+      // SAVE: a layer's output is written by the NEXT layer's after-barrier hook (see layer_mac); h is that layer's
+      // input and stays live anyway
+      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 8>{h, mat, 256, p, half, valid}; };
       // xyz_encoding_2..4
 #pragma unroll 1
       for (int l = L_S2; l <= L_S4; ++l) {
         load_bias<8>(acc, aux, l, half);
-        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(l - L_S1))); }
         finish<8, true>(acc, h);
-        if constexpr (SAVE) save_tiles<8>(h, ws.A(l - L_S1 + 1), 256, p, half, valid);
       }
       // xyz_encoding_5 (skip: cat([emb, h]))
       src.launder();
       load_bias<8>(acc, aux, L_S5, half);
-      { EmbThenHid<Src, NE, 8> s{src, h}; layer_mac<8, NE + 128>(acc, st, s); }
+      { EmbThenHid<Src, NE, 8> s{src, h}; layer_mac<8, NE + 128>(acc, st, s, save_h(ws.A(4))); }
       finish<8, true>(acc, h);
-      if constexpr (SAVE) save_tiles<8>(h, ws.A(5), 256, p, half, valid);
 #pragma unroll 1
       for (int l = L_S6; l <= L_S8; ++l) {
         load_bias<8>(acc, aux, l, half);
-        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(l - L_S1))); }
         finish<8, true>(acc, h);
-        if constexpr (SAVE) save_tiles<8>(h, ws.A(l - L_S1 + 1), 256, p, half, valid);
       }
       // sigma head (no activation, nerf_model.py:108)
       const float sg = head_dot<8>(h, aux + kAuxSSig, half) + aux[kAuxSSig + 8 * 32];
@@ -753,14 +771,13 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       } else {
       // xyz_encoding_final (no activation)
       load_bias<8>(acc, aux, L_SF, half);
-      { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s); }
+      { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(8))); }
       finish<8, false>(acc, h);
-      if constexpr (SAVE) save_tiles<8>(h, ws.sfinal(), 256, p, half, valid);
       // dir_encoding: cat([final, dir]) -> W/2, LeakyReLU
       f32x16 acc4[4], hd[4];
       src.launder();
       load_bias<4>(acc4, aux, L_SD, half);
-      { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s); }
+      { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal())); }
       finish<4, true>(acc4, hd);
       if constexpr (SAVE) save_tiles<4>(hd, ws.sdirh(), 128, p, half, valid);
       float col[3];
@@ -782,36 +799,32 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<4>(acc, aux, L_O1, half);
       { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
       finish<4, true>(acc, h);
-      if constexpr (SAVE) save_tiles<4>(h, ws.B(1), 128, p, half, valid);
+      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 4>{h, mat, 128, p, half, valid}; };
       if constexpr (PREFETCH) pre.stage_b(a.grid);
       load_bias<4>(acc, aux, L_O2, half);
-      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(1))); }
       finish<4, true>(acc, h);
-      if constexpr (SAVE) save_tiles<4>(h, ws.B(2), 128, p, half, valid);
       if constexpr (PREFETCH) pre.template stage_rows<0>(a.grid, half);
       src.launder();
       load_bias<4>(acc, aux, L_O3, half);
-      { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s); }
+      { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2))); }
       finish<4, true>(acc, h);
-      if constexpr (SAVE) save_tiles<4>(h, ws.B(3), 128, p, half, valid);
       if constexpr (PREFETCH) { pre.template stage_acc<0>(); pre.template stage_rows<1>(a.grid, half); }
       load_bias<4>(acc, aux, L_O4, half);
-      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(3))); }
       finish<4, true>(acc, h);
-      if constexpr (SAVE) save_tiles<4>(h, ws.B(4), 128, p, half, valid);
       const float sg = head_dot<4>(h, aux + kAuxOSig, half) + aux[kAuxOSig + 4 * 32];
       if constexpr (PREFETCH) pre.template stage_acc<1>();
       if constexpr (SIGMA_ONLY) {
         if (valid && half == 0) a.inst_sigma[p] = sg;
       } else {
       load_bias<4>(acc, aux, L_OF, half);
-      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s); }
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(4))); }
       finish<4, false>(acc, h);
-      if constexpr (SAVE) save_tiles<4>(h, ws.ofinal(), 128, p, half, valid);
       f32x16 acc2[2], hd[2];
       src.launder();
       load_bias<2>(acc2, aux, L_OD, half);
-      { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s); }
+      { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal())); }
       finish<2, true>(acc2, hd);
       if constexpr (SAVE) save_tiles<2>(hd, ws.odirh(), 64, p, half, valid);
       float col[3];

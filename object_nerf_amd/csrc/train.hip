@@ -129,6 +129,18 @@ int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
     m.sigma = a->sigma; m.rgb = a->rgb; m.inst_sigma = a->inst_sigma; m.inst_rgb = a->inst_rgb;
     const long ntiles = (P + 127) / 128;
     const unsigned grid = mlp_grid(ntiles);
+    if (a->rays) {
+      // embeddings computed in registers from (rays, z, grid, codes): both branches in one launch
+      if (!a->z_vals || a->S < 1 || a->n_rays * (int64_t)a->S != P || (a->do_object && !a->codes))
+        return set_error(-1, "mlp_train_forward: bad fused inputs");
+      if (a->use_voxel && (!a->grid.idx_map || !a->grid.table || a->grid.n_rows < 1))
+        return set_error(-1, "mlp_train_forward: voxel mode needs a voxel grid");
+      m.rays = a->rays; m.z_vals = a->z_vals; m.n_rays = a->n_rays; m.S = a->S;
+      m.codes = a->codes; m.code_stride = a->code_stride; m.grid = a->grid;
+      m.emb_xyz = nullptr; m.emb_dir = nullptr; m.obj_voxel = nullptr; m.obj_code = nullptr;
+      m.do_scene = 1; m.do_object = a->do_object ? 1 : 0;
+      return launch_mlp_fused(m, ntiles, grid, (hipStream_t)stream, a->workspace);
+    }
     m.do_scene = 1; m.do_object = 0;
     int rc = launch_mlp_memory(m, ntiles, grid, (hipStream_t)stream, a->workspace);
     if (rc == 0 && a->do_object) {
