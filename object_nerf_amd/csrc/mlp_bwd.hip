@@ -7,7 +7,7 @@
 // weight blocks stream through the 2-slot LDS ring (layout.h: "backward weight stream"), and the D tile of one layer
 // -- the gradient, features x points in registers -- is the B operand of the next, so the chain never leaves the
 // register file.  Per layer the kernel only reads the saved forward activation (for the LeakyReLU mask, fetched
-// before the layer's MFMAs and consumed after them) and writes the gradient w.r.t. the layer's pre-activation output,
+// under the layer's MFMAs and consumed after them) and writes the gradient w.r.t. the layer's pre-activation output,
 // which the weight-gradient GEMMs and the embedding-gradient GEMMs of train.hip consume afterwards.
 // Heads: d(dir hidden) = t2 * W_rgb and "+ d_sigma * w_sigma" are 3- and 1-term VALU updates from the aux block.
 #include "mlp_kernel.h"
@@ -27,35 +27,90 @@ struct BwdArgs {
   const float* t2i;
 };
 
+// Saved activations come back the way save_tiles wrote them: 8 consecutive lanes read one 128-byte line of a point.
+// Only their signs are needed (LeakyReLU mask), and registers are tight (gradient in + gradient out = 256 of 512),
+// so a layer fetches them four tiles at a time behind one chunk barrier and, behind the next one, turns them into
+// the D layout through the wave's LDS patch and keeps one bit per value.
+struct RawTiles { f32x4 v[4][4]; };          // 4 tiles x 4 row groups, as fetched (lane = (row q, piece k))
 template <int NT>
-__device__ __forceinline__ void load_tiles(f32x16 (&v)[NT], const float* mat, long ld, long p, int half) {
+struct MaskBits { unsigned w[NT / 2]; };     // tile t -> bits 16 (t & 1) .. + 15 of w[t / 2]
+template <int N>
+__device__ __forceinline__ void fetch_tiles(RawTiles& raw, const float* mat, long ld, int t0, const Stage& sg) {
+  const int q = sg.lane >> 3, k = sg.lane & 7;
+#pragma unroll
+  for (int t = 0; t < N; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
 #ifdef OBJ_ABL_BWD_NOLOAD     // timing ablation only
-  for (int t = 0; t < NT; ++t) for (int r = 0; r < 16; ++r) v[t][r] = 1.f;
-  return;
+      raw.v[t][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
+      const long row = sg.p0 + 8 * i + q;
+#if OBJ_NT_ACT
+      raw.v[t][i] = __builtin_nontemporal_load((const f32x4*)(mat + (row < sg.P ? row : sg.P - 1) * ld + 32 * (t0 + t) + 4 * k));
+#else
+      raw.v[t][i] = *(const f32x4*)(mat + (row < sg.P ? row : sg.P - 1) * ld + 32 * (t0 + t) + 4 * k);
 #endif
-  const float* row = mat + p * ld + 4 * half;
+#endif
+    }
+}
+template <int NT, int N, int T0>
+__device__ __forceinline__ void sign_bits(const RawTiles& raw, MaskBits<NT>& bits, const Stage& sg) {
+  const int pt = sg.lane & 31, half = sg.lane >> 5, q = sg.lane >> 3, k = sg.lane & 7;
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(sg.buf + (8 * i + q) * kStageLd + 4 * k) = raw.v[t][i];
+    unsigned m = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 act = *(const f32x4*)(sg.buf + pt * kStageLd + 8 * g + 4 * half);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m |= (act[j] > 0.f ? 1u : 0u) << (4 * g + j);
+    }
+    if (((T0 + t) & 1) == 0) bits.w[(T0 + t) / 2] = m;       // t is unrolled: resolved at compile time
+    else bits.w[(T0 + t) / 2] |= m << 16;
+  }
+}
+// h = leaky'(act) . acc      (leaky_relu backward on sign(output) = sign(input))
+template <int NT>
+__device__ __forceinline__ void mask_tiles(const f32x16 (&acc)[NT], const MaskBits<NT>& bits, f32x16 (&h)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 x = *(const f32x4*)(row + 32 * t + 8 * g);
-      v[t][4 * g] = x[0]; v[t][4 * g + 1] = x[1]; v[t][4 * g + 2] = x[2]; v[t][4 * g + 3] = x[3];
-    }
+    for (int r = 0; r < 16; ++r)
+      h[t][r] = ((bits.w[t / 2] >> (16 * (t & 1) + r)) & 1u) ? acc[t][r] : 0.01f * acc[t][r];
 }
+// after-barrier hook of one backward layer: chunk 0 stores the layer's input gradient (the previous layer's result)
+// and fetches the first four activation tiles of the mask of ITS result; chunks 1, 2 reduce them to bits / fetch the rest
+template <int NTIN, int NTOUT>
+struct BwdHook {
+  const f32x16 (&hin)[NTIN];
+  float* save_mat; long save_ld;
+  const float* act_mat; long act_ld;        // nullptr: the layer's result is not masked
+  RawTiles& raw;
+  MaskBits<NTOUT>& bits;
+  const Stage& sg;
+  template <int C>
+  __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {
+    if constexpr (C == 0) {
+      save_tiles<NTIN>(hin, save_mat, save_ld, sg);
+      if (act_mat) fetch_tiles<4>(raw, act_mat, act_ld, 0, sg);
+    } else if constexpr (C == 1) {
+      if (act_mat) {
+        sign_bits<NTOUT, 4, 0>(raw, bits, sg);
+        if constexpr (NTOUT == 8) fetch_tiles<4>(raw, act_mat, act_ld, 4, sg);
+      }
+    } else if constexpr (C == 2 && NTOUT == 8) {
+      if (act_mat) sign_bits<NTOUT, 4, 4>(raw, bits, sg);
+    }
+  }
+};
 template <int NT>
 __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-}
-// h = leaky'(act) . acc      (leaky_relu backward on sign(output) = sign(input))
-template <int NT>
-__device__ __forceinline__ void mask_tiles(const f32x16 (&acc)[NT], const f32x16 (&act)[NT], f32x16 (&h)[NT]) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h[t][r] = act[t][r] > 0.f ? acc[t][r] : 0.01f * acc[t][r];
 }
 // acc[t][r] += s * head_row[(t, half, r)]   (gradient of a 1-output head: outer product with its weight row)
 template <int NT>
@@ -70,7 +125,7 @@ __device__ __forceinline__ void add_head(f32x16 (&acc)[NT], const float* w, int 
 
 template <bool DO_OBJ>
 __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const long ntiles) {
-  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + kAuxFloats * 4];
+  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + kAuxFloats * 4 + kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int half = lane >> 5;
@@ -90,27 +145,32 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
     const bool valid = p_raw < P;
     const long p = valid ? p_raw : P - 1;
 
+    const Stage sg_scene{(float*)(ring_mem + kRingSlots * kChunkBytes + kAuxFloats * 4) + wave * kStageFloats,
+                         tile * 128 + wave * 32, P, lane};
     // Stores of a layer's result and the fetch of the activation that masks the NEXT result are issued from the
-    // after-barrier hook of the layer that consumes the former (layer_mac): they then have a chunk of MFMAs to land
+    // after-barrier hooks of the layer that consumes the former (layer_mac): they then have a chunk of MFMAs to land
     // instead of being drained by the very next barrier.
+    RawTiles raw;
     // ---------------- scene branch ----------------
     {
-      f32x16 acc[8], h[8], av[8];
+      const Stage& sg = sg_scene;
+      f32x16 acc[8], h[8];
+      MaskBits<8> bits;
       {
         // d(dir hidden) = t2 (P,3) * W_rgb (3,128), masked by the dir layer's LeakyReLU
-        f32x16 hd[4], ad[4];
-        load_tiles<4>(ad, act.sdirh(), 128, p, half);
+        f32x16 hd[4];
+        MaskBits<4> bd;
+        fetch_tiles<4>(raw, act.sdirh(), 128, 0, sg);
         zero_tiles<4>(hd);
 #pragma unroll
         for (int c = 0; c < 3; ++c) add_head<4>(hd, aux + kAuxSRgb + c * 4 * 32, half, a.t2[p * 3 + c]);
-        mask_tiles<4>(hd, ad, hd);
+        sign_bits<4, 4, 0>(raw, bd, sg);
+        mask_tiles<4>(hd, bd, hd);
         // BL_SD: -> d(xyz_encoding_final output), no activation there
         zero_tiles<8>(acc);
         {
           HidSrc<4> s{hd};
-          layer_mac<8, bwd_ks(BL_SD)>(acc, st, s, [&]() __attribute__((always_inline)) {
-            save_tiles<4>(hd, dz.sdirh(), 128, p, half, valid);
-          });
+          layer_mac<8, bwd_ks(BL_SD)>(acc, st, s, BwdHook<4, 8>{hd, dz.sdirh(), 128, nullptr, 0, raw, bits, sg});
         }
       }
       finish<8, false>(acc, h);
@@ -118,71 +178,64 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
       zero_tiles<8>(acc);
       {
         HidSrc<8> s{h};
-        layer_mac<8, 128>(acc, st, s, [&]() __attribute__((always_inline)) {
-          save_tiles<8>(h, dz.sfinal(), 256, p, half, valid);
-          load_tiles<8>(av, act.A(8), 256, p, half);
-        });
+        layer_mac<8, 128>(acc, st, s, BwdHook<8, 8>{h, dz.sfinal(), 256, act.A(8), 256, raw, bits, sg});
       }
       add_head<8>(acc, aux + kAuxSSig, half, a.d_sigma[p]);
-      mask_tiles<8>(acc, av, h);
+      mask_tiles<8>(acc, bits, h);
       // BL_S8 .. BL_S2 (BL_S5 streams the hidden block of the skip layer): dZ_l -> dZ_{l-1}
 #pragma unroll 1
       for (int l = 8; l >= 2; --l) {
         zero_tiles<8>(acc);
         {
           HidSrc<8> s{h};
-          layer_mac<8, 128>(acc, st, s, [&]() __attribute__((always_inline)) {
-            save_tiles<8>(h, dz.A(l), 256, p, half, valid);
-            load_tiles<8>(av, act.A(l - 1), 256, p, half);
-          });
+          layer_mac<8, 128>(acc, st, s, BwdHook<8, 8>{h, dz.A(l), 256, act.A(l - 1), 256, raw, bits, sg});
         }
-        mask_tiles<8>(acc, av, h);
+        mask_tiles<8>(acc, bits, h);
       }
-      save_tiles<8>(h, dz.A(1), 256, p, half, valid);
+      save_tiles<8>(h, dz.A(1), 256, sg);
     }
 
     // ---------------- object branch ----------------
     if constexpr (DO_OBJ) {
-      f32x16 acc[4], h[4], av[4];
+      // keep the compiler from computing this branch's per-lane addresses ahead of the scene branch (spills)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const Stage sg{sg_scene.buf, sg_scene.p0, sg_scene.P, lane_o};
+      f32x16 acc[4], h[4];
+      MaskBits<4> bits;
       {
-        f32x16 hd[2], ad[2];
-        load_tiles<2>(ad, act.odirh(), 64, p, half);
+        f32x16 hd[2];
+        MaskBits<2> bd;
+        fetch_tiles<2>(raw, act.odirh(), 64, 0, sg);
         zero_tiles<2>(hd);
 #pragma unroll
         for (int c = 0; c < 3; ++c) add_head<2>(hd, aux + kAuxORgb + c * 2 * 32, half, a.t2i[p * 3 + c]);
-        mask_tiles<2>(hd, ad, hd);
+        sign_bits<2, 2, 0>(raw, bd, sg);
+        mask_tiles<2>(hd, bd, hd);
         zero_tiles<4>(acc);
         {
           HidSrc<2> s{hd};
-          layer_mac<4, bwd_ks(BL_OD)>(acc, st, s, [&]() __attribute__((always_inline)) {
-            save_tiles<2>(hd, dz.odirh(), 64, p, half, valid);
-          });
+          layer_mac<4, bwd_ks(BL_OD)>(acc, st, s, BwdHook<2, 4>{hd, dz.odirh(), 64, nullptr, 0, raw, bits, sg});
         }
       }
       finish<4, false>(acc, h);
       zero_tiles<4>(acc);
       {
         HidSrc<4> s{h};
-        layer_mac<4, 64>(acc, st, s, [&]() __attribute__((always_inline)) {
-          save_tiles<4>(h, dz.ofinal(), 128, p, half, valid);
-          load_tiles<4>(av, act.B(4), 128, p, half);
-        });
+        layer_mac<4, 64>(acc, st, s, BwdHook<4, 4>{h, dz.ofinal(), 128, act.B(4), 128, raw, bits, sg});
       }
       add_head<4>(acc, aux + kAuxOSig, half, a.d_isigma[p]);
-      mask_tiles<4>(acc, av, h);
+      mask_tiles<4>(acc, bits, h);
 #pragma unroll 1
       for (int l = 4; l >= 2; --l) {
         zero_tiles<4>(acc);
         {
           HidSrc<4> s{h};
-          layer_mac<4, 64>(acc, st, s, [&]() __attribute__((always_inline)) {
-            save_tiles<4>(h, dz.B(l), 128, p, half, valid);
-            load_tiles<4>(av, act.B(l - 1), 128, p, half);
-          });
+          layer_mac<4, 64>(acc, st, s, BwdHook<4, 4>{h, dz.B(l), 128, act.B(l - 1), 128, raw, bits, sg});
         }
-        mask_tiles<4>(acc, av, h);
+        mask_tiles<4>(acc, bits, h);
       }
-      save_tiles<4>(h, dz.B(1), 128, p, half, valid);
+      save_tiles<4>(h, dz.B(1), 128, sg);
     }
   }
 }

@@ -45,6 +45,9 @@
 #ifndef OBJ_PREFETCH_TILE
 #define OBJ_PREFETCH_TILE 1  // gather prologue of the NEXT tile staged between the object-branch layers
 #endif
+#ifndef OBJ_NT_ACT
+#define OBJ_NT_ACT 1         // training kernels: activation stores / fetches carry the non-temporal hint
+#endif
 #ifndef OBJ_CODE_REGS
 #define OBJ_CODE_REGS 1      // object code (32 floats per lane half) loaded once per pass into VGPRs
 #endif
@@ -185,16 +188,20 @@ __device__ __forceinline__ void load_group(ATiles<NT>& a, WeightStream& st) {
 // read from LDS (after the chunk barrier when g+1 opens a new chunk) before the MFMAs of group g
 // issue.  sched_barrier(0) between stages keeps the compiler from hoisting the embedding
 // arithmetic of later groups (it would otherwise keep hundreds of sin/cos values live and spill).
-// `after_barrier` runs right behind the layer's first chunk barrier.  The barrier drains vmcnt (LDS-DMA), so global
-// loads/stores issued just BEFORE it are waited for in full, while ones issued just AFTER it have a whole chunk of
-// MFMAs to complete: the training kernels put their activation stores and prefetches there.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_barrier(integral_constant<int, c>)` runs right behind the barrier that opens the layer's c-th chunk.  The
+// barrier drains vmcnt (LDS-DMA), so global loads/stores issued just BEFORE it are waited for in full, while ones
+// issued just AFTER it have a whole chunk of MFMAs to complete: the training kernels put their activation stores and
+// prefetches there.
+struct NoHook {
+  template <int C> __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {}
+};
 template <int NT, int KS, class Src, class Hook = NoHook>
 __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, Src& src, Hook after_barrier = Hook{}) {
   constexpr int NG4 = (KS + 3) / 4;
+  constexpr int KG = kChunkTiles / NT;
   ATiles<NT> abuf[2];
   load_group<NT, 0>(abuf[0], st);
-  after_barrier();
+  after_barrier(std::integral_constant<int, 0>{});
 #if OBJ_EMB_PIPE
   float b_next = src.template get<0>();
 #endif
@@ -202,7 +209,10 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, S
     constexpr int g = decltype(G)::value;
     constexpr int ks0 = g * 4;
     ATiles<NT>& a = abuf[g & 1];
-    if constexpr (g + 1 < NG4) load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
+    if constexpr (g + 1 < NG4) {
+      load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
+      if constexpr (((g + 1) * 4) % KG == 0) after_barrier(std::integral_constant<int, ((g + 1) * 4) / KG>{});
+    }
 #if OBJ_HOIST_LDS
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -608,32 +618,59 @@ struct TilePrologue {
 // ---------------------------------------------------------------------------------------------
 // training forward (SAVE): every layer's output also goes to the row-major (P x width) activation matrices the
 // layer-wise backward reads (train.hip, struct Ws).  h[t][4g..4g+3] of lane half hf are features
-// 32 t + 8 g + 4 hf .. + 3 of one point: one 16-byte store; the four g of a tile complete a 128-byte line.
+// 32 t + 8 g + 4 hf .. + 3 of one point.
 // ---------------------------------------------------------------------------------------------
+// The lane-native form of a tile (16 bytes per lane at a 1 KB stride between points) costs one memory request per
+// 16-byte piece -- measured: a quarter of the training kernels' time.  Each wave therefore turns the tile around in a
+// private 32 x 36-float LDS patch: D layout in (ds_write_b128, conflict-free at the 36-float row stride), point rows
+// out (ds_read_b128), so that 8 consecutive lanes store one full 128-byte line of a point.
+constexpr int kStageLd = 36;
+constexpr int kStageFloats = 32 * kStageLd;         // one wave
+constexpr int kStageBytes = 4 * kStageFloats * 4;   // four waves
+struct Stage {
+  float* buf;     // this wave's patch (LDS)
+  long p0;        // first point of the wave's 32
+  long P;
+  int lane;
+};
 template <int NT>
-__device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, long ld, long p, int half, bool valid) {
+__device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, long ld, const Stage& sg) {
 #ifdef OBJ_ABL_NOSAVE         // timing ablation only
   return;
 #endif
-  if (!valid) return;
-  float* row = mat + p * ld + 4 * half;
+  const int pt = sg.lane & 31, half = sg.lane >> 5, q = sg.lane >> 3, k = sg.lane & 7;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v = {h[t][4 * g], h[t][4 * g + 1], h[t][4 * g + 2], h[t][4 * g + 3]};
-      *(f32x4*)(row + 32 * t + 8 * g) = v;
+      *(f32x4*)(sg.buf + pt * kStageLd + 8 * g + 4 * half) = v;
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + q;
+      const f32x4 v = *(const f32x4*)(sg.buf + row * kStageLd + 4 * k);
+      // non-temporal: ~10 GB of activations stream past per training step and must not evict the 2-4 MB weight
+      // stream every workgroup replays from L2
+      if (sg.p0 + row < sg.P) {
+#if OBJ_NT_ACT
+        __builtin_nontemporal_store(v, (f32x4*)(mat + (sg.p0 + row) * ld + 32 * t + 4 * k));
+#else
+        *(f32x4*)(mat + (sg.p0 + row) * ld + 32 * t + 4 * k) = v;
+#endif
+      }
+    }
+  }
 }
 template <bool ON, int NT>
 struct SaveHook {      // layer_mac after-barrier hook: write h (the layer's input = the previous layer's output)
   const f32x16 (&h)[NT];
   float* mat;
-  long ld, p;
-  int half;
-  bool valid;
-  __device__ __forceinline__ void operator()() const {
-    if constexpr (ON) save_tiles<NT>(h, mat, ld, p, half, valid);
+  long ld;
+  const Stage& sg;
+  template <int C>
+  __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {
+    if constexpr (ON && C == 0) save_tiles<NT>(h, mat, ld, sg);
   }
 };
 // saved-activation matrices, floats per point: scene 8 x 256 | final 256 | dir hidden 128 | (4 unused) |
@@ -658,7 +695,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");
   // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read of a glds
   // pipeline, guide §5 "three .s-level traps"): [2-slot weight ring | aux block]
-  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)];
+  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0) +
+                                                        (SAVE ? kStageBytes : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int half = lane >> 5;
@@ -733,6 +771,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       src.ovox = (VOXEL && DO_OBJ) ? a.obj_voxel + p * kObjVoxPE : nullptr;
       src.ocode = DO_OBJ ? a.obj_code + p * kCodeC : nullptr;
     }
+    const Stage stg{(float*)(ring_mem + kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)) + wave * kStageFloats,
+                   tile * 128 + wave * 32, P, lane};
     // tile whose prologue is staged during this pass (the last pass re-stages its own tile: harmless)
     const long tile_next = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
 
@@ -745,7 +785,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       finish<8, true>(acc, h);
       // SAVE: a layer's output is written by the NEXT layer's after-barrier hook (see layer_mac); h is that layer's
       // input and stays live anyway
-      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 8>{h, mat, 256, p, half, valid}; };
+      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 8>{h, mat, 256, stg}; };
       // xyz_encoding_2..4
 #pragma unroll 1
       for (int l = L_S2; l <= L_S4; ++l) {
@@ -779,7 +819,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<4>(acc4, aux, L_SD, half);
       { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal())); }
       finish<4, true>(acc4, hd);
-      if constexpr (SAVE) save_tiles<4>(hd, ws.sdirh(), 128, p, half, valid);
+      if constexpr (SAVE) save_tiles<4>(hd, ws.sdirh(), 128, stg);
       float col[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -799,7 +839,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<4>(acc, aux, L_O1, half);
       { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
       finish<4, true>(acc, h);
-      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 4>{h, mat, 128, p, half, valid}; };
+      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 4>{h, mat, 128, stg}; };
       if constexpr (PREFETCH) pre.stage_b(a.grid);
       load_bias<4>(acc, aux, L_O2, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(1))); }
@@ -826,7 +866,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       load_bias<2>(acc2, aux, L_OD, half);
       { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal())); }
       finish<2, true>(acc2, hd);
-      if constexpr (SAVE) save_tiles<2>(hd, ws.odirh(), 64, p, half, valid);
+      if constexpr (SAVE) save_tiles<2>(hd, ws.odirh(), 64, stg);
       float col[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)

@@ -59,8 +59,11 @@ static void lin_dgrad(Ctx& c, const float* dY, long lddy, const float* W, long l
 static void lin_wgrad(Ctx& c, const float* dY, long lddy, const float* X, long ldx, long P, int out, int in, float* dW,
                       long ldw, float* db = nullptr) {
   if (c.rc) return;
+  // Split over the points so that a workgroup contracts ~1024 of them (~512 when the output is a single tile):
+  // measured optimum on MI355X for P = 1.3e5 .. 2.6e5 (tools/split_bench.py) -- fewer splits leave CUs idle, more
+  // splits pay the 16K-atomic epilogue per workgroup for too little work.
   const long tiles = ((out + GBM - 1) / GBM) * (long)((in + GBN - 1) / GBN);
-  long split = (1024 + tiles - 1) / tiles;                          // ~4 workgroups per CU
+  long split = P / (tiles >= 2 ? 1024 : 512);
   const long max_split = (P + 4 * GBK - 1) / (4 * GBK);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
