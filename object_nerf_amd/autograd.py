@@ -15,6 +15,7 @@ Gradients are produced for every ObjectNeRF parameter (coarse and fine), the vox
 allocates tensors, repeats per-ray rows to per-point rows and orders the launches.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -67,8 +68,14 @@ def _composite_args(meta, ps, outs=None):
 def _train_args(meta, ps, params, packed=None, rays=None, codes=None):
     a = _lib.TrainArgs()
     if packed is not None:
-        a.blob, a.aux, a.blob_bwd = packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()
-        if rays is not None:      # forward: embeddings recomputed in registers from the un-embedded inputs
+        blob, aux, blob_bwd = packed
+        a.aux = aux.data_ptr()
+        if blob is not None:
+            a.blob = blob.data_ptr()
+        if blob_bwd is not None:
+            a.blob_bwd = blob_bwd.data_ptr()
+        if rays is not None and blob is not None and os.environ.get("OBJNERF_TRAIN_LAYERWISE") != "mem":
+            # forward: embeddings recomputed in registers from the un-embedded inputs ("mem": read them back instead)
             a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), ps.z.data_ptr(), rays.shape[0], ps.S
             if codes is not None:
                 a.codes, a.code_stride = codes.data_ptr(), codes.stride(0)

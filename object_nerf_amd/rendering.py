@@ -75,6 +75,19 @@ def _out_struct(o):
     return s
 
 
+def _train_packs(coarse, fine):
+    mode = os.environ.get("OBJNERF_TRAIN_LAYERWISE", "")
+    if mode == "1":
+        return None
+
+    def one(m):
+        if m is None:
+            return None
+        blob, aux = m.packed()
+        return (None if mode == "fwd" else blob, aux, None if mode == "bwd" else m.packed_bwd())
+    return (one(coarse), one(fine))
+
+
 def render_rays(
     models: Dict[str, Any],
     embeddings: Dict[str, Any],
@@ -144,10 +157,10 @@ def render_rays(
                     u_det=_linspace(I, dev) if I > 0 else None, grid=emb_xyz.grid_struct() if use_voxel else None,
                     ptm=pass_through_mask.reshape(n).to(torch.uint8).contiguous() if pass_through_mask is not None else None,
                     # packed weight streams (forward, aux, transposed hidden blocks): forward and the hidden dgrad chain run on
-                    # the persistent MFMA kernels; OBJNERF_TRAIN_LAYERWISE=1 keeps the layer-by-layer GEMM path instead
-                    packed=None if os.environ.get("OBJNERF_TRAIN_LAYERWISE") == "1" else
-                    (coarse.packed() + (coarse.packed_bwd(),),
-                     models["fine"].packed() + (models["fine"].packed_bwd(),) if I > 0 else None))
+                    # the persistent MFMA kernels.  OBJNERF_TRAIN_LAYERWISE = 1 | fwd | bwd keeps the layer-by-layer GEMM
+                    # version of both / the forward / the dgrad chain instead, "mem" makes the forward kernel read the
+                    # materialised embeddings back (same workspace layout in every mode; developer A/B switch)
+                    packed=_train_packs(coarse, models["fine"] if I > 0 else None))
         outs = RenderRaysFn.apply(meta, rays_c, embedding_instance, table, *plist)
         keys = sorted(["%s_%s" % (k, t) for t in (("coarse", "fine") if I > 0 else ("coarse",))
                        for k in (["weights", "opacity", "z_vals", "rgb", "depth"]

@@ -162,3 +162,122 @@ def test_training_step_updates_weights_and_repacks():
     r_tr = A.render_rays(sc.models, sc.embeddings, rays, N_samples=16, N_importance=16, perturb=0, noise_std=0,
                          embedding_instance=codes)
     assert H.normwise(r_inf["rgb_coarse"], r_tr["rgb_coarse"]) < 1e-4      # GEMM path == fused MFMA path
+
+
+def _stage_inputs(sc, use_voxel, n, S, seed=3):
+    """the dense per-point inputs of objnerf_mlp_train_forward for n rays x S depths (what autograd.py materialises)"""
+    l = _lib.lib()
+    st = _lib.stream_ptr()
+    rays = synth.camera_rays(60, n // 60).to(DEV).contiguous()
+    assert rays.shape[0] == n
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    z = (rays[:, 6:7] + (rays[:, 7:8] - rays[:, 6:7]) * torch.sort(torch.rand(n, S, device=DEV, generator=g), -1)[0]).contiguous()
+    P = n * S
+    xyz = torch.empty(P, 3, device=DEV)
+    _lib.check(l.objnerf_sample_points(_lib.ptr(rays), _lib.ptr(z), n, S, _lib.ptr(xyz), st), "sample_points")
+    grid = sc.embeddings["xyz"].grid_struct() if use_voxel else None
+    if use_voxel:
+        emb, ov = torch.empty(P, 271, device=DEV), torch.empty(P, 104, device=DEV)
+        _lib.check(l.objnerf_voxel_embed(C.byref(grid), _lib.ptr(xyz), P, _lib.ptr(emb), _lib.ptr(ov), st), "voxel_embed")
+    else:
+        emb, ov = torch.empty(P, 63, device=DEV), None
+        _lib.check(l.objnerf_pos_encode(_lib.ptr(xyz), P, 3, 10, _lib.ptr(emb), st), "pos_encode")
+    dirs = rays[:, 3:6].contiguous()
+    ed = torch.empty(n, 27, device=DEV)
+    _lib.check(l.objnerf_pos_encode(_lib.ptr(dirs), n, 3, 4, _lib.ptr(ed), st), "pos_encode")
+    codes = sc.code_library.embedding_instance.weight.detach()[synth.per_ray_ids(n).to(DEV)].contiguous()
+    return dict(rays=rays, z=z, P=P, emb=emb, ov=ov, emb_dir=ed.repeat_interleave(S, 0), codes=codes,
+                code_pts=codes.repeat_interleave(S, 0), grid=grid)
+
+
+@pytest.mark.parametrize("sname,fi", [("voxel", True), ("plain", True), ("voxel", False)])
+def test_training_kernels_against_layerwise_gemms(sname, fi):
+    """C ABI level, 1500 rays x 128 depths = 1500 tiles of 128 points on 256 workgroups (every workgroup loops over
+    several tiles; the 48-ray oracle comparisons never leave the first one):
+      forward   -- the persistent kernel in both input forms (embeddings recomputed in registers / read back) against the
+                   layer-by-layer GEMMs: outputs and EVERY saved activation matrix;
+      backward  -- on ONE set of saved activations, the fused dgrad chain against the GEMM chain: every parameter
+                   gradient and the gradients w.r.t. the inputs.
+    (End to end, gradients of two different forwards differ by ~5e-4: LeakyReLU masks of units whose pre-activation is
+    within roundoff of zero flip -- which is why the backward is compared on shared activations.)"""
+    use_voxel = sname == "voxel"
+    sc = cases.scene_for(A, sname, device=DEV)
+    n, S = 1500, 128
+    x = _stage_inputs(sc, use_voxel, n, S)
+    P = x["P"]
+    l = _lib.lib()
+    st = _lib.stream_ptr()
+    m = sc.models["coarse"]
+    params = [_lib.as_f32(p.detach()) for p in m._param_list()]
+    table = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+    blob, aux = m.packed()
+    blob_bwd = m.packed_bwd()
+    ws_floats = l.objnerf_train_workspace_floats(int(fi), P)
+
+    def forward(mode):
+        a = _lib.TrainArgs()
+        a.use_voxel, a.do_object, a.n_points, a.h_params = int(use_voxel), int(fi), P, table
+        a.emb_xyz, a.emb_dir = x["emb"].data_ptr(), x["emb_dir"].data_ptr()
+        out = {"sigma": torch.empty(P, device=DEV), "rgb": torch.empty(P, 3, device=DEV)}
+        a.sigma, a.rgb = out["sigma"].data_ptr(), out["rgb"].data_ptr()
+        if fi:
+            a.obj_code = x["code_pts"].data_ptr()
+            if use_voxel:
+                a.obj_voxel = x["ov"].data_ptr()
+            out.update(isig=torch.empty(P, device=DEV), irgb=torch.empty(P, 3, device=DEV))
+            a.inst_sigma, a.inst_rgb = out["isig"].data_ptr(), out["irgb"].data_ptr()
+        out["ws"] = torch.zeros(ws_floats, device=DEV)
+        a.workspace = out["ws"].data_ptr()
+        if mode != "layerwise":
+            a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
+        if mode == "fused":
+            a.rays, a.z_vals, a.n_rays, a.S = x["rays"].data_ptr(), x["z"].data_ptr(), n, S
+            if fi:
+                a.codes, a.code_stride = x["codes"].data_ptr(), 64
+            if use_voxel:
+                a.grid = x["grid"]
+        _lib.check(l.objnerf_mlp_train_forward(C.byref(a), st), "mlp_train_forward")
+        return a, out
+
+    a_l, o_l = forward("layerwise")
+    widths = [256] * 8 + [256, 128, 4] + ([128] * 4 + [128, 64, 4] if fi else [])
+    for mode in ("fused", "memory"):
+        _, o = forward(mode)
+        for k in ("sigma", "rgb") + (("isig", "irgb") if fi else ()):
+            assert H.normwise(o[k], o_l[k]) < 2e-5, (mode, k)
+        off = 0
+        for i, w in enumerate(widths):
+            if w != 4:                                   # the 4-float slots are scratch of the backward
+                blk_a, blk_b = o["ws"][off * P:(off + w) * P], o_l["ws"][off * P:(off + w) * P]
+                assert H.normwise(blk_a, blk_b) < 2e-5, (mode, "activation matrix %d" % i)
+            off += w
+        assert off * P == ws_floats
+
+    # backward on the layer-wise forward's activations: GEMM chain vs fused chain
+    g = torch.Generator(device=DEV).manual_seed(9)
+    d_sigma, d_rgb = torch.randn(P, device=DEV, generator=g), torch.randn(P, 3, device=DEV, generator=g)
+    d_isig, d_irgb = (torch.randn(P, device=DEV, generator=g), torch.randn(P, 3, device=DEV, generator=g)) if fi else (None, None)
+
+    def backward(fused):
+        a_l.aux = aux.data_ptr()
+        a_l.blob_bwd = blob_bwd.data_ptr() if fused else None
+        grads = [torch.zeros_like(p) for p in params]
+        gt = (C.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
+        d_emb = torch.empty_like(x["emb"])
+        d_ov = torch.empty_like(x["ov"]) if (fi and use_voxel) else None
+        d_code = torch.empty(P, 64, device=DEV) if fi else None
+        scratch = torch.zeros(l.objnerf_train_scratch_floats(P), device=DEV)
+        _lib.check(l.objnerf_mlp_train_backward(C.byref(a_l), _lib.ptr(d_sigma), _lib.ptr(d_rgb), _lib.ptr(d_isig), _lib.ptr(d_irgb),
+                                                gt, _lib.ptr(d_emb), _lib.ptr(d_ov), _lib.ptr(d_code), _lib.ptr(scratch), st),
+                   "mlp_train_backward")
+        return grads + [t for t in (d_emb, d_ov, d_code) if t is not None]
+
+    g_gemm, g_fused = backward(False), backward(True)
+    worst = 0.0
+    for i, (u, v) in enumerate(zip(g_fused, g_gemm)):
+        if v.abs().max().item() == 0:
+            assert u.abs().max().item() == 0, i
+            continue
+        worst = max(worst, rel_l2(u, v))
+    assert worst < 1e-5, worst
+    print(sname, fi, "fused dgrad chain vs GEMM chain: worst rel L2 %.2e" % worst)
