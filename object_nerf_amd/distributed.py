@@ -70,6 +70,21 @@ def render_rays_sharded(render_fn, rays: torch.Tensor, per_ray: Dict[str, torch.
     return {k: gather_pixels(res[k], n) for k in gather_keys if k in res}
 
 
+def render_rays_multi_sharded(render_fn, rays_list, gather_keys: Iterable[str] = ("rgb_fine", "depth_fine", "opacity_fine"),
+                              **kwargs):
+    """The same for `render_rays_multi` (BASELINE configs[4], the editing demo on N GPUs): every ray set of the list
+    describes the same pixels through a different object transform, so all sets are cut at the same row bounds and
+    each rank composites its band of pixels over all sets; one pixel all-gather per frame, as above."""
+    n = rays_list[0].shape[0]
+    if any(r.shape[0] != n for r in rays_list):
+        raise RuntimeError("render_rays_multi_sharded: every ray set must have the same number of rays")
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_bounds(n, rank, world)
+    res = render_fn(rays_list=[r[lo:hi] for r in rays_list], **kwargs)
+    return {k: gather_pixels(res[k], n) for k in gather_keys if k in res}
+
+
 class GradientSync:
     """Averages `.grad` of a fixed parameter list over the process group: the collective behind data-parallel
     training (what Lightning's DDP does for the reference, train.py:261-262).

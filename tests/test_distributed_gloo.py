@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from object_nerf_amd.distributed import GradientSync, gather_pixels, render_rays_sharded, shard_rays
+from object_nerf_amd.distributed import (GradientSync, gather_pixels, render_rays_multi_sharded, render_rays_sharded,
+                                         shard_rays)
 
 
 def _free_port():
@@ -42,6 +43,15 @@ def _worker(rank, world, port, n, q):
         r_loc, ex = shard_rays(rays, {"embedding_instance": codes, "flag": 1.5})
         ok = ok and ex["flag"] == 1.5 and ex["embedding_instance"].shape[0] == r_loc.shape[0]
         ok = ok and torch.equal(gather_pixels(r_loc[:, 0], n), rays[:, 0])
+        # multi-object compositor: all ray sets cut at the same bounds
+        sets = [rays, rays * 2.0 + 1.0, rays - 3.0]
+
+        def fake_multi(rays_list, obj_instance_ids, **kw):
+            acc = sum(r[:, :3] * float(i + 1) for i, r in zip(obj_instance_ids, rays_list))
+            return {"rgb_fine": acc, "depth_fine": rays_list[0][:, 6] + rays_list[-1][:, 7]}
+        want = fake_multi(sets, [0, 4, 2])
+        got = render_rays_multi_sharded(fake_multi, sets, obj_instance_ids=[0, 4, 2], gather_keys=("rgb_fine", "depth_fine"))
+        ok = ok and torch.equal(got["rgb_fine"], want["rgb_fine"]) and torch.equal(got["depth_fine"], want["depth_fine"])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
