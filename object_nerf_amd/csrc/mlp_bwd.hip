@@ -167,28 +167,25 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
         sign_bits<4, 4, 0>(raw, bd, sg);
         mask_tiles<4>(hd, bd, hd);
         // BL_SD: -> d(xyz_encoding_final output), no activation there
-        zero_tiles<8>(acc);
         {
           HidSrc<4> s{hd};
-          layer_mac<8, bwd_ks(BL_SD)>(acc, st, s, BwdHook<4, 8>{hd, dz.sdirh(), 128, nullptr, 0, raw, bits, sg});
+          layer_mac<8, bwd_ks(BL_SD), HidSrc<4>, BwdHook<4, 8>, true>(acc, st, s, {hd, dz.sdirh(), 128, nullptr, 0, raw, bits, sg});
         }
       }
       finish<8, false>(acc, h);
       // BL_SF: -> dA8, plus the density head's contribution, then layer 8's mask
-      zero_tiles<8>(acc);
       {
         HidSrc<8> s{h};
-        layer_mac<8, 128>(acc, st, s, BwdHook<8, 8>{h, dz.sfinal(), 256, act.A(8), 256, raw, bits, sg});
+        layer_mac<8, 128, HidSrc<8>, BwdHook<8, 8>, true>(acc, st, s, {h, dz.sfinal(), 256, act.A(8), 256, raw, bits, sg});
       }
       add_head<8>(acc, aux + kAuxSSig, half, a.d_sigma[p]);
       mask_tiles<8>(acc, bits, h);
       // BL_S8 .. BL_S2 (BL_S5 streams the hidden block of the skip layer): dZ_l -> dZ_{l-1}
 #pragma unroll 1
       for (int l = 8; l >= 2; --l) {
-        zero_tiles<8>(acc);
         {
           HidSrc<8> s{h};
-          layer_mac<8, 128>(acc, st, s, BwdHook<8, 8>{h, dz.A(l), 256, act.A(l - 1), 256, raw, bits, sg});
+          layer_mac<8, 128, HidSrc<8>, BwdHook<8, 8>, true>(acc, st, s, {h, dz.A(l), 256, act.A(l - 1), 256, raw, bits, sg});
         }
         mask_tiles<8>(acc, bits, h);
       }
@@ -212,26 +209,23 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
         for (int c = 0; c < 3; ++c) add_head<2>(hd, aux + kAuxORgb + c * 2 * 32, half, a.t2i[p * 3 + c]);
         sign_bits<2, 2, 0>(raw, bd, sg);
         mask_tiles<2>(hd, bd, hd);
-        zero_tiles<4>(acc);
         {
           HidSrc<2> s{hd};
-          layer_mac<4, bwd_ks(BL_OD)>(acc, st, s, BwdHook<2, 4>{hd, dz.odirh(), 64, nullptr, 0, raw, bits, sg});
+          layer_mac<4, bwd_ks(BL_OD), HidSrc<2>, BwdHook<2, 4>, true>(acc, st, s, {hd, dz.odirh(), 64, nullptr, 0, raw, bits, sg});
         }
       }
       finish<4, false>(acc, h);
-      zero_tiles<4>(acc);
       {
         HidSrc<4> s{h};
-        layer_mac<4, 64>(acc, st, s, BwdHook<4, 4>{h, dz.ofinal(), 128, act.B(4), 128, raw, bits, sg});
+        layer_mac<4, 64, HidSrc<4>, BwdHook<4, 4>, true>(acc, st, s, {h, dz.ofinal(), 128, act.B(4), 128, raw, bits, sg});
       }
       add_head<4>(acc, aux + kAuxOSig, half, a.d_isigma[p]);
       mask_tiles<4>(acc, bits, h);
 #pragma unroll 1
       for (int l = 4; l >= 2; --l) {
-        zero_tiles<4>(acc);
         {
           HidSrc<4> s{h};
-          layer_mac<4, 64>(acc, st, s, BwdHook<4, 4>{h, dz.B(l), 128, act.B(l - 1), 128, raw, bits, sg});
+          layer_mac<4, 64, HidSrc<4>, BwdHook<4, 4>, true>(acc, st, s, {h, dz.B(l), 128, act.B(l - 1), 128, raw, bits, sg});
         }
         mask_tiles<4>(acc, bits, h);
       }

@@ -195,7 +195,9 @@ __device__ __forceinline__ void load_group(ATiles<NT>& a, WeightStream& st) {
 struct NoHook {
   template <int C> __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {}
 };
-template <int NT, int KS, class Src, class Hook = NoHook>
+// ZERO: acc = W * B instead of acc += W * B (the first k-step's MFMA takes the constant 0 as its C operand; the
+// accumulators need no initialisation pass).
+template <int NT, int KS, class Src, class Hook = NoHook, bool ZERO = false>
 __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, Src& src, Hook after_barrier = Hook{}) {
   constexpr int NG4 = (KS + 3) / 4;
   constexpr int KG = kChunkTiles / NT;
@@ -227,8 +229,14 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, S
         const float b = src.template get<ks>();
 #endif
 #pragma unroll
-        for (int m = 0; m < NT; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[m][j], b, acc[m], 0, 0, 0);
+        for (int m = 0; m < NT; ++m) {
+          if constexpr (ZERO && ks == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[m][j], b, zero, 0, 0, 0);
+          } else {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[m][j], b, acc[m], 0, 0, 0);
+          }
+        }
 #if OBJ_EMB_PIPE
         // 1 MFMA, then up to OBJ_EMB_V VALU ops of the next operand's arithmetic, per out tile
 #pragma unroll
@@ -486,38 +494,7 @@ template <class S, int NH, int NT> struct HidThenDir {
 // restricted to the 12 channels of this lane half.  Operation order mirrors the reference:
 // s = (xyz + offset) / voxel_size (IEEE divide), q = floor(s), p = s - q, corner weights as the
 // products (a*b)*c, sum over the 8 corners in itertools.product([0,1],repeat=3) order.
-// ---------------------------------------------------------------------------------------------
-struct VoxelCell {
-  float w[8];
-  int row[8];     // table row or -1
-};
-__device__ __forceinline__ VoxelCell voxel_cell(const objnerf_voxel_grid& g, float x, float y, float z) {
-  VoxelCell c;
-  const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
-  const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
-  const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
-  const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
-  const float u = sx - qx, v = sy - qy, w = sz - qz;
-  const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
-  c.w[0] = (lu * lv) * lw; c.w[1] = (lu * lv) * w; c.w[2] = (lu * v) * lw; c.w[3] = (lu * v) * w;
-  c.w[4] = (u * lv) * lw;  c.w[5] = (u * lv) * w;  c.w[6] = (u * v) * lw;  c.w[7] = (u * v) * w;
-  const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
-    const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
-    int r = -1;
-    if (ok) {
-      const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
-      r = g.idx_map[((size_t)ix * g.shape[1] + iy) * g.shape[2] + iz];
-      if (r >= g.n_rows) r = -1;
-    }
-    c.row[k] = r;
-  }
-  return c;
-}
-
-// ---------------------------------------------------------------------------------------------
+//
 // per-tile gather prologue, in stages.  Run back to back it is the plain prologue; with OBJ_PREFETCH_TILE the
 // stages of the NEXT tile are placed between the object-branch layers of the current one, so that each level
 // of its dependent loads (ray row + depth -> 8 index-map reads -> 24 feature-row reads) has a whole layer of
