@@ -231,10 +231,13 @@ __global__ void __launch_bounds__(256) composite_kernel(const objnerf_composite_
 
 // ------------------------------------------------------------------------------------------
 // K4: sample_pdf (rendering.py:11-61) and the merge sort(cat([z, z_])) (rendering.py:313)
-// One wave per ray; cdf / bins tables live in LDS.
+// One wave per ray, four rays per workgroup; each wave owns a slice of the dynamic LDS (bins | cdf | merge buffer |
+// sorted new samples) and never synchronises with the other three (LDS operations of one wave execute in order).
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxBins = 1024;      // supports N_samples up to 1025
 constexpr int kMaxMerge = 2048;     // S + I
+
+__device__ __forceinline__ bool wave_all(bool p) { return __ballot(p) == ~0ull; }
 
 // builds cdf[0..nb) for weights w[0..nb-1) and draws `I` samples into out (lane-strided)
 __device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf_lds, const float* __restrict__ wts,
@@ -243,23 +246,25 @@ __device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf
   const int nw = nb - 1;
   // weights + eps, row sum  (rendering.py:30-31)
   float part = 0.f;
-  for (int i = lane; i < nw; i += 64) {
-    const float w = wts[i] + eps;
-    cdf_lds[i + 1] = w;
-    part += w;
-  }
+  for (int i = lane; i < nw; i += 64) part += wts[i] + eps;
   const float tot = wave_sum(part);
-  __syncthreads();
-  // cdf = cat([0, cumsum(pdf)]) in the reference's sequential order (rendering.py:32-33)
-  if (lane == 0) {
-    float c = 0.f;
-    cdf_lds[0] = 0.f;
-    for (int i = 0; i < nw; ++i) {
-      c = c + __fdiv_rn(cdf_lds[i + 1], tot);
-      cdf_lds[i + 1] = c;
+  // cdf = cat([0, cumsum(pdf)]) in the reference's SEQUENTIAL order (rendering.py:32-33).  Every lane runs the same
+  // chain of adds on wave-uniform operands (v_readlane of the pdf value of element i), so all lanes hold the running
+  // sum and lane i keeps it at step i: ~3 instructions per element and no memory round trip inside the chain.
+  float run = 0.f;
+  if (lane == 0) cdf_lds[0] = 0.f;
+  for (int base = 0; base < nw; base += 64) {
+    const int idx = base + lane;
+    const float pdf = idx < nw ? __fdiv_rn(wts[idx] + eps, tot) : 0.f;     // x + 0 = x: padding lanes do not disturb the chain
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      run = run + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pdf), i));
+      mine = lane == i ? run : mine;
     }
+    if (idx < nw) cdf_lds[idx + 1] = mine;
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   for (int j = lane; j < I; j += 64) {
     const float uj = u[j];
     // searchsorted(cdf, u, right=True): first index with cdf[idx] > u  (rendering.py:43)
@@ -278,55 +283,104 @@ __device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf
     if (out_lds) out_lds[j] = smp;
     if (out_glb) out_glb[j] = smp;
   }
+  __builtin_amdgcn_wave_barrier();
 }
 
-__global__ void __launch_bounds__(64) sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ weights,
-                                                        const float* __restrict__ u, long u_stride, long n_rays,
-                                                        int nb, int I, float eps, float* __restrict__ samples) {
-  __shared__ float bins_lds[kMaxBins];
-  __shared__ float cdf_lds[kMaxBins];
-  const int lane = threadIdx.x;
-  for (long ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+__global__ void __launch_bounds__(256) sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ weights,
+                                                         const float* __restrict__ u, long u_stride, long n_rays,
+                                                         int nb, int I, float eps, float* __restrict__ samples) {
+  extern __shared__ float pdf_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+  float* bins_lds = pdf_lds + wave * 2 * nb;
+  float* cdf_lds = bins_lds + nb;
+  for (long ray = (long)blockIdx.x * nwb + wave; ray < n_rays; ray += (long)gridDim.x * nwb) {
     for (int i = lane; i < nb; i += 64) bins_lds[i] = bins[ray * nb + i];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     sample_pdf_ray(bins_lds, cdf_lds, weights + ray * (nb - 1), nb, u + ray * u_stride, I, eps,
                    nullptr, samples + ray * I, lane);
-    __syncthreads();
   }
 }
 
+// number of elements of the ascending array a[0..n) that are < v (strict) or <= v
+__device__ __forceinline__ int count_below(const float* a, int n, float v, bool or_equal) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const bool take = or_equal ? a[mid] <= v : a[mid] < v;
+    if (take) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 // fine depths: z_mid bins from the coarse depths, weights[:,1:-1], then ascending merge
-__global__ void __launch_bounds__(64) sample_pdf_merge_kernel(const float* __restrict__ z_coarse,
-                                                              const float* __restrict__ weights,
-                                                              const float* __restrict__ u, long u_stride,
-                                                              long n_rays, int S, int I, float eps,
-                                                              float* __restrict__ z_samples, float* __restrict__ z_fine) {
-  __shared__ float bins_lds[kMaxBins];
-  __shared__ float cdf_lds[kMaxBins];
-  __shared__ float all_lds[kMaxMerge];   // [0,S) coarse z, [S,S+I) new samples
-  const int lane = threadIdx.x;
+__global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __restrict__ z_coarse,
+                                                               const float* __restrict__ weights,
+                                                               const float* __restrict__ u, long u_stride,
+                                                               long n_rays, int S, int I, float eps,
+                                                               float* __restrict__ z_samples, float* __restrict__ z_fine) {
+  extern __shared__ float pdf_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
   const int nb = S - 1;
   const int M = S + I;
-  for (long ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+  float* bins_lds = pdf_lds + wave * (2 * nb + M + I);
+  float* cdf_lds = bins_lds + nb;
+  float* all_lds = cdf_lds + nb;         // [0,S) coarse z, [S,S+I) new samples
+  float* sorted_new = all_lds + M;       // the new samples in ascending (stable) order, when they are not already
+  for (long ray = (long)blockIdx.x * nwb + wave; ray < n_rays; ray += (long)gridDim.x * nwb) {
     const float* z = z_coarse + ray * S;
-    for (int i = lane; i < S; i += 64) all_lds[i] = z[i];
-    // z_vals_mid = 0.5 * (z[:-1] + z[1:])   (rendering.py:302-304)
-    for (int i = lane; i < nb; i += 64) bins_lds[i] = 0.5f * (z[i] + z[i + 1]);
-    __syncthreads();
+    bool coarse_sorted = true;
+    for (int i = lane; i < S; i += 64) {
+      const float zi = z[i];
+      all_lds[i] = zi;
+      // z_vals_mid = 0.5 * (z[:-1] + z[1:])   (rendering.py:302-304)
+      if (i < nb) {
+        const float zn = z[i + 1];
+        bins_lds[i] = 0.5f * (zi + zn);
+        coarse_sorted = coarse_sorted && zn >= zi;
+      }
+    }
+    coarse_sorted = wave_all(coarse_sorted);
+    __builtin_amdgcn_wave_barrier();
     sample_pdf_ray(bins_lds, cdf_lds, weights + ray * S + 1, nb, u + ray * u_stride, I, eps,
                    all_lds + S, z_samples ? z_samples + ray * I : nullptr, lane);
-    __syncthreads();
-    // stable rank sort of the concatenation (== torch.sort(torch.cat([z, z_]))[0])
-    for (int i = lane; i < M; i += 64) {
-      const float v = all_lds[i];
-      int rank = 0;
-      for (int j = 0; j < M; ++j) {
-        const float o = all_lds[j];
-        rank += (o < v || (o == v && j < i)) ? 1 : 0;
+    float* out = z_fine + ray * M;
+    // z_fine = torch.sort(torch.cat([z, z_]))[0], ties in concatenation order (stable)
+    if (!coarse_sorted) {
+      // general case (far < near): rank of every element among all M
+      for (int i = lane; i < M; i += 64) {
+        const float v = all_lds[i];
+        int rank = 0;
+        for (int j = 0; j < M; ++j) {
+          const float o = all_lds[j];
+          rank += (o < v || (o == v && j < i)) ? 1 : 0;
+        }
+        out[rank] = v;
       }
-      z_fine[ray * M + rank] = v;
+    } else {
+      // Both runs ascending -> two binary searches per element.  The new samples are ascending whenever u is
+      // (deterministic sampling: the inverse cdf is monotone); random u: order them first by rank among themselves.
+      const float* nw_ = all_lds + S;
+      bool new_sorted = true;
+      for (int j = lane; j < I; j += 64) new_sorted = new_sorted && (j == 0 || nw_[j] >= nw_[j - 1]);
+      new_sorted = wave_all(new_sorted);
+      if (!new_sorted) {
+        for (int j = lane; j < I; j += 64) {
+          const float v = nw_[j];
+          int rank = 0;
+          for (int k = 0; k < I; ++k) {
+            const float o = nw_[k];
+            rank += (o < v || (o == v && k < j)) ? 1 : 0;
+          }
+          sorted_new[rank] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        nw_ = sorted_new;
+      }
+      // a coarse depth goes behind the new samples strictly below it; a new sample behind the coarse depths <= it
+      for (int i = lane; i < S; i += 64) out[i + count_below(nw_, I, all_lds[i], false)] = all_lds[i];
+      for (int r = lane; r < I; r += 64) out[r + count_below(all_lds, S, nw_[r], true)] = nw_[r];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -573,14 +627,22 @@ int objnerf_composite(const objnerf_composite_args* a, void* stream) {
   return check_launch("composite");
 }
 
+// K4 keeps one wave per ray; as many rays per workgroup (1, 2 or 4) as fit the default 64 KiB of dynamic LDS
+static inline int waves_per_block(size_t lds_per_wave) {
+  return lds_per_wave * 4 <= 48 * 1024 ? 4 : (lds_per_wave * 2 <= 48 * 1024 ? 2 : 1);
+}
+
 int objnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_stride, int64_t n_rays,
                        int nb, int I, float eps, float* samples, void* stream) {
   if (!bins || !weights || !u || !samples || nb < 2 || nb > kMaxBins || I < 1)
     return set_error(-1, "sample_pdf: bad arguments (2 <= bins <= 1024)");
   if (n_rays == 0) return 0;
-  unsigned grid = (unsigned)(n_rays < 65536 ? n_rays : 65536);
-  hipLaunchKernelGGL(sample_pdf_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, bins, weights, u,
-                     (long)u_stride, (long)n_rays, nb, I, eps, samples);
+  const size_t per_wave = (size_t)2 * nb * sizeof(float);
+  const int nwb = waves_per_block(per_wave);
+  const long blocks = (n_rays + nwb - 1) / nwb;
+  unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3(grid), dim3(64 * nwb), per_wave * nwb, (hipStream_t)stream, bins,
+                     weights, u, (long)u_stride, (long)n_rays, nb, I, eps, samples);
   return check_launch("sample_pdf");
 }
 
@@ -590,9 +652,12 @@ int objnerf_sample_pdf_merge(const float* z_coarse, const float* weights, const 
   if (!z_coarse || !weights || !u || !z_fine || S < 3 || S - 1 > kMaxBins || I < 1 || S + I > kMaxMerge)
     return set_error(-1, "sample_pdf_merge: bad arguments (3 <= S <= 1025, S + I <= 2048)");
   if (n_rays == 0) return 0;
-  unsigned grid = (unsigned)(n_rays < 65536 ? n_rays : 65536);
-  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, z_coarse, weights, u,
-                     (long)u_stride, (long)n_rays, S, I, eps, z_samples, z_fine);
+  const size_t per_wave = (size_t)(2 * (S - 1) + (S + I) + I) * sizeof(float);      // <= 6142 floats = 24 KiB
+  const int nwb = waves_per_block(per_wave);
+  const long blocks = (n_rays + nwb - 1) / nwb;
+  unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64 * nwb), per_wave * nwb, (hipStream_t)stream, z_coarse,
+                     weights, u, (long)u_stride, (long)n_rays, S, I, eps, z_samples, z_fine);
   return check_launch("sample_pdf_merge");
 }
 
