@@ -11,7 +11,6 @@ HIP path; `export_state_dict` writes the same key layout back.
 """
 from collections import OrderedDict
 
-import torch
 from torch import nn
 
 from .code_library import CodeLibrary

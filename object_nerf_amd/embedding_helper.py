@@ -14,7 +14,6 @@ Out of scope: progressive-training utilities (self_pruning_
 voxel_subdivision), the unused dense/ray-box helpers.
 """
 import ctypes as C
-import itertools
 
 import numpy as np
 import torch

@@ -22,7 +22,6 @@ vectors under tests/golden/; tests/test_oracle_vs_golden.py re-checks them on CP
 tests/test_oracle_vs_reference.py compares live whenever the mount is present).
 """
 import itertools
-import math
 
 import torch
 

@@ -11,7 +11,7 @@ import torch
 import cases
 import helpers as H
 import object_nerf_amd as A
-from object_nerf_amd import _lib, synth
+from object_nerf_amd import _lib
 from object_nerf_amd.distributed import shard_bounds
 from object_nerf_amd.nerf_model import PARAM_LAYERS
 

@@ -2,7 +2,6 @@
 """Throughput of the training path's fp32 MFMA GEMM (csrc/gemm.h) on the three products of a 256-wide Linear layer
 over one training batch's sample points (2048 rays x 192 = 393,216 points), against the 157.3 TFLOP/s fp32 MFMA peak.
 Usage: python tools/gemm_bench.py [lib tag ...]   ('ship' = libobjnerf_hip.so, else object_nerf_amd/tune/libobjnerf_<tag>.so)"""
-import ctypes as C
 import os
 import sys
 
