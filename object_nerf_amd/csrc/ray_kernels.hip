@@ -80,70 +80,61 @@ __global__ void pos_encode_kernel(const float* __restrict__ x, long n, int C, in
 }
 
 // ------------------------------------------------------------------------------------------
-// EmbeddingVoxel.forward (embedding_helper.py:325-411), one thread per point
+// EmbeddingVoxel.forward (embedding_helper.py:325-411).  32 lanes per point, lane = one input channel of the
+// positional encoding: 0..15 scene voxel features, 16..23 object voxel features, 24..26 x, y, z (27..31 idle).
+// A corner's 24 features are then one 96-byte read, and every (frequency, sin|cos) block of the output row is
+// written by neighbouring lanes; the per-channel arithmetic (corner order, sin/cos) is the same as a serial loop.
 // ------------------------------------------------------------------------------------------
-__global__ void voxel_embed_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz, long n,
-                                   float* __restrict__ scene_ftr, float* __restrict__ obj_ftr) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
-  const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
-  const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
-  const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
-  const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
-  const float u = sx - qx, v = sy - qy, w = sz - qz;
-  const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
-  float wt[8];
-  wt[0] = (lu * lv) * lw; wt[1] = (lu * lv) * w; wt[2] = (lu * v) * lw; wt[3] = (lu * v) * w;
-  wt[4] = (u * lv) * lw;  wt[5] = (u * lv) * w;  wt[6] = (u * v) * lw;  wt[7] = (u * v) * w;
-  float f[kVoxC];
-#pragma unroll
-  for (int i = 0; i < kVoxC; ++i) f[i] = 0.f;
-  const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
-  for (int k = 0; k < 8; ++k) {
-    const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
-    const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
-    int r = -1;
-    if (ok) {
-      r = g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz];
-      if (r >= g.n_rows) r = -1;
-    }
-    const float* t = g.table + (size_t)(r < 0 ? 0 : r) * kVoxC;
-#pragma unroll
-    for (int i = 0; i < kVoxC; ++i) {
-      const float fv = r < 0 ? 0.f : t[i];
-      f[i] = k == 0 ? fv * wt[k] : f[i] + fv * wt[k];
-    }
-  }
+__global__ void __launch_bounds__(256) voxel_embed_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz, long n,
+                                                          float* __restrict__ scene_ftr, float* __restrict__ obj_ftr) {
+  const int sub = threadIdx.x & 31;
+  const long p = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (p >= n || sub >= kVoxC + 3) return;
   float* so = scene_ftr + p * (long)(kScnVoxPE + kXyzPE);
-  float* oo = obj_ftr + p * (long)kObjVoxPE;
+  float val;       // the channel this lane encodes
+  float* o;        // its output block
+  int C, cc, F;    // channels in the block, index inside it, number of frequencies
+  if (sub >= kVoxC) {
+    val = xyz[p * 3 + (sub - kVoxC)];
+    o = so + kScnVoxPE; C = 3; cc = sub - kVoxC; F = kFreqXyz;
+  } else {
+    const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
+    const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
+    const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
+    const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
+    const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
+    const float u = sx - qx, v = sy - qy, w = sz - qz;
+    const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
+    float wt[8];
+    wt[0] = (lu * lv) * lw; wt[1] = (lu * lv) * w; wt[2] = (lu * v) * lw; wt[3] = (lu * v) * w;
+    wt[4] = (u * lv) * lw;  wt[5] = (u * lv) * w;  wt[6] = (u * v) * lw;  wt[7] = (u * v) * w;
+    const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
+    float f = 0.f;
 #pragma unroll
-  for (int c = 0; c < kVoxC; ++c) {
-    const bool scn = c < kScnVoxC;
-    float* o = scn ? so : oo;
-    const int C = scn ? kScnVoxC : kObjVoxC;
-    const int cc = scn ? c : c - kScnVoxC;
-    o[cc] = f[c];
-    float fr = 1.f;
-    for (int k = 0; k < kFreqVox; ++k) {
-      const SinCos sc = psincos<true>(fr * f[c]);
-      o[C * (1 + 2 * k) + cc] = sc.s;
-      o[C * (2 + 2 * k) + cc] = sc.c;
-      fr *= 2.f;
+    for (int k = 0; k < 8; ++k) {
+      const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
+      const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
+      int r = -1;
+      if (ok) {
+        r = g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz];
+        if (r >= g.n_rows) r = -1;
+      }
+      // voxel_ftr[invalid] = 0 ; (voxel_ftr * weights).sum(0)   (embedding_helper.py:351,387-389)
+      const float fv = r < 0 ? 0.f : g.table[(size_t)r * kVoxC + sub];
+      f = k == 0 ? fv * wt[k] : f + fv * wt[k];
     }
+    val = f;
+    F = kFreqVox;
+    if (sub < kScnVoxC) { o = so; C = kScnVoxC; cc = sub; }
+    else { o = obj_ftr + p * (long)kObjVoxPE; C = kObjVoxC; cc = sub - kScnVoxC; }
   }
-  const float pos[3] = {x, y, z};
-  float* xo = so + kScnVoxPE;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    xo[c] = pos[c];
-    float fr = 1.f;
-    for (int k = 0; k < kFreqXyz; ++k) {
-      const SinCos sc = psincos<true>(fr * pos[c]);
-      xo[3 * (1 + 2 * k) + c] = sc.s;
-      xo[3 * (2 + 2 * k) + c] = sc.c;
-      fr *= 2.f;
-    }
+  o[cc] = val;
+  float fr = 1.f;
+  for (int k = 0; k < F; ++k) {
+    const SinCos sc = psincos<true>(fr * val);
+    o[C * (1 + 2 * k) + cc] = sc.s;
+    o[C * (2 + 2 * k) + cc] = sc.c;
+    fr *= 2.f;
   }
 }
 
@@ -605,7 +596,7 @@ int objnerf_voxel_embed(const objnerf_voxel_grid* grid, const float* xyz, int64_
   if (!grid || !grid->idx_map || !grid->table || !xyz || !scene_ftr || !obj_ftr)
     return set_error(-1, "voxel_embed: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(voxel_embed_kernel, dim3(blocks_for(n, 128)), dim3(128), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(voxel_embed_kernel, dim3(blocks_for(n, 8)), dim3(256), 0, (hipStream_t)stream,
                      *grid, xyz, (long)n, scene_ftr, obj_ftr);
   return check_launch("voxel_embed");
 }

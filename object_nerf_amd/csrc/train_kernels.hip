@@ -157,91 +157,78 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
 // each row it touched to memory once; contributions that find no slot within 8 probes go to memory directly.
 constexpr int kVbSlots = 512;               // power of two
 constexpr int kVbStride = kVoxC + 1;        // odd stride: spreads the rows over the LDS banks
-__global__ void __launch_bounds__(128) voxel_embed_bwd_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz,
+constexpr int kVbPoints = 128;              // points per workgroup (the aggregation window)
+// 32 lanes per point, lane = voxel channel (0..15 scene, 16..23 object; 24..31 idle), 8 points per pass of a
+// 256-thread workgroup: a corner's features and every (frequency, sin|cos) block of the incoming gradient row are
+// contiguous across the lanes, and the 24 lanes of a point add to 24 different LDS words of its row's slot.
+__global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz,
                                                                long n, const float* __restrict__ d_scene,
                                                                const float* __restrict__ d_obj,
                                                                float* __restrict__ table_grad) {
   __shared__ int keys[kVbSlots];
   __shared__ float vals[kVbSlots * kVbStride];
-  for (int i = threadIdx.x; i < kVbSlots; i += 128) keys[i] = -1;
-  for (int i = threadIdx.x; i < kVbSlots * kVbStride; i += 128) vals[i] = 0.f;
+  for (int i = threadIdx.x; i < kVbSlots; i += 256) keys[i] = -1;
+  for (int i = threadIdx.x; i < kVbSlots * kVbStride; i += 256) vals[i] = 0.f;
   __syncthreads();
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) {
-  const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
-  const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
-  const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
-  const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
-  const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
-  const float u = sx - qx, v = sy - qy, w = sz - qz;
-  const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
-  float wt[8];
-  wt[0] = (lu * lv) * lw; wt[1] = (lu * lv) * w; wt[2] = (lu * v) * lw; wt[3] = (lu * v) * w;
-  wt[4] = (u * lv) * lw;  wt[5] = (u * lv) * w;  wt[6] = (u * v) * lw;  wt[7] = (u * v) * w;
-  int row[8];
-  const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
-  float f[kVoxC];
+  const int sub = threadIdx.x & 31;
+  const bool scn = sub < kScnVoxC;
+  const float* dbase = scn ? d_scene : d_obj;                       // object gradients may be absent (scene-only training)
+  const long dld = scn ? (kScnVoxPE + kXyzPE) : kObjVoxPE;
+  const int C = scn ? kScnVoxC : kObjVoxC;
+  const int cc = scn ? sub : sub - kScnVoxC;
+  for (int it = 0; it < kVbPoints / 8; ++it) {
+    const long p = (long)blockIdx.x * kVbPoints + it * 8 + (threadIdx.x >> 5);
+    if (p >= n || sub >= kVoxC || !dbase) continue;
+    const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
+    const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
+    const float sy = __fdiv_rn(y + g.offset[1], g.voxel_size);
+    const float sz = __fdiv_rn(z + g.offset[2], g.voxel_size);
+    const float qx = floorf(sx), qy = floorf(sy), qz = floorf(sz);
+    const float u = sx - qx, v = sy - qy, w = sz - qz;
+    const float lu = 1.f - u, lv = 1.f - v, lw = 1.f - w;
+    float wt[8];
+    wt[0] = (lu * lv) * lw; wt[1] = (lu * lv) * w; wt[2] = (lu * v) * lw; wt[3] = (lu * v) * w;
+    wt[4] = (u * lv) * lw;  wt[5] = (u * lv) * w;  wt[6] = (u * v) * lw;  wt[7] = (u * v) * w;
+    int row[8];
+    const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
+    float f = 0.f;                                                  // this channel's interpolated feature (forward value)
 #pragma unroll
-  for (int i = 0; i < kVoxC; ++i) f[i] = 0.f;
-  for (int k = 0; k < 8; ++k) {
-    const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
-    const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
-    int r = -1;
-    if (ok) {
-      r = g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz];
-      if (r >= g.n_rows) r = -1;
-    }
-    row[k] = r;
-    if (r >= 0) {
-      const float* t = g.table + (size_t)r * kVoxC;
-#pragma unroll
-      for (int i = 0; i < kVoxC; ++i) f[i] = f[i] + t[i] * wt[k];
-    }
-  }
-  const float* ds = d_scene + p * (long)(kScnVoxPE + kXyzPE);
-  const float* dobj = d_obj ? d_obj + p * (long)kObjVoxPE : nullptr;
-  float dF[kVoxC];
-#pragma unroll
-  for (int c = 0; c < kVoxC; ++c) {
-    const bool scn = c < kScnVoxC;
-    const float* d = scn ? ds : dobj;
-    const int C = scn ? kScnVoxC : kObjVoxC;
-    const int cc = scn ? c : c - kScnVoxC;
-    float acc = 0.f;
-    if (d) {
-      acc = d[cc];
-      float fr = 1.f;
-      for (int k = 0; k < kFreqVox; ++k) {
-        const SinCos sc = psincos<true>(fr * f[c]);
-        // d/df sin(fr f) = fr cos, d/df cos(fr f) = -fr sin
-        acc += fr * (d[C * (1 + 2 * k) + cc] * sc.c - d[C * (2 + 2 * k) + cc] * sc.s);
-        fr *= 2.f;
+    for (int k = 0; k < 8; ++k) {
+      const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
+      const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
+      int r = -1;
+      if (ok) {
+        r = g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz];
+        if (r >= g.n_rows) r = -1;
       }
+      row[k] = r;
+      if (r >= 0) f = f + g.table[(size_t)r * kVoxC + sub] * wt[k];
     }
-    dF[c] = acc;
-  }
-  for (int k = 0; k < 8; ++k) {
-    if (row[k] < 0) continue;                       // invalid corners were zeroed in the forward pass
-    unsigned h = ((unsigned)row[k] * 2654435761u) >> 23;       // 9 bits
-    int slot = -1;
-    for (int probe = 0; probe < 8; ++probe) {
-      const int prev = atomicCAS(&keys[h], -1, row[k]);
-      if (prev == -1 || prev == row[k]) { slot = (int)h; break; }
-      h = (h + 1) & (kVbSlots - 1);
+    // d/df [f, sin(2^k f), cos(2^k f)]: 1, 2^k cos, -2^k sin
+    const float* d = dbase + p * dld;
+    float dF = d[cc];
+    float fr = 1.f;
+    for (int k = 0; k < kFreqVox; ++k) {
+      const SinCos sc = psincos<true>(fr * f);
+      dF += fr * (d[C * (1 + 2 * k) + cc] * sc.c - d[C * (2 + 2 * k) + cc] * sc.s);
+      fr *= 2.f;
     }
-    if (slot >= 0) {
-      float* t = vals + slot * kVbStride;
 #pragma unroll
-      for (int c = 0; c < kVoxC; ++c) atomicAdd(t + c, dF[c] * wt[k]);
-    } else {
-      float* t = table_grad + (size_t)row[k] * kVoxC;
-#pragma unroll
-      for (int c = 0; c < kVoxC; ++c) atomicAdd(t + c, dF[c] * wt[k]);
+    for (int k = 0; k < 8; ++k) {
+      if (row[k] < 0) continue;                       // invalid corners were zeroed in the forward pass
+      unsigned h = ((unsigned)row[k] * 2654435761u) >> 23;       // 9 bits
+      int slot = -1;
+      for (int probe = 0; probe < 8; ++probe) {
+        const int prev = atomicCAS(&keys[h], -1, row[k]);
+        if (prev == -1 || prev == row[k]) { slot = (int)h; break; }
+        h = (h + 1) & (kVbSlots - 1);
+      }
+      float* t = slot >= 0 ? vals + slot * kVbStride : table_grad + (size_t)row[k] * kVoxC;   // no free slot: to memory
+      atomicAdd(t + sub, dF * wt[k]);
     }
-  }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kVbSlots * kVoxC; i += 128) {
+  for (int i = threadIdx.x; i < kVbSlots * kVoxC; i += 256) {
     const int slot = i / kVoxC, c = i - slot * kVoxC;
     const int r = keys[slot];
     if (r < 0) continue;
@@ -306,7 +293,7 @@ int objnerf_voxel_embed_backward(const objnerf_voxel_grid* grid, const float* xy
   if (!grid || !grid->idx_map || !grid->table || !xyz || !d_scene_ftr || !table_grad)
     return set_error(-1, "voxel_embed_backward: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(voxel_embed_bwd_kernel, dim3(blk(n, 128)), dim3(128), 0, (hipStream_t)stream, *grid, xyz, (long)n,
+  hipLaunchKernelGGL(voxel_embed_bwd_kernel, dim3(blk(n, kVbPoints)), dim3(256), 0, (hipStream_t)stream, *grid, xyz, (long)n,
                      d_scene_ftr, d_obj_ftr, table_grad);
   return check_launch("voxel_embed_backward");
 }
