@@ -311,7 +311,9 @@ int64_t objnerf_train_scratch_floats(int64_t n_points);
 int objnerf_mlp_train_forward(const objnerf_train_args* args, void* stream);
 /* Backward of the call above (same args, outputs and workspace untouched in between).
  * d_*: gradients w.r.t. sigma (P), rgb (P,3), inst_sigma, inst_rgb.  h_param_grads: HOST array of DEVICE
- * pointers, one per parameter tensor, ACCUMULATED into (+=).  d_emb_xyz (P,in_xyz), d_obj_voxel (P,104),
+ * pointers, one per parameter tensor, ACCUMULATED into (+=).  d_emb_xyz (P,in_xyz; only the 208 voxel-feature columns
+ * are written -- the xyz positional-encoding columns have no consumer, depths are detached -- and nothing in plain-PE
+ * mode), d_obj_voxel (P,104),
  * d_obj_code (P,64) are overwritten.  scratch: objnerf_train_scratch_floats() floats (holds the gradient w.r.t. every
  * layer's pre-activation output, in the layout of the activation workspace). */
 int objnerf_mlp_train_backward(const objnerf_train_args* args, const float* d_sigma, const float* d_rgb,

@@ -211,6 +211,9 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   const Ws w{P, a->workspace, obj};       // saved activations
   const Ws d{P, scratch, obj};            // gradients w.r.t. the pre-activation outputs, same layout
   const float* X = a->emb_xyz;
+  // d_emb_xyz: only the voxel-feature columns have a consumer (the table scatter); the xyz positional-encoding
+  // columns would be the gradient w.r.t. the sample positions, which the reference detaches (rendering.py:307)
+  const int ce = vox ? kScnVoxPE : 0;
   float* t2 = d.rgb();                    // (P,3) gradient w.r.t. the rgb heads' pre-sigmoid outputs
   float* t2i = d.irgb();
 
@@ -255,10 +258,10 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     if (l == 5) {          // cat([input_xyz, h])
       lin_wgrad(c, d.A(5), 256, X, cx, P, 256, cx, gW(P_S5), cx + 256, db);
       lin_wgrad(c, d.A(5), 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
-      lin_dgrad(c, d.A(5), 256, Wt(P_S5), cx + 256, P, 256, cx, d_emb_xyz, cx, 0);
+      if (ce) lin_dgrad(c, d.A(5), 256, Wt(P_S5), cx + 256, P, 256, ce, d_emb_xyz, cx, 0);
     } else if (l == 1) {
       lin_wgrad(c, d.A(1), 256, X, cx, P, 256, cx, gW(P_S1), cx, db);
-      lin_dgrad(c, d.A(1), 256, Wt(P_S1), cx, P, 256, cx, d_emb_xyz, cx, 1);          // layer 5 wrote it first
+      if (ce) lin_dgrad(c, d.A(1), 256, Wt(P_S1), cx, P, 256, ce, d_emb_xyz, cx, 1);   // layer 5 wrote it first
     } else {
       lin_wgrad(c, d.A(l), 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256, db);
     }
@@ -276,7 +279,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
       lin_wgrad(c, dY, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
       if (vox) lin_wgrad(c, dY, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
       lin_wgrad(c, dY, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
-      lin_dgrad(c, dY, 128, Wt(wid), ldw, P, 128, cx, d_emb_xyz, cx, 1);             // the scene branch wrote it first
+      if (ce) lin_dgrad(c, dY, 128, Wt(wid), ldw, P, 128, ce, d_emb_xyz, cx, 1);      // the scene branch wrote it first
       if (vox) lin_dgrad(c, dY, 128, Wt(wid) + cx, ldw, P, 128, kObjVoxPE, d_obj_voxel, kObjVoxPE, ov_written ? 1 : 0);
       lin_dgrad(c, dY, 128, Wt(wid) + cx + ov, ldw, P, 128, kCodeC, d_obj_code, kCodeC, ov_written ? 1 : 0);
       ov_written = true;

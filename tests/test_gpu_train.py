@@ -263,7 +263,7 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
         a_l.blob_bwd = blob_bwd.data_ptr() if fused else None
         grads = [torch.zeros_like(p) for p in params]
         gt = (C.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
-        d_emb = torch.empty_like(x["emb"])
+        d_emb = torch.zeros_like(x["emb"])        # only the voxel-feature columns are written
         d_ov = torch.empty_like(x["ov"]) if (fi and use_voxel) else None
         d_code = torch.empty(P, 64, device=DEV) if fi else None
         scratch = torch.zeros(l.objnerf_train_scratch_floats(P), device=DEV)
