@@ -70,10 +70,11 @@ def main(W=640, H=480):
                                      perturb=0, noise_std=0, background_skip_bbox={4: box}), sets
         t, (r, sets) = timed(frame)
         hit = [(s[:, 7] > 0).float().mean().item() for s in sets]
-        ev = n * 192 * 3
-        flop = n * 192 * (1399808 + 2 * 376320)
-        print("config5 render_rays_multi [0,4,4] 64+64 (+ device ray generation): %.1f ms/frame, %.2f M ray-samples/s (one branch "
-              "each), %.1f TFLOP/s; box hit fraction %s; mean rgb %.4f"
+        # evaluated sample points: rays that missed their object's box are compacted away before the MLP kernel
+        ev = n * 192 * sum(hit)
+        flop = n * 192 * (1399808 * hit[0] + 376320 * (hit[1] + hit[2]))
+        print("config5 render_rays_multi [0,4,4] 64+64 (+ device ray generation): %.1f ms/frame, %.2f M evaluated ray-samples/s (one "
+              "branch each), %.1f TFLOP/s; box hit fraction %s; mean rgb %.4f"
               % (t * 1e3, ev / t / 1e6, flop / t / 1e12, ["%.2f" % h for h in hit], r["rgb_fine"].mean().item()))
 
 
