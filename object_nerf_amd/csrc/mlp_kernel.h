@@ -45,6 +45,9 @@
 #ifndef OBJ_PREFETCH_TILE
 #define OBJ_PREFETCH_TILE 1  // gather prologue of the NEXT tile staged between the object-branch layers
 #endif
+#ifndef OBJ_XCD_TILES
+#define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers)
+#endif
 #ifndef OBJ_NT_ACT
 #define OBJ_NT_ACT 1         // training kernels: activation stores / fetches carry the non-temporal hint
 #endif
@@ -702,26 +705,40 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   constexpr int NE = ks_emb(VOXEL);
   constexpr int NO = ks_objin(VOXEL);
 
+  // Tile -> workgroup map.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with
+  // its own 4 MB L2.  Every XCD gets ONE contiguous eighth of the tiles and its 32 workgroups walk it side by side, so
+  // the voxel-table rows shared by neighbouring depths / neighbouring pixels are fetched into one L2 instead of eight
+  // (with the plain "tile = b + k * grid" map consecutive tiles land on 8 different XCDs).
+#if OBJ_XCD_TILES
+  const bool by_xcd = (gridDim.x & 7) == 0;
+#else
+  const bool by_xcd = false;
+#endif
+  const long tiles_per_xcd = (ntiles + 7) / 8;
+  const long tile_first = by_xcd ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const long tile_step = by_xcd ? (gridDim.x >> 3) : gridDim.x;
+  const long tile_end = by_xcd ? (((blockIdx.x & 7) + 1) * tiles_per_xcd < ntiles ? ((blockIdx.x & 7) + 1) * tiles_per_xcd : ntiles)
+                               : ntiles;
   constexpr bool PREFETCH = OBJ_PREFETCH_TILE && FUSED && DO_OBJ;
   TilePrologue<VOXEL> pre;
   if constexpr (FUSED) {
 #ifdef OBJ_ABL_PROLOGUE     // timing ablation only: no voxel gather
-    pre.stage_a(a, blockIdx.x, P, wave, lane);
+    pre.stage_a(a, tile_first, P, wave, lane);
     pre.stage_b(a.grid);
 #pragma unroll
     for (int i = 0; i < 12; ++i) pre.vf[i] = pre.pos[i % 3];
 #else
-    pre.run_all(a, blockIdx.x, P, wave, lane, half);
+    pre.run_all(a, tile_first, P, wave, lane, half);
 #endif
   }
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (long tile = tile_first; tile < tile_end; tile += tile_step) {
     long p;
     bool valid;
     Src src;
     src.half = half;
     if constexpr (FUSED) {
       if constexpr (!PREFETCH) {
-        if (tile != (long)blockIdx.x) {
+        if (tile != tile_first) {
 #ifdef OBJ_ABL_PROLOGUE
           pre.stage_a(a, tile, P, wave, lane);
           pre.stage_b(a.grid);
@@ -751,7 +768,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
     const Stage stg{(float*)(ring_mem + kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)) + wave * kStageFloats,
                    tile * 128 + wave * 32, P, lane};
     // tile whose prologue is staged during this pass (the last pass re-stages its own tile: harmless)
-    const long tile_next = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+    const long tile_next = tile + tile_step < tile_end ? tile + tile_step : tile;
 
     if constexpr (DO_SCENE) {
       f32x16 acc[8], h[8];
