@@ -48,6 +48,9 @@
 #ifndef OBJ_XCD_TILES
 #define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers)
 #endif
+#ifndef OBJ_NT_OUT
+#define OBJ_NT_OUT 1         // sigma / rgb output stores carry the non-temporal hint
+#endif
 #ifndef OBJ_NT_ACT
 #define OBJ_NT_ACT 1         // training kernels: activation stores / fetches carry the non-temporal hint
 #endif
@@ -666,6 +669,16 @@ struct SaveWs {
   __device__ __forceinline__ float* odirh() const { return ofinal() + 128L * P; }
 };
 
+// sigma / rgb results: written once, read by the compositing kernel after this one has finished -- non-temporal, so
+// that 1.9 GB per frame of outputs do not push the weight stream and the voxel rows out of the XCD's L2
+__device__ __forceinline__ void out_store(float* p, float v) {
+#if OBJ_NT_OUT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
@@ -801,7 +814,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       // sigma head (no activation, nerf_model.py:108)
       const float sg = head_dot<8>(h, aux + kAuxSSig, half) + aux[kAuxSSig + 8 * 32];
       if constexpr (SIGMA_ONLY) {
-        if (valid && half == 0) a.sigma[p] = sg;
+        if (valid && half == 0) out_store(a.sigma + p, sg);
       } else {
       // xyz_encoding_final (no activation)
       load_bias<8>(acc, aux, L_SF, half);
@@ -819,8 +832,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       for (int c = 0; c < 3; ++c)
         col[c] = sigmoidf(head_dot<4>(hd, aux + kAuxSRgb + c * 4 * 32, half) + aux[kAuxSRgb + 3 * 4 * 32 + c]);
       if (valid && half == 0) {
-        a.sigma[p] = sg;
-        if (a.rgb) { a.rgb[p * 3 + 0] = col[0]; a.rgb[p * 3 + 1] = col[1]; a.rgb[p * 3 + 2] = col[2]; }
+        out_store(a.sigma + p, sg);
+        if (a.rgb) { out_store(a.rgb + p * 3 + 0, col[0]); out_store(a.rgb + p * 3 + 1, col[1]); out_store(a.rgb + p * 3 + 2, col[2]); }
       }
       }
     }
@@ -850,7 +863,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       const float sg = head_dot<4>(h, aux + kAuxOSig, half) + aux[kAuxOSig + 4 * 32];
       if constexpr (PREFETCH) pre.template stage_acc<1>();
       if constexpr (SIGMA_ONLY) {
-        if (valid && half == 0) a.inst_sigma[p] = sg;
+        if (valid && half == 0) out_store(a.inst_sigma + p, sg);
       } else {
       load_bias<4>(acc, aux, L_OF, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(4))); }
@@ -866,8 +879,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       for (int c = 0; c < 3; ++c)
         col[c] = sigmoidf(head_dot<2>(hd, aux + kAuxORgb + c * 2 * 32, half) + aux[kAuxORgb + 3 * 2 * 32 + c]);
       if (valid && half == 0) {
-        a.inst_sigma[p] = sg;
-        if (a.inst_rgb) { a.inst_rgb[p * 3 + 0] = col[0]; a.inst_rgb[p * 3 + 1] = col[1]; a.inst_rgb[p * 3 + 2] = col[2]; }
+        out_store(a.inst_sigma + p, sg);
+        if (a.inst_rgb) { out_store(a.inst_rgb + p * 3 + 0, col[0]); out_store(a.inst_rgb + p * 3 + 1, col[1]); out_store(a.inst_rgb + p * 3 + 2, col[2]); }
       }
       }
     }
