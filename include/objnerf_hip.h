@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 2
+#define OBJNERF_ABI_VERSION 3
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -56,6 +56,15 @@ int objnerf_pack_index(int use_voxel, uint32_t* h_blob_idx, uint32_t* h_aux_idx)
  * h_param_ptrs: HOST array of objnerf_num_param_ptrs() DEVICE pointers. */
 int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx,
                          const float* const* h_param_ptrs, float* blob, float* aux, void* stream);
+
+/* Optional arithmetic mode of the fused form (objnerf_mlp_args.mfma_bf16x3): the same fp32 contraction carried out on
+ * the bf16 matrix pipe with every operand split exactly into three bf16 pieces and 6 of the 9 cross products (dropped
+ * terms <= 2^-23 relative), fp32 accumulation.  Needs its own packing of the weights (aux is shared):
+ * idx has objnerf_blob_floats() entries, the blob objnerf_b3_blob_bytes() bytes. */
+int64_t objnerf_b3_blob_bytes(int use_voxel);
+int objnerf_pack_index_b3(int use_voxel, uint32_t* h_blob_idx);
+int objnerf_pack_weights_b3(int use_voxel, const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob,
+                            void* stream);
 
 /* Training only: the transposed weight stream of the hidden-to-hidden blocks, consumed by the fused backward of the
  * hidden chain (objnerf_train_args.blob_bwd).  Same tile/chunk format as the forward stream with rows = input
@@ -121,6 +130,8 @@ typedef struct {
    * 142-143 `sigma_only=True`, used by tools/extract_mesh.py:85-108): the final / direction / rgb
    * layers are skipped (scene branch: 597,760 instead of 699,904 MAC per point) */
   int32_t sigma_only;
+  /* fused form only: `blob` is an objnerf_pack_weights_b3() stream and the MLP runs in the split-bf16 mode above */
+  int32_t mfma_bf16x3;
 } objnerf_mlp_args;
 int objnerf_mlp_eval(const objnerf_mlp_args* args, void* stream);
 
@@ -232,6 +243,7 @@ typedef struct {
   int32_t use_zero_as_last_delta;
   float frustum_bound_th;
   int32_t rays_in_bbox;
+  int32_t mfma_bf16x3;       /* blob_coarse / blob_fine are objnerf_pack_weights_b3() streams (see objnerf_mlp_args) */
 } objnerf_render_cfg;
 
 typedef struct {

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 2     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 3     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -43,7 +43,7 @@ class MlpArgs(C.Structure):
         ("emb_xyz", C.c_void_p), ("emb_dir", C.c_void_p), ("obj_voxel", C.c_void_p), ("obj_code", C.c_void_p),
         ("n_points", C.c_int64),
         ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
-        ("sigma_only", C.c_int32),
+        ("sigma_only", C.c_int32), ("mfma_bf16x3", C.c_int32),
     ]
 
 
@@ -90,7 +90,7 @@ class RenderCfg(C.Structure):
         ("use_voxel", C.c_int32), ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("use_disp", C.c_int32),
         ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32),
         ("forward_instance", C.c_int32), ("is_eval", C.c_int32), ("use_zero_as_last_delta", C.c_int32),
-        ("frustum_bound_th", C.c_float), ("rays_in_bbox", C.c_int32),
+        ("frustum_bound_th", C.c_float), ("rays_in_bbox", C.c_int32), ("mfma_bf16x3", C.c_int32),
     ]
 
 
@@ -125,6 +125,9 @@ SIGNATURES = {
     "objnerf_param_numel": (C.c_int64, [C.c_int, C.c_int]),
     "objnerf_pack_index": (C.c_int, [C.c_int, _VP, _VP]),
     "objnerf_pack_weights": (C.c_int, [C.c_int, _VP, _VP, C.POINTER(_VP), _VP, _VP, _VP]),
+    "objnerf_b3_blob_bytes": (C.c_int64, [C.c_int]),
+    "objnerf_pack_index_b3": (C.c_int, [C.c_int, _VP]),
+    "objnerf_pack_weights_b3": (C.c_int, [C.c_int, _VP, C.POINTER(_VP), _VP, _VP]),
     "objnerf_bwd_blob_floats": (C.c_int64, []),
     "objnerf_pack_index_bwd": (C.c_int, [C.c_int, _VP]),
     "objnerf_pack_weights_bwd": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),

@@ -129,6 +129,39 @@ int objnerf_pack_index(int use_voxel, uint32_t* blob_idx, uint32_t* aux_idx) {
   return 0;
 }
 
+int64_t objnerf_b3_blob_bytes(int use_voxel) { return (int64_t)total_chunks(use_voxel != 0) * kB3ChunkBytes; }
+
+// one entry per weight position, in the element order of plane 0:
+//   e = chunk * 8192 + ((s_local * nt + m) * 64 + lane) * 8 + j      (16 sub-tiles (s, m) per chunk for every nt)
+int objnerf_pack_index_b3(int use_voxel, uint32_t* blob_idx) {
+  if (!blob_idx) return set_error(-1, "pack_index_b3: null output");
+  const bool vox = use_voxel != 0;
+  const long n = objnerf_blob_floats(use_voxel);
+  for (long i = 0; i < n; ++i) blob_idx[i] = kPackZero;
+  for (int l = 0; l < L_COUNT; ++l) {
+    const int nt = layer_nt(l), spc = b3_steps_per_chunk(nt), ks_n = layer_ks(vox, l), ns = b3_steps(vox, l);
+    if ((ns + spc - 1) / spc != layer_chunks(vox, l)) return set_error(-3, "pack_index_b3: chunk count self-check failed");
+    const int p = layer_param(l);
+    const ParamShape sh = param_shape(vox, p);
+    const long base = (long)layer_chunk_start(vox, l) * kChunkFloats;
+    for (int s = 0; s < ns; ++s) {
+      const int chunk = s / spc, sl = s % spc;
+      for (int m = 0; m < nt; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int ks = 8 * s + j;
+            if (ks >= ks_n) continue;                                 // zero padding up to a whole s-step
+            const int row = 32 * m + (lane & 31);
+            const int col = layer_kcol(vox, l, ks, lane >> 5);
+            if (row >= sh.out || col < 0) continue;
+            if (col >= sh.in) return set_error(-3, "pack_index_b3: column out of range");
+            blob_idx[base + (long)chunk * kChunkFloats + ((long)(sl * nt + m) * 64 + lane) * 8 + j] = enc(2 * p, (long)row * sh.in + col);
+          }
+    }
+  }
+  return 0;
+}
+
 int64_t objnerf_bwd_blob_floats(void) { return (int64_t)bwd_total_chunks() * kChunkFloats; }
 
 int objnerf_pack_index_bwd(int use_voxel, uint32_t* blob_idx) {
@@ -239,7 +272,7 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
   objnerf_mlp_args m;
   memset(&m, 0, sizeof(m));
   m.use_voxel = cfg->use_voxel; m.do_scene = 1; m.do_object = cfg->forward_instance;
-  m.blob = blob; m.aux = aux;
+  m.blob = blob; m.aux = aux; m.mfma_bf16x3 = cfg->mfma_bf16x3;
   m.rays = in->rays; m.z_vals = out->z_vals; m.n_rays = N; m.S = S;
   m.codes = in->codes; m.code_stride = in->code_stride; m.grid = in->grid;
   m.sigma = sigma; m.rgb = rgb;

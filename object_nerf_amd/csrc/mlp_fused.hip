@@ -6,7 +6,10 @@ namespace objnerf {
 
 template <bool VOXEL, bool SC, bool OB>
 static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+  if (a.mfma_bf16x3)      // split-bf16 arithmetic on the bf16 matrix pipe (a.blob is an objnerf_pack_weights_b3 stream)
+    hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB, false, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+  else
+    hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
 }
 #ifndef OBJ_TUNE_ONLY_MAIN
 // training forward: scene (+ object) branch, every layer's activations also written to save_ws
@@ -22,6 +25,7 @@ int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipS
   if (save_ws) return set_error(-9, "tuning build: training kernels are not compiled");
 #else
   if (save_ws) {
+    if (a.mfma_bf16x3) return set_error(-1, "mlp_eval(fused, training): the split-bf16 mode is inference only");
     if (!sc) return set_error(-1, "mlp_eval(fused, training): the scene branch is always evaluated");
     if (a.use_voxel) { if (ob) launch_save<true, true>(a, ntiles, grid, s, save_ws); else launch_save<true, false>(a, ntiles, grid, s, save_ws); }
     else { if (ob) launch_save<false, true>(a, ntiles, grid, s, save_ws); else launch_save<false, false>(a, ntiles, grid, s, save_ws); }

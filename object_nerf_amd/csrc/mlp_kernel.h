@@ -48,6 +48,12 @@
 #ifndef OBJ_XCD_TILES
 #define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers)
 #endif
+#ifndef OBJ_B3_SPREAD_DMA
+#define OBJ_B3_SPREAD_DMA 1  // split-bf16 mode: weight DMA pieces issued between the MFMA groups instead of as a burst
+#endif
+#ifndef OBJ_B3_PAIR
+#define OBJ_B3_PAIR 1        // split-bf16 mode: two out tiles' products interleaved (no back-to-back dependent MFMAs)
+#endif
 #ifndef OBJ_NT_OUT
 #define OBJ_NT_OUT 1         // sigma / rgb output stores carry the non-temporal hint
 #endif
@@ -86,12 +92,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 constexpr int kRingSlots = OBJ_RING_SLOTS;
 
-struct WeightStream {
+template <int CB>
+struct WeightStreamT {
+  static constexpr int kBytes = CB;   // bytes per chunk
   const char* win;     // global base of the stream window (first chunk of this mode)
   int nchunks;         // chunks in the window (wraps around: every pass replays it)
   int next;            // window index of the next chunk to DMA
   int cur;             // ring slot holding the chunk being consumed
-  lds_char* ring;      // 2 * kChunkBytes
+  lds_char* ring;      // 2 * CB
   lds_char* rd;        // per-lane read base of the current slot (ring + cur*chunk + lane*16)
   int tid;
 #if OBJ_DMA_BUFFER
@@ -99,7 +107,7 @@ struct WeightStream {
   int wave;            // wave-uniform (readfirstlane)
 #endif
 
-  // One chunk = kChunkBytes, copied linearly global -> LDS by the 4 waves.
+  // One chunk = CB, copied linearly global -> LDS by the 4 waves.
   // OBJ_DMA_BUFFER: wave w owns the contiguous quarter [w*Q, (w+1)*Q) and moves it as Q/1024
   // buffer_load_dwordx4...lds: descriptor and chunk offset live in SGPRs, the piece offset in the
   // 12-bit immediate (applied to the global AND the LDS address), M0 (LDS base) changes once per
@@ -118,17 +126,17 @@ struct WeightStream {
     int n = next;
     asm volatile("" : "+s"(n));
 #if OBJ_DMA_BUFFER
-    constexpr int Q = kChunkBytes / 4;
-    lds_char* dst = ring + slot * kChunkBytes + wave * Q;
-    const int soff = n * kChunkBytes + wave * Q;
+    constexpr int Q = CB / 4;
+    lds_char* dst = ring + slot * CB + wave * Q;
+    const int soff = n * CB + wave * Q;
     const int voff = (tid & 63) * 16;
     static_for<Q / 1024>([&](auto I) __attribute__((always_inline)) { piece<decltype(I)::value>(dst, voff, soff); });
 #else
-    const char* src = win + (size_t)n * kChunkBytes + tid * 16;
+    const char* src = win + (size_t)n * CB + tid * 16;
     // wave-uniform LDS base; the DMA adds lane*16 itself
-    lds_char* dst = ring + slot * kChunkBytes + (tid >> 6) * 1024;
+    lds_char* dst = ring + slot * CB + (tid >> 6) * 1024;
 #pragma unroll
-    for (int i = 0; i < kChunkBytes / 4096; ++i) {
+    for (int i = 0; i < CB / 4096; ++i) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(src + i * 4096),
           (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
@@ -136,10 +144,28 @@ struct WeightStream {
 #endif
     next = (next + 1 == nchunks) ? 0 : next + 1;
   }
+  // Spread mode (split-bf16 stream): next_chunk() only selects the chunk; its kPieces DMA instructions are then issued
+  // one at a time between the MFMA groups of the chunk being consumed (layer_mac_b3).  Issued as one burst, the 4 waves'
+  // 48 KiB take ~770 cycles to drain through the 64 B/clk vector-memory path and stall the issuing waves for that long
+  // every ~3000-cycle chunk.
+  static constexpr int kPieces = CB / 4 / 1024;       // per wave and chunk
+  lds_char* pend_dst;
+  int pend_soff;
+  __device__ __forceinline__ void select(int slot) {
+    int n = next;
+    asm volatile("" : "+s"(n));
+    pend_dst = ring + slot * CB + wave * (CB / 4);
+    pend_soff = n * CB + wave * (CB / 4);
+    next = (next + 1 == nchunks) ? 0 : next + 1;
+  }
+  template <int I>
+  __device__ __forceinline__ void piece_now() {
+    if constexpr (I < kPieces) piece<I>(pend_dst, (tid & 63) * 16, pend_soff);
+  }
   __device__ __forceinline__ void init(const char* w, int n, lds_char* r, int t) {
     win = w; nchunks = n; next = 0; ring = r; tid = t; cur = kRingSlots - 1;
 #if OBJ_DMA_BUFFER
-    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, n * kChunkBytes, 0x00020000);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, n * CB, 0x00020000);
     wave = __builtin_amdgcn_readfirstlane(t >> 6);
 #endif
     issue(0);
@@ -154,22 +180,26 @@ struct WeightStream {
 #endif
       cur ^= 1;
 #ifndef OBJ_ABL_DMA         // timing ablation only: weights never refreshed
-      issue(cur ^ 1);
+      if constexpr (CB == kB3ChunkBytes && OBJ_B3_SPREAD_DMA) select(cur ^ 1);
+      else issue(cur ^ 1);
 #endif
     } else {
       // 3 slots: the chunk consumed next was DMA'd two chunk-times ago; only the pieces of the
-      // chunk after it (the newest kChunkBytes/4096 VMEM ops of this wave) may still be in flight.
+      // chunk after it (the newest CB/4096 VMEM ops of this wave) may still be in flight.
       // __syncthreads() would drain vmcnt(0) (LDS-DMA counts as a pending LDS write), so: counted
       // vmcnt + lgkmcnt(0) (this wave's reads of the slot being recycled) + raw s_barrier.
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(kChunkBytes / 4096) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(CB / 4096) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       cur = cur == 2 ? 0 : cur + 1;
       issue(cur == 0 ? 2 : cur - 1);     // slot of the chunk consumed before the current one
     }
-    rd = ring + cur * kChunkBytes + (tid & 63) * 16;
+    rd = ring + cur * CB + (tid & 63) * 16;
   }
 };
+
+using WeightStream = WeightStreamT<kChunkBytes>;        // fp32 stream
+using WeightStreamB3 = WeightStreamT<kB3ChunkBytes>;   // split-bf16 stream (1.5x the bytes)
 
 __device__ __forceinline__ f32x4 lds_read16(const lds_char* p) {
   return *(const __attribute__((address_space(3))) f32x4*)p;
@@ -180,8 +210,8 @@ __device__ __forceinline__ f32x4 lds_read16(const lds_char* p) {
 template <int NT>
 struct ATiles { f32x4 v[NT]; };
 
-template <int NT, int G>
-__device__ __forceinline__ void load_group(ATiles<NT>& a, WeightStream& st) {
+template <int NT, int G, class Stream>
+__device__ __forceinline__ void load_group(ATiles<NT>& a, Stream& st) {
   constexpr int KG = kChunkTiles / NT;
   constexpr int ks0 = G * 4;
   if constexpr (ks0 % KG == 0) st.next_chunk();
@@ -203,8 +233,15 @@ struct NoHook {
 };
 // ZERO: acc = W * B instead of acc += W * B (the first k-step's MFMA takes the constant 0 as its C operand; the
 // accumulators need no initialisation pass).
-template <int NT, int KS, class Src, class Hook = NoHook, bool ZERO = false>
-__device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, Src& src, Hook after_barrier = Hook{}) {
+template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream>
+__device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier);
+
+template <int NT, int KS, class Src, class Hook = NoHook, bool ZERO = false, class Stream = WeightStream>
+__device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier = Hook{}) {
+  if constexpr (Stream::kBytes == kB3ChunkBytes) {
+    layer_mac_b3<NT, KS, Src, Hook, ZERO>(acc, st, src, after_barrier);
+    return;
+  }
   constexpr int NG4 = (KS + 3) / 4;
   constexpr int KG = kChunkTiles / NT;
   ATiles<NT> abuf[2];
@@ -262,6 +299,115 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], WeightStream& st, S
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 #endif
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-bf16 contraction (layout.h "split-bf16 weight stream"): per s-step (8 fp32 k-steps) the lane's 8 B values are
+// split exactly into (hi, mid, lo) bf16 triples, each out tile reads its three A planes (3 x ds_read_b128) and issues
+// the 6 products with |term| >= 2^-16, smallest first.  The split of step s + 1 is computed in the same scheduling
+// region as the MFMAs of step s: on the bf16 pipe (unlike fp32 MFMA) VALU work runs beside the matrix instructions.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct B3Operand { u32x4 hi, mid, lo; };
+
+__device__ __forceinline__ unsigned bf16_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream>
+__device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier) {
+  constexpr int NS = (KS + 7) / 8;
+  constexpr int SPC = kChunkTiles / NT / 8;      // s-steps per chunk
+  constexpr int G = (OBJ_B3_PAIR && NT >= 2) ? 2 : 1;      // out tiles whose products are interleaved
+  constexpr int NGRP = NT / G;
+  constexpr int PPI = (Stream::kPieces + SPC * NGRP - 1) / (SPC * NGRP);      // DMA pieces per MFMA group (spread mode)
+  auto split = [&](auto S_, B3Operand& b) __attribute__((always_inline)) {
+    constexpr int s = decltype(S_)::value;
+    static_for<4>([&](auto J) __attribute__((always_inline)) {
+      constexpr int jj = decltype(J)::value;
+      constexpr int k0 = 8 * s + 2 * jj, k1 = k0 + 1;
+      float x0 = 0.f, x1 = 0.f;
+      if constexpr (k0 < KS) x0 = src.template get<k0>();
+      if constexpr (k1 < KS) x1 = src.template get<k1>();
+      const unsigned h0 = bf16_trunc(x0), h1 = bf16_trunc(x1);
+      const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+      const unsigned m0 = bf16_trunc(r0), m1 = bf16_trunc(r1);
+      const float t0 = r0 - __uint_as_float(m0), t1 = r1 - __uint_as_float(m1);
+      b.hi[jj] = (h0 >> 16) | h1;
+      b.mid[jj] = (m0 >> 16) | m1;
+      b.lo[jj] = (bf16_trunc(t0) >> 16) | bf16_trunc(t1);
+    });
+  };
+  auto load_a = [&](u32x4 (&a)[G][3], int sl, int grp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < G; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[t][pl] = *(const __attribute__((address_space(3))) u32x4*)(st.rd + ((sl * NT + grp * G + t) * 3 + pl) * 1024);
+  };
+  B3Operand bop[2];
+  u32x4 abuf[2][G][3];
+  split(std::integral_constant<int, 0>{}, bop[0]);
+  static_for<NS>([&](auto S_) __attribute__((always_inline)) {
+    constexpr int s = decltype(S_)::value;
+    constexpr int sl = s % SPC;
+    if constexpr (sl == 0) {
+      st.next_chunk();
+      after_barrier(std::integral_constant<int, s / SPC>{});
+    }
+    const B3Operand& b = bop[s & 1];
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bm = __builtin_bit_cast(bf16x8, b.mid), bl = __builtin_bit_cast(bf16x8, b.lo);
+    // A tiles: double-buffered across the groups of a chunk (the buffer index alternates with the group's position in
+    // the chunk); the first group of a chunk is read right behind the chunk barrier
+    if constexpr (sl == 0) load_a(abuf[0], 0, 0);
+    static_for<NGRP>([&](auto GR) __attribute__((always_inline)) {
+      constexpr int grp = decltype(GR)::value;
+      constexpr int it = sl * NGRP + grp;                 // group index inside the chunk
+      u32x4 (&a)[G][3] = abuf[it & 1];
+      if constexpr (grp + 1 < NGRP) load_a(abuf[(it + 1) & 1], sl, grp + 1);
+      else if constexpr (sl + 1 < SPC && s + 1 < NS) load_a(abuf[(it + 1) & 1], sl + 1, 0);
+      // this chunk's share of the NEXT chunk's DMA: PPI 1-KiB pieces per wave in front of each MFMA group
+      if constexpr (OBJ_B3_SPREAD_DMA)
+        static_for<PPI>([&](auto Q) __attribute__((always_inline)) { st.template piece_now<it * PPI + decltype(Q)::value>(); });
+      // keep the loads above the MFMAs below (the compiler otherwise sinks them to their first use: exposed LDS latency)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (grp == 0 && s + 1 < NS) split(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1]);
+      bf16x8 ah[G], am[G], al[G];
+#pragma unroll
+      for (int t = 0; t < G; ++t) {
+        ah[t] = __builtin_bit_cast(bf16x8, a[t][0]);
+        am[t] = __builtin_bit_cast(bf16x8, a[t][1]);
+        al[t] = __builtin_bit_cast(bf16x8, a[t][2]);
+      }
+      // 6 products per tile, smallest terms first; the G tiles alternate so that no MFMA waits for its predecessor
+#pragma unroll
+      for (int t = 0; t < G; ++t) {
+        if constexpr (ZERO && s == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, zero, 0, 0, 0);
+        } else {
+          acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[grp * G + t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[grp * G + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bm, acc[grp * G + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bh, acc[grp * G + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bm, acc[grp * G + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[grp * G + t], 0, 0, 0);
+    });
+    // last s-step of the layer: the pieces the (shorter) last chunk had no MFMA group for
+    if constexpr (OBJ_B3_SPREAD_DMA && s == NS - 1) {
+      constexpr int done = (sl + 1) * NGRP * PPI;
+      static_for<Stream::kPieces>([&](auto I) __attribute__((always_inline)) {
+        if constexpr (decltype(I)::value >= done) st.template piece_now<decltype(I)::value>();
+      });
+    }
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -682,13 +828,15 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false>
+template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles, float* const save_ws = nullptr) {
+  static_assert(!B3 || (FUSED && !SAVE && !SIGMA_ONLY), "split-bf16 mode: fused inference form only");
+  constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");
   // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read of a glds
   // pipeline, guide §5 "three .s-level traps"): [2-slot weight ring | aux block]
-  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0) +
+  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kCB + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0) +
                                                         (SAVE ? kStageBytes : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -698,15 +846,15 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   constexpr int kStart = DO_SCENE ? 0 : scene_chunks(VOXEL);
   constexpr int kEnd = SIGMA_ONLY ? layer_chunk_start(VOXEL, DO_SCENE ? L_SF : L_OF)
                                   : (DO_OBJ ? total_chunks(VOXEL) : scene_chunks(VOXEL));
-  WeightStream st;
-  st.init((const char*)a.blob + (size_t)kStart * kChunkBytes, kEnd - kStart,
+  WeightStreamT<kCB> st;
+  st.init((const char*)a.blob + (size_t)kStart * kCB, kEnd - kStart,
           (lds_char*)ring_mem, tid);
 
   const long P = FUSED ? a.n_rays * (long)a.S : a.n_points;
   const SaveWs ws{save_ws, P};
 #if OBJ_AUX_LDS
   // biases + head weights (16 KiB) are read by every wave every pass: stage them once in LDS
-  float* aux_lds = (float*)(ring_mem + kRingSlots * kChunkBytes);
+  float* aux_lds = (float*)(ring_mem + kRingSlots * kCB);
   for (int i = tid; i < kAuxFloats; i += 256) aux_lds[i] = a.aux[i];
   __syncthreads();
   const float* aux = aux_lds;
@@ -778,7 +926,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       src.ovox = (VOXEL && DO_OBJ) ? a.obj_voxel + p * kObjVoxPE : nullptr;
       src.ocode = DO_OBJ ? a.obj_code + p * kCodeC : nullptr;
     }
-    const Stage stg{(float*)(ring_mem + kRingSlots * kChunkBytes + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)) + wave * kStageFloats,
+    const Stage stg{(float*)(ring_mem + kRingSlots * kCB + (OBJ_AUX_LDS ? kAuxFloats * 4 : 0)) + wave * kStageFloats,
                    tile * 128 + wave * 32, P, lane};
     // tile whose prologue is staged during this pass (the last pass re-stages its own tile: harmless)
     const long tile_next = tile + tile_step < tile_end ? tile + tile_step : tile;

@@ -562,6 +562,26 @@ __global__ void pack_kernel(const uint32_t* __restrict__ idx, long n, const Para
   out[i] = e == kPackZero ? 0.f : pp.p[e >> 24][e & 0xFFFFFFu];
 }
 
+// split-bf16 packer: gather, split exactly into three bf16 pieces (truncation), scatter to the three planes
+__global__ void pack_b3_kernel(const uint32_t* __restrict__ idx, long n, const ParamPtrs pp, uint16_t* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const uint32_t ix = idx[e];
+  const float w = ix == kPackZero ? 0.f : pp.p[ix >> 24][ix & 0xFFFFFFu];
+  const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
+  const float r1 = w - __uint_as_float(hi);
+  const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mid);
+  const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;            // r2 has <= 8 significant bits: exact
+  const long chunk = e / kChunkFloats;
+  const int r = (int)(e - chunk * kChunkFloats);
+  const int q = r >> 9, lane = (r >> 3) & 63, j = r & 7;
+  uint16_t* o = out + (chunk * kB3ChunkBytes + (long)(q * 3) * 1024 + lane * 16 + j * 2) / 2;
+  o[0] = (uint16_t)(hi >> 16);
+  o[512] = (uint16_t)(mid >> 16);
+  o[1024] = (uint16_t)(lo >> 16);
+}
+
 }  // namespace objnerf
 
 // ==========================================================================================
@@ -720,6 +740,20 @@ int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t
   hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, pp, blob);
   hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(na, 256)), dim3(256), 0, (hipStream_t)stream, aux_idx, na, pp, aux);
   return check_launch("pack_weights");
+}
+
+int objnerf_pack_weights_b3(int use_voxel, const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob,
+                            void* stream) {
+  if (!blob_idx || !h_param_ptrs || !blob) return set_error(-1, "pack_weights_b3: bad arguments");
+  ParamPtrs pp;
+  for (int i = 0; i < kNumParamPtrs; ++i) {
+    if (!h_param_ptrs[i]) return set_error(-1, "pack_weights_b3: null parameter pointer");
+    pp.p[i] = h_param_ptrs[i];
+  }
+  const long n = objnerf_blob_floats(use_voxel);
+  hipLaunchKernelGGL(pack_b3_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, n, pp,
+                     (uint16_t*)blob);
+  return check_launch("pack_weights_b3");
 }
 
 int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream) {

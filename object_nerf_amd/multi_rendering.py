@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .bbox import pack_boxes
 from .embedding_helper import EmbeddingVoxel
-from .rendering import _linspace
+from .rendering import _linspace, mfma_mode
 
 __all__ = ["render_rays_multi"]
 
@@ -43,9 +43,10 @@ def _mlp_one_branch(model, use_voxel, grid, rays, z, oid, code_library, l):
             rgb_all.index_copy_(0, active, c)
         return sigma_all, rgb_all
     n = n_all
-    blob, aux = model.packed()
+    b3 = mfma_mode() == "bf16x3"
+    blob, aux = model.packed(split_bf16=b3)
     a = _lib.MlpArgs()
-    a.use_voxel = int(use_voxel)
+    a.use_voxel, a.mfma_bf16x3 = int(use_voxel), int(b3)
     a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
     a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), z.data_ptr(), n, S
     if use_voxel:

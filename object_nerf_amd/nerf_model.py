@@ -43,6 +43,16 @@ def _pack_index(use_voxel, device):
     return _index_cache[key]
 
 
+def _pack_index_b3(use_voxel, device):
+    key = ("b3", bool(use_voxel), str(device))
+    if key not in _index_cache:
+        l = _lib.lib()
+        bi = torch.empty(l.objnerf_blob_floats(int(use_voxel)), dtype=torch.int32)
+        _lib.check(l.objnerf_pack_index_b3(int(use_voxel), C.c_void_p(bi.data_ptr())), "pack_index_b3")
+        _index_cache[key] = bi.to(device)
+    return _index_cache[key]
+
+
 def _pack_index_bwd(use_voxel, device):
     key = ("bwd", bool(use_voxel), str(device))
     if key not in _index_cache:
@@ -116,6 +126,8 @@ class ObjectNeRF(nn.Module):
         self._packed_key = None
         self._packed_bwd = None
         self._packed_bwd_key = None
+        self._packed_b3 = None
+        self._packed_b3_key = None
 
     # ---- weight stream ---------------------------------------------------------------------
     def _param_list(self):
@@ -126,11 +138,25 @@ class ObjectNeRF(nn.Module):
             out += [m.weight, m.bias]
         return out
 
-    def packed(self):
+    def packed(self, split_bf16=False):
         """(blob, aux) device tensors for the kernel; re-gathered when any parameter changed
-        (optimizer step, load_state_dict, .to()) -- keyed on (data_ptr, _version)."""
+        (optimizer step, load_state_dict, .to()) -- keyed on (data_ptr, _version).
+        split_bf16: the blob of the split-bf16 arithmetic mode (rendering.mfma_mode()); aux is shared."""
         params = self._param_list()
         key = tuple((p.data_ptr(), p._version) for p in params)
+        if split_bf16:
+            _, aux = self.packed()
+            if self._packed_b3 is None or key != self._packed_b3_key:
+                l = _lib.lib()
+                uv = int(self.use_voxel_embedding)
+                dev = params[0].device
+                srcs = [_lib.as_f32(p.detach()) for p in params]
+                idx = _pack_index_b3(uv, dev)
+                blob = torch.empty(l.objnerf_b3_blob_bytes(uv) // 4, dtype=torch.float32, device=dev)
+                table = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+                _lib.check(l.objnerf_pack_weights_b3(uv, _lib.ptr(idx), table, _lib.ptr(blob), _lib.stream_ptr()), "pack_weights_b3")
+                self._packed_b3, self._packed_b3_key = blob, key
+            return self._packed_b3, aux
         if self._packed is not None and key == self._packed_key:
             return self._packed
         dev = params[0].device

@@ -75,6 +75,16 @@ def _out_struct(o):
     return s
 
 
+def mfma_mode():
+    """Arithmetic of the fused inference MLP kernel: "f32" (default; v_mfma_f32_32x32x2_f32) or "bf16x3" (the same fp32
+    contraction on the bf16 matrix pipe: operands split exactly into three bf16 pieces, 6 of 9 cross products, fp32
+    accumulation; include/objnerf_hip.h).  Selected per call by the environment variable OBJNERF_MFMA."""
+    m = os.environ.get("OBJNERF_MFMA", "f32")
+    if m not in ("f32", "bf16x3"):
+        raise RuntimeError("OBJNERF_MFMA must be 'f32' or 'bf16x3', got %r" % m)
+    return m
+
+
 def _train_packs(coarse, fine):
     mode = os.environ.get("OBJNERF_TRAIN_LAYERWISE", "")
     if mode == "1":
@@ -174,7 +184,7 @@ def render_rays(
         perturb=float(perturb), noise_std=float(noise_std), white_back=int(bool(white_back)),
         forward_instance=int(bool(forward_instance)), is_eval=int(is_eval),
         use_zero_as_last_delta=int(use_zero_as_last_delta), frustum_bound_th=float(frustum_bound_th),
-        rays_in_bbox=int(bool(rays_in_bbox)))
+        rays_in_bbox=int(bool(rays_in_bbox)), mfma_bf16x3=int(mfma_mode() == "bf16x3"))
     l = _lib.lib()
     ws = torch.empty(l.objnerf_render_workspace_bytes(C.byref(cfg), n), dtype=torch.uint8, device=dev)
 
@@ -186,10 +196,10 @@ def render_rays(
         ptm = pass_through_mask.reshape(n).to(torch.uint8).contiguous()
         rin.pass_through_mask = ptm.data_ptr()
         keep.append(ptm)
-    bc, ac = coarse.packed()
+    bc, ac = coarse.packed(split_bf16=bool(cfg.mfma_bf16x3))
     rin.blob_coarse, rin.aux_coarse = bc.data_ptr(), ac.data_ptr()
     if I > 0:
-        bf, af = models["fine"].packed()
+        bf, af = models["fine"].packed(split_bf16=bool(cfg.mfma_bf16x3))
         rin.blob_fine, rin.aux_fine = bf.data_ptr(), af.data_ptr()
     if use_voxel:
         rin.grid = emb_xyz.grid_struct()

@@ -36,9 +36,10 @@ def main(tags, n_rays=76800, S=128, rounds=5):
     out = [torch.empty(n_rays, S, device=dev), torch.empty(n_rays, S, 3, device=dev),
            torch.empty(n_rays, S, device=dev), torch.empty(n_rays, S, 3, device=dev)]
     grid = sc.embeddings["xyz"].grid_struct()
-    libs, packs = {}, {}
+    libs, packs, b3 = {}, {}, {}
     for t in tags:
-        l = load(t)
+        b3[t] = t.endswith("+b3")             # "<tag>+b3": the split-bf16 arithmetic mode of that library
+        l = load(t[:-3] if b3[t] else t)
         nb, na = l.objnerf_blob_floats(1), l.objnerf_aux_floats()
         bi, ai = torch.empty(nb, dtype=torch.int32), torch.empty(na, dtype=torch.int32)
         assert l.objnerf_pack_index(1, C.c_void_p(bi.data_ptr()), C.c_void_p(ai.data_ptr())) == 0
@@ -46,11 +47,17 @@ def main(tags, n_rays=76800, S=128, rounds=5):
         blob, aux = torch.empty(nb, device=dev), torch.empty(na, device=dev)
         table = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
         assert l.objnerf_pack_weights(1, _lib.ptr(bi), _lib.ptr(ai), table, _lib.ptr(blob), _lib.ptr(aux), _lib.stream_ptr()) == 0
+        if b3[t]:
+            bi3 = torch.empty(nb, dtype=torch.int32)
+            assert l.objnerf_pack_index_b3(1, C.c_void_p(bi3.data_ptr())) == 0
+            bi3 = bi3.to(dev)
+            blob = torch.empty(l.objnerf_b3_blob_bytes(1) // 4, device=dev)
+            assert l.objnerf_pack_weights_b3(1, _lib.ptr(bi3), table, _lib.ptr(blob), _lib.stream_ptr()) == 0
         libs[t], packs[t] = l, (blob, aux)
 
     def args_for(t):
         a = _lib.MlpArgs()
-        a.use_voxel, a.do_scene, a.do_object = 1, 1, 1
+        a.use_voxel, a.do_scene, a.do_object, a.mfma_bf16x3 = 1, 1, 1, int(b3[t])
         a.blob, a.aux = packs[t][0].data_ptr(), packs[t][1].data_ptr()
         a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), z.data_ptr(), n_rays, S
         a.codes, a.code_stride, a.grid = codes.data_ptr(), 0, grid
@@ -58,6 +65,7 @@ def main(tags, n_rays=76800, S=128, rounds=5):
         return a
 
     times = {t: [] for t in tags}
+    errs, ref_out = {}, None
     sums = {}
     for r in range(rounds + 1):
         for t in tags:
@@ -71,6 +79,10 @@ def main(tags, n_rays=76800, S=128, rounds=5):
             if r > 0:
                 times[t].append(dt * 1e3)
             sums[t] = (out[0].double().sum().item(), out[1].double().sum().item(), out[2].double().sum().item(), out[3].double().sum().item())
+            if r == rounds:          # element-wise distance of this variant's outputs from the first tag's (normwise, per output)
+                if t == tags[0]:
+                    ref_out = [o.clone() for o in out]
+                errs[t] = tuple(((o - q).abs().max() / q.abs().max()).item() for o, q in zip(out, ref_out))
     evals = n_rays * S
     base = None
     for t in tags:
@@ -78,7 +90,8 @@ def main(tags, n_rays=76800, S=128, rounds=5):
         tf = evals * 1776128 / (med * 1e-3) / 1e12
         base = base or med
         print("%-14s median %8.3f ms  min %8.3f  %6.1f TFLOP/s  %.3f of peak  x%.3f vs first  checksum %.6e %.6e %.6e %.6e"
-              % (t, med, min(times[t]), tf, tf / 157.3, base / med, *sums[t]), flush=True)
+              "  normwise err vs first (sigma, rgb, isigma, irgb) %.1e %.1e %.1e %.1e"
+              % (t, med, min(times[t]), tf, tf / 157.3, base / med, *sums[t], *errs[t]), flush=True)
 
 
 if __name__ == "__main__":
