@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--n-importance", type=int, default=64)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--split-bf16-steps", type=int, default=2,
+                    help="extra, separately reported frames in the opt-in split-bf16 arithmetic mode (0 = skip)")
     return ap.parse_args()
 
 
@@ -123,6 +125,41 @@ def main():
     lib.objnerf_timing_enable(0)
 
     log("timed region done: %.3f s for %d steps" % (t1 - t0, args.steps))
+
+    # Not part of `value`: the same frame in the opt-in split-bf16 arithmetic mode (OBJNERF_MFMA=bf16x3: the fp32
+    # contraction carried out on the bf16 matrix pipe with exactly split operands), reported beside
+    # the fp32-MFMA headline with its distance from the fp32 path's pixels.
+    extra = None
+    if args.split_bf16_steps > 0:
+        ref_rgb = last["rgb_fine"].clone()
+        os.environ["OBJNERF_MFMA"] = "bf16x3"
+        try:
+            step()
+            fence()
+            lib.objnerf_timing_enable(1)
+            tb0 = time.perf_counter()
+            for _ in range(args.split_bf16_steps):
+                step()
+            fence()
+            tb1 = time.perf_counter()
+            bl, bms = C.c_int64(0), C.c_double(0.0)
+            lib.objnerf_timing_read(C.byref(bl), C.byref(bms))
+            lib.objnerf_timing_enable(0)
+            eb = torch.tensor([tb1 - tb0], dtype=torch.float64, device=dev)
+            if dist is not None:
+                dist.all_reduce(eb, op=dist.ReduceOp.MAX)
+            eb = eb.item()
+            mse = ((last["rgb_fine"].double() - ref_rgb.double()) ** 2).mean().item()
+            import math
+            extra = {"value": world * n * (S + S + I) * args.split_bf16_steps / eb, "unit": "ray-samples/s",
+                     "ms_per_step": 1e3 * eb / args.split_bf16_steps, "steps": args.split_bf16_steps,
+                     "dtype": "f32 operands split exactly into 3 x bf16, 6 of 9 products on the bf16 matrix pipe, f32 accumulate",
+                     "mlp_tflops_f32_equivalent": float(n * (S + S + I)) * args.split_bf16_steps * FLOP_PER_EVAL_BOTH_VOXEL / (bms.value / 1e3) / 1e12,
+                     "psnr_vs_f32_mfma_path_db": -10.0 * math.log10(max(mse, 1e-30)),
+                     "max_abs_diff_vs_f32_mfma_path": (last["rgb_fine"] - ref_rgb).abs().max().item()}
+        finally:
+            os.environ.pop("OBJNERF_MFMA", None)
+        last["rgb_fine"] = ref_rgb
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -153,6 +190,8 @@ def main():
                          "launches": int(launches.value), "avg_launch_ms": kms.value / max(1, launches.value),
                          "flop_per_eval": FLOP_PER_EVAL_BOTH_VOXEL, "mlp_time_frac_of_step": mlp_s / elapsed},
         }
+        if extra is not None:
+            res["split_bf16_mode"] = extra
         if world == 1 and args.cpu_rays > 0:
             res["cpu_baseline"], psnr = cpu_baseline(sc, rays, codes, kw, args.cpu_rays, evals_per_ray, last["rgb_fine"])
             # second half of BASELINE.json's metric ("+ PSNR vs ref"): utils/metrics.py:5-15 on the baseline's rays

@@ -321,7 +321,9 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
   constexpr int SPC = kChunkTiles / NT / 8;      // s-steps per chunk
   constexpr int G = (OBJ_B3_PAIR && NT >= 2) ? 2 : 1;      // out tiles whose products are interleaved
   constexpr int NGRP = NT / G;
-  constexpr int PPI = (Stream::kPieces + SPC * NGRP - 1) / (SPC * NGRP);      // DMA pieces per MFMA group (spread mode)
+  // DMA pieces per MFMA group (spread mode): front-loaded into the first half of the chunk's groups, so that the last
+  // piece has half a chunk to land before the (early) barrier that opens its chunk
+  constexpr int PPI = (Stream::kPieces + SPC * NGRP / 2 - 1) / (SPC * NGRP / 2);
   auto split = [&](auto S_, B3Operand& b) __attribute__((always_inline)) {
     constexpr int s = decltype(S_)::value;
     static_for<4>([&](auto J) __attribute__((always_inline)) {
@@ -352,23 +354,36 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
   static_for<NS>([&](auto S_) __attribute__((always_inline)) {
     constexpr int s = decltype(S_)::value;
     constexpr int sl = s % SPC;
-    if constexpr (sl == 0) {
+    // The layer's first chunk is opened here; every later one is opened EARLY, in front of the MFMAs of the previous
+    // chunk's last group (below): by then that group's A tiles sit in registers, so the barrier may recycle the slot,
+    // and the next chunk's first A tiles are fetched under those MFMAs instead of behind an idle barrier.
+    if constexpr (s == 0) {
       st.next_chunk();
-      after_barrier(std::integral_constant<int, s / SPC>{});
+      after_barrier(std::integral_constant<int, 0>{});
+      load_a(abuf[0], 0, 0);
     }
     const B3Operand& b = bop[s & 1];
     const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bm = __builtin_bit_cast(bf16x8, b.mid), bl = __builtin_bit_cast(bf16x8, b.lo);
-    // A tiles: double-buffered across the groups of a chunk (the buffer index alternates with the group's position in
-    // the chunk); the first group of a chunk is read right behind the chunk barrier
-    if constexpr (sl == 0) load_a(abuf[0], 0, 0);
     static_for<NGRP>([&](auto GR) __attribute__((always_inline)) {
       constexpr int grp = decltype(GR)::value;
       constexpr int it = sl * NGRP + grp;                 // group index inside the chunk
-      u32x4 (&a)[G][3] = abuf[it & 1];
-      if constexpr (grp + 1 < NGRP) load_a(abuf[(it + 1) & 1], sl, grp + 1);
-      else if constexpr (sl + 1 < SPC && s + 1 < NS) load_a(abuf[(it + 1) & 1], sl + 1, 0);
-      // this chunk's share of the NEXT chunk's DMA: PPI 1-KiB pieces per wave in front of each MFMA group
-      if constexpr (OBJ_B3_SPREAD_DMA)
+      // A tiles are double-buffered across all groups of the layer: group number gi uses abuf[gi & 1]
+      constexpr int gi = s * NGRP + grp;
+      u32x4 (&a)[G][3] = abuf[gi & 1];
+      constexpr bool last_of_chunk = (it == SPC * NGRP - 1);
+      constexpr bool more = (grp + 1 < NGRP) || (s + 1 < NS);
+      if constexpr (more && last_of_chunk) {
+        st.next_chunk();                                  // barrier: every wave holds its last A tiles of the old slot
+        after_barrier(std::integral_constant<int, s / SPC + 1>{});
+        load_a(abuf[(gi + 1) & 1], 0, 0);
+      } else if constexpr (grp + 1 < NGRP) {
+        load_a(abuf[(gi + 1) & 1], sl, grp + 1);
+      } else if constexpr (s + 1 < NS) {
+        load_a(abuf[(gi + 1) & 1], sl + 1, 0);
+      }
+      // this chunk's share of the NEXT chunk's DMA: PPI 1-KiB pieces per wave in front of each MFMA group (the group
+      // that opened the next chunk has already selected the chunk after it: its pieces start with that group's successor)
+      if constexpr (OBJ_B3_SPREAD_DMA && !last_of_chunk)
         static_for<PPI>([&](auto Q) __attribute__((always_inline)) { st.template piece_now<it * PPI + decltype(Q)::value>(); });
       // keep the loads above the MFMAs below (the compiler otherwise sinks them to their first use: exposed LDS latency)
       __builtin_amdgcn_sched_barrier(0);
@@ -403,7 +418,7 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
     });
     // last s-step of the layer: the pieces the (shorter) last chunk had no MFMA group for
     if constexpr (OBJ_B3_SPREAD_DMA && s == NS - 1) {
-      constexpr int done = (sl + 1) * NGRP * PPI;
+      constexpr int done = ((sl + 1) * NGRP - (((sl + 1) * NGRP == SPC * NGRP) ? 1 : 0)) * PPI;
       static_for<Stream::kPieces>([&](auto I) __attribute__((always_inline)) {
         if constexpr (decltype(I)::value >= done) st.template piece_now<decltype(I)::value>();
       });

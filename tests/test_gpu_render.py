@@ -251,3 +251,30 @@ def test_full_frame_properties():
         if k.endswith("coarse"):
             assert H.normwise(r[k][idx], ro[k]) < 1e-4, k
     assert psnr(r["rgb_fine"][idx].cpu(), ro["rgb_fine"]) >= 60.0
+
+
+def test_split_bf16_mode_matches_f32_mfma_mode(monkeypatch):
+    """OBJNERF_MFMA=bf16x3 (the fp32 contraction on the bf16 matrix pipe: operands split exactly into three bf16 pieces,
+    6 of 9 products, fp32 accumulation) against the default fp32-MFMA kernel on a batch where every workgroup loops over
+    several tiles, and against the reference's golden outputs through the ordinary parity test of one case."""
+    sc = cases.scene_for(A, "voxel", device=DEV)
+    rays = synth.camera_rays(160, 120).to(DEV)
+    n = rays.shape[0]
+    ids = synth.per_ray_ids(n).to(DEV)
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"].contiguous()
+        kw = dict(N_samples=64, N_importance=64, perturb=0, noise_std=0, embedding_instance=codes, is_eval=True)
+        monkeypatch.delenv("OBJNERF_MFMA", raising=False)
+        r32 = A.render_rays(sc.models, sc.embeddings, rays, **kw)
+        monkeypatch.setenv("OBJNERF_MFMA", "bf16x3")
+        rb3 = A.render_rays(sc.models, sc.embeddings, rays, **kw)
+        rb3_again = A.render_rays(sc.models, sc.embeddings, rays, **kw)
+    for k in r32:
+        assert torch.isfinite(rb3[k]).all(), k
+        assert torch.equal(rb3[k], rb3_again[k]), "non-deterministic: " + k
+        if k.endswith("coarse"):
+            assert H.normwise(rb3[k], r32[k]) < 2e-5, k          # measured ~2e-6: fp32-roundoff class
+    assert psnr(rb3["rgb_fine"].cpu(), r32["rgb_fine"].cpu()) >= 70.0     # fine pass: sampler sensitivity, see above
+    monkeypatch.setenv("OBJNERF_MFMA", "fp16")
+    with pytest.raises(RuntimeError), torch.no_grad():
+        A.render_rays(sc.models, sc.embeddings, rays[:8].contiguous(), **dict(kw, embedding_instance=codes[:8]))
