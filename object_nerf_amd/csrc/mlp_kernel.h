@@ -48,6 +48,9 @@
 #ifndef OBJ_XCD_TILES
 #define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers)
 #endif
+#ifndef OBJ_SPREAD_DMA
+#define OBJ_SPREAD_DMA 1     // fp32 stream: weight DMA pieces issued between the MFMA groups instead of as a burst
+#endif
 #ifndef OBJ_B3_SPREAD_DMA
 #define OBJ_B3_SPREAD_DMA 1  // split-bf16 mode: weight DMA pieces issued between the MFMA groups instead of as a burst
 #endif
@@ -180,7 +183,7 @@ struct WeightStreamT {
 #endif
       cur ^= 1;
 #ifndef OBJ_ABL_DMA         // timing ablation only: weights never refreshed
-      if constexpr (CB == kB3ChunkBytes && OBJ_B3_SPREAD_DMA) select(cur ^ 1);
+      if constexpr ((CB == kB3ChunkBytes && OBJ_B3_SPREAD_DMA) || (CB == kChunkBytes && OBJ_SPREAD_DMA)) select(cur ^ 1);
       else issue(cur ^ 1);
 #endif
     } else {
@@ -244,6 +247,15 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
   }
   constexpr int NG4 = (KS + 3) / 4;
   constexpr int KG = kChunkTiles / NT;
+  // spread mode: the 8 DMA pieces of the chunk after the current one are issued in front of the chunk's MFMA groups
+  constexpr int GPC = KG / 4;                                  // groups per chunk
+  // pieces per group, front-loaded into the first half of the chunk's groups: the chunk is opened (barrier, vmcnt(0))
+  // in front of the current chunk's LAST group, so the last piece gets at least a third of a chunk to land
+  constexpr int PPG = (Stream::kPieces + (GPC / 2 > 0 ? GPC / 2 : 1) - 1) / (GPC / 2 > 0 ? GPC / 2 : 1);
+  auto pieces = [&](auto GQ) __attribute__((always_inline)) {
+    if constexpr (OBJ_SPREAD_DMA && kRingSlots == 2)
+      static_for<PPG>([&](auto Q) __attribute__((always_inline)) { st.template piece_now<decltype(GQ)::value * PPG + decltype(Q)::value>(); });
+  };
   ATiles<NT> abuf[2];
   load_group<NT, 0>(abuf[0], st);
   after_barrier(std::integral_constant<int, 0>{});
@@ -254,9 +266,15 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
     constexpr int g = decltype(G)::value;
     constexpr int ks0 = g * 4;
     ATiles<NT>& a = abuf[g & 1];
+    pieces(std::integral_constant<int, g % GPC>{});              // group g's share (after the barrier that opened its chunk)
     if constexpr (g + 1 < NG4) {
       load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
       if constexpr (((g + 1) * 4) % KG == 0) after_barrier(std::integral_constant<int, ((g + 1) * 4) / KG>{});
+    } else if constexpr (OBJ_SPREAD_DMA && kRingSlots == 2) {
+      // end of the layer: pieces the (shorter) last chunk had no group for
+      static_for<Stream::kPieces>([&](auto I) __attribute__((always_inline)) {
+        if constexpr (decltype(I)::value >= (g % GPC + 1) * PPG) st.template piece_now<decltype(I)::value>();
+      });
     }
 #if OBJ_HOIST_LDS
     __builtin_amdgcn_sched_barrier(0);
