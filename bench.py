@@ -157,6 +157,12 @@ def main():
                      "mlp_tflops_f32_equivalent": float(n * (S + S + I)) * args.split_bf16_steps * FLOP_PER_EVAL_BOTH_VOXEL / (bms.value / 1e3) / 1e12,
                      "psnr_vs_f32_mfma_path_db": -10.0 * math.log10(max(mse, 1e-30)),
                      "max_abs_diff_vs_f32_mfma_path": (last["rgb_fine"] - ref_rgb).abs().max().item()}
+        except Exception as e:      # the optional mode must never cost the headline line
+            extra = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                lib.objnerf_timing_enable(0)
+            except Exception:
+                pass
         finally:
             os.environ.pop("OBJNERF_MFMA", None)
         last["rgb_fine"] = ref_rgb
