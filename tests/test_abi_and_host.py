@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -56,6 +57,39 @@ def test_pack_index_is_a_bijection(use_voxel):
     assert used.numel() == total == sum(p.numel() for p in m.parameters())
     # weights live in the stream, biases and heads in the aux block
     assert set(((bi.to(torch.int64) & 0xFFFFFFFF)[bi != -1] >> 24).unique().tolist()) <= set(range(0, 40, 2))
+
+
+@pytest.mark.parametrize("use_voxel", [1, 0])
+def test_other_weight_streams_reference_the_right_elements(use_voxel):
+    """split-bf16 stream: the same multiset of weight elements as the fp32 stream (it is the same weights in another
+    order, three planes each); backward stream: exactly the hidden-to-hidden blocks, each element once."""
+    l = _lib.lib()
+    nb, na = l.objnerf_blob_floats(use_voxel), l.objnerf_aux_floats()
+    bi, ai = torch.empty(nb, dtype=torch.int32), torch.empty(na, dtype=torch.int32)
+    _lib.check(l.objnerf_pack_index(use_voxel, C.c_void_p(bi.data_ptr()), C.c_void_p(ai.data_ptr())), "pack_index")
+    b3 = torch.empty(nb, dtype=torch.int32)
+    _lib.check(l.objnerf_pack_index_b3(use_voxel, C.c_void_p(b3.data_ptr())), "pack_index_b3")
+    assert l.objnerf_b3_blob_bytes(use_voxel) == nb * 6                 # 3 planes x 2 bytes per element
+    a, b = bi.numpy().view("uint32"), b3.numpy().view("uint32")
+    assert (np.sort(a[a != 0xFFFFFFFF]) == np.sort(b[b != 0xFFFFFFFF])).all()
+    assert (a != 0xFFFFFFFF).sum() == (b != 0xFFFFFFFF).sum() > 500_000
+
+    nbw = l.objnerf_bwd_blob_floats()
+    bw = torch.empty(nbw, dtype=torch.int32)
+    _lib.check(l.objnerf_pack_index_bwd(use_voxel, C.c_void_p(bw.data_ptr())), "pack_index_bwd")
+    w = bw.numpy().view("uint32")
+    assert (w != 0xFFFFFFFF).all()                                       # whole tiles, no padding
+    assert np.unique(w).size == w.size                                   # every streamed element exactly once
+    # expected element count: SD[:, :256], SF, S8..S6, S5[:, hidden], S4..S2 (256 x 256 each, SD 128 x 256) and
+    # OD[:, :128] (64 x 128), OF, O4, O3[:, hidden], O2 (128 x 128 each)
+    assert w.size == 128 * 256 + 8 * 256 * 256 + 64 * 128 + 4 * 128 * 128
+    # pointer ids: weights only (even ids) of the layers named above
+    ids = set((w >> 24).tolist())
+    names = [n for n in PARAM_LAYERS]
+    want = {"dir_encoding.0", "xyz_encoding_final", "xyz_encoding_8.0", "xyz_encoding_7.0", "xyz_encoding_6.0",
+            "xyz_encoding_5.0", "xyz_encoding_4.0", "xyz_encoding_3.0", "xyz_encoding_2.0", "inst_dir_encoding.0",
+            "instance_encoding_final.0", "instance_encoding_4.0", "instance_encoding_3.0", "instance_encoding_2.0"}
+    assert ids == {2 * names.index(n) for n in want}
 
 
 def test_module_types_and_state_dict_names():
