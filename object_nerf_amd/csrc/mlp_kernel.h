@@ -9,8 +9,10 @@
 //   * activations never leave registers: layer l's 32x32 accumulator tiles (after bias +
 //     LeakyReLU) ARE the B operands of layer l+1 (layout.h explains the permutation);
 //   * weights are a linear stream of pre-permuted A tiles; 32 KiB chunks are DMA'd
-//     global->LDS (global_load_lds_dwordx4) one chunk ahead into a 2-slot ring shared by the
-//     4 waves, and read back as ds_read_b128 (4 k-steps of one out tile per instruction);
+//     global->LDS (buffer_load_dwordx4 ... lds) one chunk ahead into a 2-slot ring shared by the
+//     4 waves -- issued piecewise between the MFMA groups of the chunk being consumed, not as one
+//     burst -- and read back as ds_read_b128 (4 k-steps of one out tile per instruction);
+//   * every XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers);
 //   * positional / voxel embeddings are generated in registers right where the MFMA needs
 //     them (never materialised: the reference writes 375 floats per sample to HBM);
 //   * the 1-row sigma heads and 3-row rgb heads run on the VALU (an MFMA tile would be
@@ -18,6 +20,10 @@
 //
 // Roofline: MFMA-bound. 13,876 v_mfma_f32_32x32x2_f32 per 32 points (both branches, voxel
 // mode) = 1,776,128 algorithmic FLOP per point; fp32 MFMA peak 157.3 TFLOP/s.
+//
+// Template variants of the same kernel: FUSED = false reads pre-embedded rows (ObjectNeRF.forward /
+// forward_instance), SIGMA_ONLY stops after the density head, SAVE is the training forward (every layer's
+// output also written to memory), B3 is the opt-in split-bf16 arithmetic mode (layout.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
