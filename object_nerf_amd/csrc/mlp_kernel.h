@@ -60,8 +60,8 @@
 #ifndef OBJ_B3_SPREAD_DMA
 #define OBJ_B3_SPREAD_DMA 1  // split-bf16 mode: weight DMA pieces issued between the MFMA groups instead of as a burst
 #endif
-#ifndef OBJ_B3_PAIR
-#define OBJ_B3_PAIR 1        // split-bf16 mode: two out tiles' products interleaved (no back-to-back dependent MFMAs)
+#ifndef OBJ_B3_GROUP
+#define OBJ_B3_GROUP 2       // split-bf16 mode: out tiles whose products are interleaved (no back-to-back dependent MFMAs)
 #endif
 #ifndef OBJ_NT_OUT
 #define OBJ_NT_OUT 1         // sigma / rgb output stores carry the non-temporal hint
@@ -343,7 +343,7 @@ template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream>
 __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier) {
   constexpr int NS = (KS + 7) / 8;
   constexpr int SPC = kChunkTiles / NT / 8;      // s-steps per chunk
-  constexpr int G = (OBJ_B3_PAIR && NT >= 2) ? 2 : 1;      // out tiles whose products are interleaved
+  constexpr int G = OBJ_B3_GROUP < NT ? OBJ_B3_GROUP : NT;      // out tiles whose products are interleaved
   constexpr int NGRP = NT / G;
   // DMA pieces per MFMA group (spread mode): front-loaded into the first half of the chunk's groups, so that the last
   // piece has half a chunk to land before the (early) barrier that opens its chunk
