@@ -72,6 +72,10 @@ int objnerf_pack_weights_b3(int use_voxel, const uint32_t* blob_idx, const float
 int64_t objnerf_bwd_blob_floats(void);
 int objnerf_pack_index_bwd(int use_voxel, uint32_t* h_blob_idx);
 int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream);
+/* the same stream for the split-bf16 mode (objnerf_train_args.mfma_bf16x3): idx has objnerf_bwd_blob_floats() entries,
+ * the blob 6 bytes per entry */
+int objnerf_pack_index_bwd_b3(int use_voxel, uint32_t* h_blob_idx);
+int objnerf_pack_weights_bwd_b3(const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob, void* stream);
 
 /* ---- stage entry points ---- */
 
@@ -317,6 +321,9 @@ typedef struct {
   const float* rays; const float* z_vals; int64_t n_rays; int32_t S; int32_t _pad;
   const float* codes; int64_t code_stride;
   objnerf_voxel_grid grid;
+  /* blob / blob_bwd are split-bf16 streams (objnerf_pack_weights_b3 / objnerf_pack_weights_bwd_b3): the fused forward
+   * (fused inputs required) and the fused dgrad chain run in the split-bf16 arithmetic mode; the GEMMs stay fp32 */
+  int32_t mfma_bf16x3;
 } objnerf_train_args;
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points);
 int64_t objnerf_train_scratch_floats(int64_t n_points);

@@ -71,6 +71,7 @@ class TrainArgs(C.Structure):
         ("rays", C.c_void_p), ("z_vals", C.c_void_p), ("n_rays", C.c_int64), ("S", C.c_int32), ("_pad", C.c_int32),
         ("codes", C.c_void_p), ("code_stride", C.c_int64),
         ("grid", VoxelGrid),
+        ("mfma_bf16x3", C.c_int32),
     ]
 
 
@@ -131,6 +132,8 @@ SIGNATURES = {
     "objnerf_bwd_blob_floats": (C.c_int64, []),
     "objnerf_pack_index_bwd": (C.c_int, [C.c_int, _VP]),
     "objnerf_pack_weights_bwd": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),
+    "objnerf_pack_index_bwd_b3": (C.c_int, [C.c_int, _VP]),
+    "objnerf_pack_weights_bwd_b3": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),
     "objnerf_sample_coarse": (C.c_int, [_VP, _VP, _VP, C.c_float, C.c_int, C.c_int64, C.c_int, _VP, _VP]),
     "objnerf_pos_encode": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
     "objnerf_voxel_embed": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP]),

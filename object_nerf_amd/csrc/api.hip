@@ -190,6 +190,33 @@ int objnerf_pack_index_bwd(int use_voxel, uint32_t* blob_idx) {
   return 0;
 }
 
+int objnerf_pack_index_bwd_b3(int use_voxel, uint32_t* blob_idx) {
+  if (!blob_idx) return set_error(-1, "pack_index_bwd_b3: null output");
+  const bool vox = use_voxel != 0;
+  const long n = objnerf_bwd_blob_floats();
+  for (long i = 0; i < n; ++i) blob_idx[i] = kPackZero;
+  for (int l = 0; l < BL_COUNT; ++l) {
+    const int nt = bwd_nt(l), spc = b3_steps_per_chunk(nt), ks_n = bwd_ks(l), ns = ks_n / 8;
+    if (ks_n % 8 != 0 || (ns + spc - 1) / spc != bwd_chunks(l)) return set_error(-3, "pack_index_bwd_b3: layout self-check failed");
+    const int p = bwd_param(l);
+    const ParamShape sh = param_shape(vox, p);
+    const int col0 = bwd_col0(vox, l);
+    const long base = (long)bwd_chunk_start(l) * kChunkFloats;
+    for (int s = 0; s < ns; ++s) {
+      const int chunk = s / spc, sl = s % spc;
+      for (int m = 0; m < nt; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int in_feat = col0 + 32 * m + (lane & 31);
+            const int out_feat = hid_feat(8 * s + j, lane >> 5);
+            blob_idx[base + (long)chunk * kChunkFloats + ((long)(sl * nt + m) * 64 + lane) * 8 + j] =
+                enc(2 * p, (long)out_feat * sh.in + in_feat);
+          }
+    }
+  }
+  return 0;
+}
+
 int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (!a || !a->blob || !a->aux) return set_error(-1, "mlp_eval: null weights");
   if ((a->emb_xyz == nullptr ? a->n_rays * (int64_t)a->S : a->n_points) == 0) return 0;   // nothing to do

@@ -869,7 +869,7 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 // ---------------------------------------------------------------------------------------------
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles, float* const save_ws = nullptr) {
-  static_assert(!B3 || (FUSED && !SAVE && !SIGMA_ONLY), "split-bf16 mode: fused inference form only");
+  static_assert(!B3 || (FUSED && !SIGMA_ONLY), "split-bf16 mode: fused form only");
   constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");

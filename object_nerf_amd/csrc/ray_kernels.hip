@@ -756,6 +756,19 @@ int objnerf_pack_weights_b3(int use_voxel, const uint32_t* blob_idx, const float
   return check_launch("pack_weights_b3");
 }
 
+int objnerf_pack_weights_bwd_b3(const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob, void* stream) {
+  if (!blob_idx || !h_param_ptrs || !blob) return set_error(-1, "pack_weights_bwd_b3: bad arguments");
+  ParamPtrs pp;
+  for (int i = 0; i < kNumParamPtrs; ++i) {
+    if (!h_param_ptrs[i]) return set_error(-1, "pack_weights_bwd_b3: null parameter pointer");
+    pp.p[i] = h_param_ptrs[i];
+  }
+  const long n = objnerf_bwd_blob_floats();
+  hipLaunchKernelGGL(pack_b3_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, n, pp,
+                     (uint16_t*)blob);
+  return check_launch("pack_weights_bwd_b3");
+}
+
 int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream) {
   if (!blob_idx || !h_param_ptrs || !blob) return set_error(-1, "pack_weights_bwd: bad arguments");
   ParamPtrs pp;

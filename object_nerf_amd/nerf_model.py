@@ -53,12 +53,13 @@ def _pack_index_b3(use_voxel, device):
     return _index_cache[key]
 
 
-def _pack_index_bwd(use_voxel, device):
-    key = ("bwd", bool(use_voxel), str(device))
+def _pack_index_bwd(use_voxel, device, b3=False):
+    key = ("bwd_b3" if b3 else "bwd", bool(use_voxel), str(device))
     if key not in _index_cache:
         l = _lib.lib()
         bi = torch.empty(l.objnerf_bwd_blob_floats(), dtype=torch.int32)
-        _lib.check(l.objnerf_pack_index_bwd(int(use_voxel), C.c_void_p(bi.data_ptr())), "pack_index_bwd")
+        fn = l.objnerf_pack_index_bwd_b3 if b3 else l.objnerf_pack_index_bwd
+        _lib.check(fn(int(use_voxel), C.c_void_p(bi.data_ptr())), "pack_index_bwd")
         _index_cache[key] = bi.to(device)
     return _index_cache[key]
 
@@ -180,13 +181,24 @@ class ObjectNeRF(nn.Module):
         self._packed, self._packed_key = (blob, aux), key
         return self._packed
 
-    def packed_bwd(self):
+    def packed_bwd(self, split_bf16=False):
         """Training only: device tensor with the transposed hidden-block weight stream of the fused backward
-        (objnerf_pack_weights_bwd), re-gathered like `packed()` when a parameter changed."""
+        (objnerf_pack_weights_bwd[_b3]), re-gathered like `packed()` when a parameter changed."""
         params = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (bool(split_bf16),) + tuple((p.data_ptr(), p._version) for p in params)
         if self._packed_bwd is not None and key == self._packed_bwd_key:
             return self._packed_bwd
+        if split_bf16:
+            dev = params[0].device
+            _lib.require_cuda(params[0], "ObjectNeRF parameters")
+            l = _lib.lib()
+            srcs = [_lib.as_f32(p.detach()) for p in params]
+            idx = _pack_index_bwd(int(self.use_voxel_embedding), dev, b3=True)
+            blob = torch.empty(l.objnerf_bwd_blob_floats() * 6 // 4, dtype=torch.float32, device=dev)
+            table = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+            _lib.check(l.objnerf_pack_weights_bwd_b3(_lib.ptr(idx), table, _lib.ptr(blob), _lib.stream_ptr()), "pack_weights_bwd_b3")
+            self._packed_bwd, self._packed_bwd_key = blob, key
+            return blob
         dev = params[0].device
         _lib.require_cuda(params[0], "ObjectNeRF parameters")
         l = _lib.lib()

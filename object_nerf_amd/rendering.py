@@ -90,11 +90,13 @@ def _train_packs(coarse, fine):
     if mode == "1":
         return None
 
+    b3 = mfma_mode() == "bf16x3"      # split-bf16 arithmetic in the two fused kernels (the GEMMs stay fp32 MFMA)
+
     def one(m):
         if m is None:
             return None
-        blob, aux = m.packed()
-        return (None if mode == "fwd" else blob, aux, None if mode == "bwd" else m.packed_bwd())
+        blob, aux = m.packed(split_bf16=b3)
+        return (None if mode == "fwd" else blob, aux, None if mode == "bwd" else m.packed_bwd(split_bf16=b3), b3)
     return (one(coarse), one(fine))
 
 

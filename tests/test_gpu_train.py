@@ -134,6 +134,14 @@ def test_render_rays_gradients_match_oracle_autograd(case):
     print(case, "worst parameter-gradient rel L2 error %.2e" % worst)
 
 
+@pytest.mark.parametrize("case", ["voxel_train", "plain_train"])
+def test_gradients_in_split_bf16_mode(case, monkeypatch):
+    """OBJNERF_MFMA=bf16x3 also switches the two fused training kernels (forward with saved activations, dgrad chain)
+    to the split-bf16 arithmetic; the GEMMs stay fp32.  Same oracle comparison, same tolerances."""
+    monkeypatch.setenv("OBJNERF_MFMA", "bf16x3")
+    test_render_rays_gradients_match_oracle_autograd(case)
+
+
 def test_training_step_updates_weights_and_repacks():
     """an optimizer step on the HIP gradients changes the render, through the automatic weight repack"""
     sc = cases.scene_for(A, "plain", device=DEV)
