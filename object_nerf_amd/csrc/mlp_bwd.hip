@@ -90,6 +90,10 @@ struct BwdHook {
   RawTiles& raw;
   MaskBits<NTOUT>& bits;
   const Stage& sg;
+  // (per-group spreading of the stores, as the forward's SaveHook does, overflows this kernel's register budget:
+  // gradient in + gradient out + raw activation tiles leave no room for the store temporaries mid-layer)
+  template <int GI>
+  __device__ __forceinline__ void group() const {}
   template <int C>
   __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {
     if constexpr (C == 0) {

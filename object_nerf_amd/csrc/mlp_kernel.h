@@ -239,6 +239,7 @@ __device__ __forceinline__ void load_group(ATiles<NT>& a, Stream& st) {
 // prefetches there.
 struct NoHook {
   template <int C> __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {}
+  template <int GI> __device__ __forceinline__ void group() const {}     // in front of the layer's GI-th MFMA group
 };
 // ZERO: acc = W * B instead of acc += W * B (the first k-step's MFMA takes the constant 0 as its C operand; the
 // accumulators need no initialisation pass).
@@ -273,6 +274,7 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
     constexpr int ks0 = g * 4;
     ATiles<NT>& a = abuf[g & 1];
     pieces(std::integral_constant<int, g % GPC>{});              // group g's share (after the barrier that opened its chunk)
+    after_barrier.template group<g>();
     if constexpr (g + 1 < NG4) {
       load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
       if constexpr (((g + 1) * 4) % KG == 0) after_barrier(std::integral_constant<int, ((g + 1) * 4) / KG>{});
@@ -409,6 +411,7 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
       // that opened the next chunk has already selected the chunk after it: its pieces start with that group's successor)
       if constexpr (OBJ_B3_SPREAD_DMA && !last_of_chunk)
         static_for<PPI>([&](auto Q) __attribute__((always_inline)) { st.template piece_now<it * PPI + decltype(Q)::value>(); });
+      after_barrier.template group<gi>();
       // keep the loads above the MFMAs below (the compiler otherwise sinks them to their first use: exposed LDS latency)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (grp == 0 && s + 1 < NS) split(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1]);
@@ -802,13 +805,12 @@ struct Stage {
   int lane;
 };
 template <int NT>
-__device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, long ld, const Stage& sg) {
+__device__ __forceinline__ void save_tile(const f32x16 (&h)[NT], int t, float* mat, long ld, const Stage& sg) {
 #ifdef OBJ_ABL_NOSAVE         // timing ablation only
   return;
 #endif
   const int pt = sg.lane & 31, half = sg.lane >> 5, q = sg.lane >> 3, k = sg.lane & 7;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 v = {h[t][4 * g], h[t][4 * g + 1], h[t][4 * g + 2], h[t][4 * g + 3]};
@@ -830,6 +832,11 @@ __device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, lo
     }
   }
 }
+template <int NT>
+__device__ __forceinline__ void save_tiles(const f32x16 (&h)[NT], float* mat, long ld, const Stage& sg) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) save_tile<NT>(h, t, mat, ld, sg);
+}
 template <bool ON, int NT>
 struct SaveHook {      // layer_mac after-barrier hook: write h (the layer's input = the previous layer's output)
   const f32x16 (&h)[NT];
@@ -837,8 +844,11 @@ struct SaveHook {      // layer_mac after-barrier hook: write h (the layer's inp
   long ld;
   const Stage& sg;
   template <int C>
-  __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {
-    if constexpr (ON && C == 0) save_tiles<NT>(h, mat, ld, sg);
+  __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {}
+  // one tile per MFMA group (a burst of all NT tiles' stores stalls the issuing wave like a burst of DMA pieces does)
+  template <int GI>
+  __device__ __forceinline__ void group() const {
+    if constexpr (ON && GI < NT) save_tile<NT>(h, GI, mat, ld, sg);
   }
 };
 // saved-activation matrices, floats per point: scene 8 x 256 | final 256 | dir hidden 128 | (4 unused) |
