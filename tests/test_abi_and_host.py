@@ -90,6 +90,10 @@ def test_other_weight_streams_reference_the_right_elements(use_voxel):
             "xyz_encoding_5.0", "xyz_encoding_4.0", "xyz_encoding_3.0", "xyz_encoding_2.0", "inst_dir_encoding.0",
             "instance_encoding_final.0", "instance_encoding_4.0", "instance_encoding_3.0", "instance_encoding_2.0"}
     assert ids == {2 * names.index(n) for n in want}
+    # its split-bf16 layout streams the same elements
+    bw3 = torch.empty(nbw, dtype=torch.int32)
+    _lib.check(l.objnerf_pack_index_bwd_b3(use_voxel, C.c_void_p(bw3.data_ptr())), "pack_index_bwd_b3")
+    assert (np.sort(bw3.numpy().view("uint32")) == np.sort(w)).all()
 
 
 def test_module_types_and_state_dict_names():
