@@ -4,6 +4,7 @@ The library is the product: there is NO CPU / PyTorch fallback.  If the shared o
 missing or a call fails, a RuntimeError is raised.
 """
 import ctypes as C
+import functools
 import os
 
 import torch
@@ -191,7 +192,28 @@ def check(rc, what=""):
 
 
 def stream_ptr():
+    """torch's current stream on the CURRENT device; entry points run under `on_device_of`, which makes the
+    tensors' device current first (the library sizes its grids from hipGetDevice())."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device_of(pick):
+    """Decorator for the public entry points: run the call with the device of `pick(*args, **kwargs)` (a tensor)
+    current, so that rays / models on cuda:1 work while cuda:0 is the current device, as they do with the
+    PyTorch reference (launch stream, grid sizing and allocations all follow the current device)."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            try:
+                t = pick(*args, **kwargs)
+            except (IndexError, KeyError, TypeError):
+                t = None
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index != torch.cuda.current_device():
+                with torch.cuda.device(t.device):
+                    return fn(*args, **kwargs)
+            return fn(*args, **kwargs)
+        return wrapper
+    return deco
 
 
 def ptr(t):

@@ -31,18 +31,25 @@ __device__ __forceinline__ float wscan_add(float v, int lane) {
 //     dL/da_i = T_i g_i - (sum_{j>i} w_j g_j) / (1 - a_i + 1e-10)
 //     dL/ds_i = dL/da_i * delta_i * exp(-delta_i relu(s_i)) * [s_i > 0]          (0 where the alpha was masked)
 //     dL/dc_i = w_i gC
-// Two forward sweeps (the first accumulates V = sum w_j g_j, the second turns running prefixes into the suffix
-// sums), so no reverse scan and no per-ray storage is needed.
+// Two forward sweeps.  The first leaves the sum of w_j g_j over chunk c (64 samples) in lane c of `vchunk`; the second
+// builds  sum_{j>i} w_j g_j  = (chunks after i's) + (exclusive REVERSE scan inside i's chunk) from those -- sums of the
+// terms behind sample i only.  (Taking it as V - prefix cancels behind an opaque surface, where the suffix is ~0 and is
+// then divided by t ~ 1e-10.)  No per-ray storage; S <= 4096.
+__device__ __forceinline__ float wscan_add_rev_excl(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_down(v, o); if (lane + o < 64) v += t; }
+  const float e = __shfl_down(v, 1);
+  return lane == 63 ? 0.f : e;
+}
 __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ z, const float* __restrict__ sigma,
                                                   const float* __restrict__ rgb, const float* __restrict__ noise,
                                                   float noise_std, float last_delta, int S, int lane, bool occl,
                                                   float occl_limit, float gC0, float gC1, float gC2, float gD, float go,
                                                   float* __restrict__ d_sigma, float* __restrict__ d_rgb) {
-  float V = 0.f;
+  float vchunk = 0.f;
   for (int sweep = 0; sweep < 2; ++sweep) {
-    float carry = 1.f, run = 0.f;          // transmittance / sum_{j < base} w_j g_j
-    float vpart = 0.f;
-    for (int base = 0; base < S; base += 64) {
+    float carry = 1.f;                     // transmittance in front of the chunk
+    for (int base = 0, c = 0; base < S; base += 64, ++c) {
       const int i = base + lane;
       const bool in = i < S;
       float zi = 0.f, alpha = 0.f, dads = 0.f, gi = 0.f;
@@ -65,20 +72,19 @@ __device__ __forceinline__ void composite_bwd_ray(const float* __restrict__ z, c
       const float w = alpha * T;
       const float v = in ? w * gi : 0.f;
       if (sweep == 0) {
-        vpart += v;
+        const float tot = wsum(v);
+        if (lane == c) vchunk = tot;
       } else {
-        const float pin = wscan_add(v, lane);                 // inclusive prefix inside the chunk
+        const float later = wsum(lane > c ? vchunk : 0.f);     // chunks behind this one
+        const float suffix = later + wscan_add_rev_excl(v, lane);
         if (in) {
-          const float suffix = V - (run + pin);                // sum_{j > i} w_j g_j
           const float dLda = T * gi - suffix / t;
           d_sigma[i] = dLda * dads;
           d_rgb[i * 3] = w * gC0; d_rgb[i * 3 + 1] = w * gC1; d_rgb[i * 3 + 2] = w * gC2;
         }
-        run += __shfl(pin, 63);
       }
       carry = carry * __shfl(incl, 63);
     }
-    if (sweep == 0) V = wsum(vpart);
   }
 }
 
@@ -271,6 +277,7 @@ int objnerf_composite_backward(const objnerf_composite_args* fwd, const float* g
                                float* d_inst_rgb, void* stream) {
   if (!fwd || !fwd->z_vals || !fwd->sigma || !fwd->rgb || !d_sigma || !d_rgb)
     return set_error(-1, "composite_backward: bad arguments");
+  if (fwd->S > 4096) return set_error(-1, "composite_backward: at most 4096 samples per ray");
   if (fwd->inst_sigma && (!fwd->inst_rgb || !d_inst_sigma || !d_inst_rgb))
     return set_error(-1, "composite_backward: instance gradients missing");
   if (fwd->noise_std != 0.f && (!fwd->noise || (fwd->inst_sigma && !fwd->noise_inst)))

@@ -35,6 +35,7 @@ class Embedding(nn.Module):
         self.out_channels = in_channels * (len(self.funcs) * N_freqs + 1)
         self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)   # plain attribute, like the reference
 
+    @_lib.on_device_of(lambda self, x: x)
     def forward(self, x):
         _lib.require_cuda(x, "Embedding input")
         if torch.is_grad_enabled() and x.requires_grad:
@@ -116,11 +117,13 @@ class EmbeddingVoxel(nn.Module):
 
     # ---- device view for the kernels --------------------------------------------------------
     def grid_struct(self):
-        """objnerf_voxel_grid for the current device state (int32 copy of the int64 index map is
-        cached per buffer version)."""
+        """objnerf_voxel_grid for the current device state.  The int32 copy of the int64 index map and the host copies
+        of the grid scalars are cached per buffer version (all four buffers are part of the key); the fp32-contiguous
+        view of the table is kept on `self` so that a converted copy (a .half()/.double() table) outlives the launch
+        that reads it.  `invalidate_grid_cache()` after in-place writes through `.data` (they do not bump `_version`)."""
         m = self.voxel_idx_map
         _lib.require_cuda(m, "EmbeddingVoxel buffers")
-        key = (m.data_ptr(), m._version)
+        key = tuple((b.data_ptr(), b._version) for b in (m, self.voxel_shape, self.voxel_offset, self.voxel_size))
         if self._idx32 is None or key != self._idx32_key:
             self._idx32 = m.to(torch.int32).contiguous()
             self._idx32_key = key
@@ -128,9 +131,10 @@ class EmbeddingVoxel(nn.Module):
             self._host = (tuple(int(v) for v in self.voxel_shape.tolist()),
                           tuple(float(v) for v in self.voxel_offset.tolist()), float(self.voxel_size.item()))
         table = self.embedding_space_ftr.weight
+        self._table32 = _lib.as_f32(table.detach())      # same storage for an fp32 contiguous table, else a kept copy
         g = _lib.VoxelGrid()
         g.idx_map = self._idx32.data_ptr()
-        g.table = _lib.as_f32(table.detach()).data_ptr()
+        g.table = self._table32.data_ptr()
         shape, off, vs = self._host
         if tuple(self._idx32.shape) != shape:
             raise RuntimeError("voxel_idx_map shape does not match voxel_shape")
@@ -141,6 +145,11 @@ class EmbeddingVoxel(nn.Module):
         g.n_rows = table.shape[0]
         return g
 
+    def invalidate_grid_cache(self):
+        self._idx32 = None
+        self._idx32_key = None
+
+    @_lib.on_device_of(lambda self, xyz: xyz)
     def forward(self, xyz):
         _lib.require_cuda(xyz, "EmbeddingVoxel input")
         if torch.is_grad_enabled() and (xyz.requires_grad or self.embedding_space_ftr.weight.requires_grad):

@@ -97,6 +97,7 @@ def _composite(l, zs, sigmas, rgbs, noise_std, white_back, want_ids, want_own, n
     return out, own
 
 
+@_lib.on_device_of(lambda *a, **k: (k["rays_list"] if "rays_list" in k else a[3])[0])
 def render_rays_multi(
     models: Dict[str, Any],
     embeddings: Dict[str, torch.nn.Module],
@@ -125,8 +126,14 @@ def render_rays_multi(
     rays_c = []
     for r in rays_list:
         _lib.require_cuda(r, "rays_list entry")
-        r = _lib.as_f32(r)
-        rays_c.append(r if r.shape[1] == 8 else r[:, :8].contiguous())
+        if r.dim() != 2 or r.shape[1] != 8:
+            # The reference also accepts 10 columns (bbox_mask_near / far clamp the fine depths,
+            # multi_rendering.py:277-285); its callers only ever build 8 (editable_renderer.py:160,177-179) and that
+            # variant is not built here -- silently dropping the two columns would change the result
+            raise NotImplementedError("render_rays_multi: ray sets must be (N, 8) [o, d, near, far]; got %s. The "
+                                      "10-column bbox-clamp variant of the reference is not implemented."
+                                      % (tuple(r.shape),))
+        rays_c.append(_lib.as_f32(r))
     n = rays_c[0].shape[0]
     dev = rays_c[0].device
     if any(r.shape[0] != n for r in rays_c):

@@ -16,6 +16,7 @@ specialised for the architecture every shipped reference config uses
 (config/default_conf.yml:7-36); other widths/depths are rejected loudly.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -131,6 +132,31 @@ class ObjectNeRF(nn.Module):
         self._packed_b3_key = None
 
     # ---- weight stream ---------------------------------------------------------------------
+    def invalidate_packed(self):
+        """Drops the cached weight streams.  They are re-gathered automatically when a parameter's
+        (data_ptr, _version) changes -- optimizer steps, load_state_dict, .to() -- but in-place writes made through
+        `.data` (`p.data.copy_(w)`, EMA / weight-clipping code, some manual checkpoint loaders) do not bump
+        `_version`: call this after them.  OBJNERF_PACK_CHECK=1 adds a content checksum to the cache key (one small
+        reduction + host read per parameter set and call: a debugging aid, not for production)."""
+        self._packed = self._packed_key = None
+        self._packed_bwd = self._packed_bwd_key = None
+        self._packed_b3 = self._packed_b3_key = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _pack_key(self, params):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if os.environ.get("OBJNERF_PACK_CHECK") == "1":
+            with torch.no_grad():
+                key += (float(sum(p.detach().double().sum() for p in params)),)
+        return key
+
     def _param_list(self):
         mods = dict(self.named_modules())
         out = []
@@ -144,7 +170,7 @@ class ObjectNeRF(nn.Module):
         (optimizer step, load_state_dict, .to()) -- keyed on (data_ptr, _version).
         split_bf16: the blob of the split-bf16 arithmetic mode (rendering.mfma_mode()); aux is shared."""
         params = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = self._pack_key(params)
         if split_bf16:
             _, aux = self.packed()
             if self._packed_b3 is None or key != self._packed_b3_key:
@@ -185,7 +211,7 @@ class ObjectNeRF(nn.Module):
         """Training only: device tensor with the transposed hidden-block weight stream of the fused backward
         (objnerf_pack_weights_bwd[_b3]), re-gathered like `packed()` when a parameter changed."""
         params = self._param_list()
-        key = (bool(split_bf16),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (bool(split_bf16),) + self._pack_key(params)
         if self._packed_bwd is not None and key == self._packed_bwd_key:
             return self._packed_bwd
         if split_bf16:
@@ -218,6 +244,7 @@ class ObjectNeRF(nn.Module):
                 "object_nerf_amd: the HIP path is forward-only in this round (backward = SURVEY §8 row f1). "
                 "Call under torch.no_grad(); there is deliberately no PyTorch fallback.")
 
+    @_lib.on_device_of(lambda self, inputs, *a, **k: inputs["emb_xyz"])
     def _run(self, inputs, scene, sigma_only=False):
         emb_xyz = inputs["emb_xyz"]
         emb_dir = inputs.get("emb_dir", None)

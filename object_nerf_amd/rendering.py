@@ -35,6 +35,7 @@ def _linspace(n, device):
     return _tables[key]
 
 
+@_lib.on_device_of(lambda bins, *a, **k: bins)
 def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5, u=None):
     """models/rendering.py:11-61.  `u` (N_rays, N_importance) optionally injects the uniform draws
     used when det=False (tests); otherwise they are drawn with torch.rand like the reference."""
@@ -100,6 +101,7 @@ def _train_packs(coarse, fine):
     return (one(coarse), one(fine))
 
 
+@_lib.on_device_of(lambda *a, **k: k["rays"] if "rays" in k else a[2])
 def render_rays(
     models: Dict[str, Any],
     embeddings: Dict[str, Any],
@@ -210,21 +212,22 @@ def render_rays(
         rin.u_det = _linspace(I, dev).data_ptr()
     # random draws (training mode only), same distributions as rendering.py:276, 40, 156, 187
     if perturb > 0:
-        pr = randoms["perturb_rand"] if randoms else torch.rand(n, S, device=dev)
+        # the CONVERTED tensors are the ones kept alive until the launch is enqueued: as_f32 may copy
+        pr = _lib.as_f32(randoms["perturb_rand"] if randoms else torch.rand(n, S, device=dev))
         keep.append(pr)
-        rin.perturb_rand = _lib.as_f32(pr).data_ptr()
+        rin.perturb_rand = pr.data_ptr()
         if I > 0:
-            ur = randoms["u_rand"] if randoms else torch.rand(n, I, device=dev)
+            ur = _lib.as_f32(randoms["u_rand"] if randoms else torch.rand(n, I, device=dev))
             keep.append(ur)
-            rin.u_rand = _lib.as_f32(ur).data_ptr()
+            rin.u_rand = ur.data_ptr()
     if noise_std != 0:
         shapes = [(n, S), (n, S), (n, S + I), (n, S + I)]
         for k in range(4 if I > 0 else 2):
             if not forward_instance and (k & 1):
                 continue
-            nz = randoms["noise"][k] if randoms else torch.randn(*shapes[k], device=dev)
+            nz = _lib.as_f32(randoms["noise"][k] if randoms else torch.randn(*shapes[k], device=dev))
             keep.append(nz)
-            rin.noise[k] = _lib.as_f32(nz).data_ptr()
+            rin.noise[k] = nz.data_ptr()
     rin.workspace = ws.data_ptr()
 
     oc = _alloc_out(n, S, dev, forward_instance)

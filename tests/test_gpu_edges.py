@@ -111,3 +111,49 @@ def test_non_contiguous_and_float64_inputs_are_accepted():
                           noise_std=0, embedding_instance=codes, is_eval=True)
     for k in a:
         assert a[k].dtype == torch.float32 and torch.equal(a[k], b[k]), k
+
+
+def test_ten_column_ray_sets_are_rejected_not_truncated():
+    """multi_rendering.py:277-285 clamps the fine depths with columns 8:10; that variant is not built, so it must not be
+    silently rendered as the 8-column one"""
+    sc = scene("voxel")
+    base, _ = cases.multi_inputs()
+    wide = [torch.cat([s, s[:, 6:8]], 1).to(DEV) for s in base]
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="10-column"):
+        render_rays_multi(sc.models, sc.embeddings, sc.code_library, wide, [0, 4, 4], N_samples=8, N_importance=0)
+
+
+def test_random_inputs_in_other_dtypes_are_kept_alive_and_used():
+    """the `_randoms` hook / callers may hand float64 draws: the converted copies (not the originals) must be the
+    buffers the kernels read (a freed temporary could alias an output)"""
+    sc = scene("plain")
+    n, S, I = 40, 32, 32
+    rays = H.test_rays(n).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    rnd = dict(perturb_rand=torch.rand(n, S, generator=g), u_rand=torch.rand(n, I, generator=g),
+               noise=[torch.randn(n, S, generator=g), torch.randn(n, S, generator=g),
+                      torch.randn(n, S + I, generator=g), torch.randn(n, S + I, generator=g)])
+    kw = dict(N_samples=S, N_importance=I, perturb=1.0, noise_std=1.0, is_eval=False, frustum_bound_th=0.025)
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": synth.per_ray_ids(n).to(DEV)})["embedding_instance"]
+        f32 = dict(perturb_rand=rnd["perturb_rand"].to(DEV), u_rand=rnd["u_rand"].to(DEV), noise=[t.to(DEV) for t in rnd["noise"]])
+        f64 = dict(perturb_rand=rnd["perturb_rand"].double().to(DEV), u_rand=rnd["u_rand"].double().to(DEV),
+                   noise=[t.double().to(DEV) for t in rnd["noise"]])
+        a = A.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, _randoms=f32, **kw)
+        b = A.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, _randoms=f64, **kw)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_invalidate_packed_after_data_writes():
+    """in-place writes through `.data` do not bump `_version`: the cached weight stream is stale until
+    invalidate_packed() (or OBJNERF_PACK_CHECK=1) -- documented contract of nerf_model.ObjectNeRF.packed()"""
+    sc = cases.scene_for(A, "plain", device=DEV)
+    rays = H.test_rays(8).to(DEV)
+    kw = dict(N_samples=16, N_importance=0, perturb=0, noise_std=0, embedding_instance=torch.zeros(8, 64, device=DEV), is_eval=True)
+    with torch.no_grad():
+        a = A.render_rays(sc.models, sc.embeddings, rays, **kw)["rgb_coarse"].clone()
+        sc.models["coarse"].rgb[0].bias.data.add_(0.5)
+        sc.models["coarse"].invalidate_packed()
+        b = A.render_rays(sc.models, sc.embeddings, rays, **kw)["rgb_coarse"]
+    assert (a - b).abs().max().item() > 1e-3

@@ -289,3 +289,46 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
         worst = max(worst, rel_l2(u, v))
     assert worst < 1e-5, worst
     print(sname, fi, "fused dgrad chain vs GEMM chain: worst rel L2 %.2e" % worst)
+
+
+@pytest.mark.parametrize("S", [128, 192])
+def test_composite_backward_opaque_surface(S):
+    """objnerf_composite_backward at fine-pass sample counts with an OPAQUE slab in the middle of every ray (alpha rounds
+    to exactly 1 there, the transmittance factor 1 - alpha + 1e-10 is 1e-10, and everything behind it has ~zero weight)
+    against float64 autograd through the oracle's compositing.  The suffix sums of the backward are divided by that
+    1e-10: they must be sums of the terms behind the sample, not `total - prefix` (cancellation)."""
+    n = 64
+    g = torch.Generator().manual_seed(S)
+    z = torch.sort(0.2 + 2.5 * torch.rand(n, S, generator=g), -1)[0]
+    sigma = 3.0 * torch.randn(n, S, generator=g)
+    isig = 3.0 * torch.randn(n, S, generator=g)
+    for r in range(n):
+        a = 20 + (r * 7) % (S - 60)
+        sigma[r, a:a + 3] = 1e6                       # fully opaque
+        isig[r, a + 10:a + 12] = 2e5
+    rgb, irgb = torch.rand(n, S, 3, generator=g), torch.rand(n, S, 3, generator=g)
+    gm = dict(rgb=torch.randn(n, 3, generator=g), depth=torch.randn(n, generator=g), opacity=torch.randn(n, generator=g),
+              rgb_instance=torch.randn(n, 3, generator=g), depth_instance=torch.randn(n, generator=g),
+              opacity_instance=torch.randn(n, generator=g))
+    # float64 autograd
+    leaves = [t.double().clone().requires_grad_(True) for t in (sigma, rgb, isig, irgb)]
+    out = O.composite(z.double(), leaves[0], leaves[1], leaves[2], leaves[3], white_back=True)
+    sum((out[k] * gm[k].double()).sum() for k in gm).backward()
+    # HIP
+    dev = {k: v.to(DEV).contiguous() for k, v in dict(z=z, sigma=sigma, rgb=rgb, isig=isig, irgb=irgb, **{"g_" + k: v for k, v in gm.items()}).items()}
+    a = _lib.CompositeArgs()
+    a.n_rays, a.S = n, S
+    a.z_vals, a.sigma, a.rgb, a.inst_sigma, a.inst_rgb = (dev[k].data_ptr() for k in ("z", "sigma", "rgb", "isig", "irgb"))
+    a.white_back = 1
+    outs = [torch.empty(n, S, device=DEV), torch.empty(n, S, 3, device=DEV), torch.empty(n, S, device=DEV), torch.empty(n, S, 3, device=DEV)]
+    _lib.check(_lib.lib().objnerf_composite_backward(
+        C.byref(a), _lib.ptr(dev["g_rgb"]), _lib.ptr(dev["g_depth"]), _lib.ptr(dev["g_opacity"]), _lib.ptr(dev["g_rgb_instance"]),
+        _lib.ptr(dev["g_depth_instance"]), _lib.ptr(dev["g_opacity_instance"]), *[_lib.ptr(t) for t in outs], _lib.stream_ptr()),
+        "composite_backward")
+    for name, got, leaf in zip(("d_sigma", "d_rgb", "d_inst_sigma", "d_inst_rgb"), outs, leaves):
+        want = leaf.grad
+        assert torch.isfinite(got).all(), name
+        # per ray, relative to the ray's largest gradient entry
+        flat_w, flat_g = want.reshape(n, -1), got.cpu().double().reshape(n, -1)
+        err = ((flat_g - flat_w).abs().max(1)[0] / flat_w.abs().max(1)[0].clamp_min(1e-30)).max().item()
+        assert err < 2e-5, "%s: %.3e" % (name, err)
