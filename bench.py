@@ -1,36 +1,56 @@
 #!/usr/bin/env python
-"""bench.py -- render_rays throughput on MI355X (BASELINE.json metric: ray-samples/sec/GPU).
+"""bench.py -- render_rays / render_rays_multi throughput on MI355X (BASELINE.json metric: ray-samples/sec).
 
-A "step" = one full 640x480 frame (307,200 rays) through render_rays, scene + object branches,
-64 coarse + 64 fine samples, voxel embedding, eval mode (BASELINE.json configs[1]); i.e.
-192 MLP-evaluated sample points ("ray-samples") per ray, 58,982,400 per step.
-Inputs (rays, codes, weights, voxel grid) are resident in HBM before the timed region.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {0,1,2,3,4}] [--scaling {strong,weak}]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank renders
-its own frame of a N-frame batch (rays are independent, no data-path collective inside the
-renderer), then ONE all_gather_into_tensor of the rendered pixels (rgb_fine, 3 floats/ray) over
-RCCL so that every rank holds all frames; that collective is inside the timed region.
+A "step" = one 640x480 frame (307,200 pixels) through the hot path.  A "ray-sample" = one MLP-evaluated sample point
+(SURVEY.md §8d): S + (S + I) per ray.  Inputs (rays, codes, weights, voxel grid) are resident in HBM before the timed
+region.  `--config` selects the BASELINE.json configuration (index into its `configs` list):
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     -- fused MLP kernel, fp32 MFMA bound: algorithmic FLOP (1,776,128 per eval) /
-                  HIP-event time of the kernel launches on the launch stream;
-  cpu_baseline -- the oracle ("port" of the reference's PyTorch path, oracle/objnerf_oracle.py)
-                  timed on the host cores on a bounded sample of the same rays (N=1 only).
+  0  ToyDesk-2 frame, scene branch only, 64 coarse samples (the reference's CPU plumbing case, here on the GPU)
+  1  ToyDesk-2 frame, scene + object branches, 64 + 64                  <- the configuration the metric is quoted on;
+                                                                           DEFAULT at --gpus 1
+  2  ScanNet-0113-multi frame, 5 object codes (per ray), 64 + 128, frustum bound 0.025, rays_in_bbox
+  3  configs[2]'s frame cut into contiguous ray bands over the N ranks + ONE RCCL all-gather of the rendered pixels
+     (rgb, depth, opacity packed in one message)                        <- DEFAULT at --gpus N > 1 (strong scaling)
+  4  the editing demo (duplicating + moving): ray sets [background, object 4, object 4'] generated on the device,
+     render_rays_multi 64 + 64 with the removed-object box, pixels sharded like 3
+
+--gpus N > 1 without a launcher: bench.py starts the N ranks itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, rendezvous on 127.0.0.1).  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it
+uses the launcher's environment instead.  --scaling strong (default for configs 3, 4): ONE frame per step shared by all
+ranks; weak (default for configs 0-2 at N > 1): one frame per rank per step, all frames gathered.  The collective is
+inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with
+  roofline     -- the fused MLP kernel, fp32-MFMA bound: algorithmic FLOP / HIP-event time of its launches on the launch
+                  stream; `traffic` = HBM bytes per launch from rocprofv3 PMC passes run by bench.py itself on the same
+                  workload (N = 1; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), or the latest
+                  committed profile when rocprofv3 is unavailable;
+  cpu_baseline -- the oracle (port of the reference's PyTorch path, oracle/objnerf_oracle.py) timed on the host cores
+                  on a bounded sample of the same workload (N = 1 only), and PSNR of the GPU pixels against it;
+  multi_gpu    -- (N > 1 or --dist) RCCL world size, per-rank render ms, gather ms.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_EVAL_BOTH_VOXEL = 1_776_128
-PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+# algorithmic FLOP per MLP evaluation of one sample point (GEMM FLOP only, 2 x MAC)
+FLOP_BOTH, FLOP_SCENE, FLOP_OBJECT = 1_776_128, 1_399_808, 376_320
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16; the split-bf16 mode spends 6 bf16 products per fp32 product
 
 
 def log(msg):
@@ -38,257 +58,582 @@ def log(msg):
         print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=None, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json configs[] index (default: 1 at --gpus 1, 3 at --gpus N > 1)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None,
+                    help="N > 1: strong = one frame shared by all ranks (default for configs 3, 4), weak = one frame per rank")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--n-importance", type=int, default=64)
+    ap.add_argument("--max-voxels", type=int, default=800_000, help="rows of the voxel feature table (config default 800000)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the CPU baseline sample (0 = skip)")
     ap.add_argument("--split-bf16-steps", type=int, default=2,
                     help="extra, separately reported frames in the opt-in split-bf16 arithmetic mode (0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
+                    help="collect roofline.traffic with two rocprofv3 --pmc passes of this workload (auto: N = 1 and rocprofv3 on PATH)")
+    ap.add_argument("--dist", action="store_true", help="initialise the RCCL process group even at N = 1")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` starts its own N ranks
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv, cmd=None):
+    """Starts ranks 0..N-1 of this script (cmd: the test suite substitutes a stand-in child), waits for all of them and
+    returns the first non-zero exit code (stopping the remaining ranks) or 0."""
+    n = args.gpus
+    if cmd is None:
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+        cmd = [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OBJNERF_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(list(cmd) + list(argv), env=env))
+    rc = 0
+    try:
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    log("rank %d exited with %d: stopping the other ranks" % (r, code))
+                    for q in alive:
+                        procs[q].terminate()          # exact PIDs started above
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the product renderer (the only one the timed region ever uses; a test may inject another through run())
+# ---------------------------------------------------------------------------------------------------------------------
+class HipRenderer:
+    name = "hip"
+
+    def __init__(self, device):
+        import object_nerf_amd as A
+        from object_nerf_amd.multi_rendering import render_rays_multi
+        from object_nerf_amd.ray_utils import generate_rays
+        self.A, self._multi, self._gen = A, render_rays_multi, generate_rays
+        self.device = device
+
+    def render_rays(self, sc, rays, **kw):
+        with torch.no_grad():
+            return self.A.render_rays(sc.models, sc.embeddings, rays, **kw)
+
+    def render_rays_multi(self, sc, rays_list, obj_instance_ids, **kw):
+        with torch.no_grad():
+            return self._multi(sc.models, sc.embeddings, sc.code_library, rays_list, obj_instance_ids, **kw)
+
+    def generate_rays(self, H, W, focal, c2w, near=0.0, far=0.0, box=None, bbox_enlarge=0.0):
+        return self._gen(H, W, focal, c2w, near, far, box=box, bbox_enlarge=bbox_enlarge, device=self.device)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads = BASELINE.json configs
+# ---------------------------------------------------------------------------------------------------------------------
+CONFIG_TEXT = {
+    0: "BASELINE configs[0]: ToyDesk-2 %dx%d frame, scene branch only, %d coarse samples, voxel embedding, eval mode",
+    1: "BASELINE configs[1]: ToyDesk-2 %dx%d frame, scene+object branches, %d coarse + %d fine, voxel embedding, eval mode",
+    2: "BASELINE configs[2]: ScanNet-0113-multi %dx%d frame, 5 object codes (per ray), %d coarse + %d fine, frustum bound "
+       "0.025, rays_in_bbox, voxel embedding, eval mode",
+    3: "BASELINE configs[3]: configs[2]'s %dx%d frame (5 codes, %d + %d), ray bands sharded over the ranks + one RCCL "
+       "all-gather of rgb/depth/opacity",
+    4: "BASELINE configs[4]: demo_editable_render duplicating+moving, %dx%d, ray sets [background, object 4, object 4'] "
+       "generated on the device, render_rays_multi %d + %d, removed-object box, pixel bands sharded over the ranks",
+}
+
+
+class Workload:
+    """One BASELINE config bound to a renderer, a rank and a scaling mode.  step() renders this rank's share of one step
+    and all-gathers the pixels; everything it reads is resident on the device beforehand."""
+
+    def __init__(self, cfg_id, args, R, rank, world, scaling, dist):
+        import object_nerf_amd as A
+        from object_nerf_amd import synth
+        from object_nerf_amd.distributed import shard_bounds
+        self.cfg_id, self.R, self.rank, self.world, self.scaling, self.dist = cfg_id, R, rank, world, scaling, dist
+        self.W, self.H = args.width, args.height
+        dev = R.device
+        self.S = 64
+        self.I = {0: 0, 1: 64, 2: 128, 3: 128, 4: 64}[cfg_id]
+        self.preset = synth.TOYDESK2 if cfg_id in (0, 1) else synth.SCANNET_LIKE
+        self.sc = synth.build_scene(A, use_voxel=True, preset=self.preset, max_voxels=args.max_voxels, device=dev,
+                                    n_importance=max(self.I, 1))
+        self.typ = "fine" if self.I > 0 else "coarse"
+        self.gather_keys = tuple("%s_%s" % (k, self.typ) for k in ("rgb", "depth", "opacity"))
+        n = self.W * self.H
+        self.n_pixels = n                                   # per frame
+        # strong: one frame, this rank's band; weak: this rank's own frame (camera rotated per rank)
+        self.frames_per_step = 1 if (scaling == "strong" or world == 1) else world
+        self.lo, self.hi = shard_bounds(n, rank, world) if scaling == "strong" else (0, n)
+        yaw = 0.0 if scaling == "strong" else 20.0 * rank
+        self.marks = []                                     # (t_start, t_rendered, t_gathered) per step
+        if cfg_id == 4:
+            self.kind = "multi"
+            self.focal, self.poses, self.box = synth.edit_demo_geometry(self.preset, self.W)
+            self.obj_ids = [0, 4, 4]
+            self.kw = dict(N_samples=self.S, N_importance=self.I, perturb=0, noise_std=0, background_skip_bbox={4: self.box})
+            sets = self._ray_sets()
+            R.sync()
+            hit = torch.stack([(s[:, 7] > 0).float().sum() for s in sets]).double()      # evaluated rays of this rank per set
+            self.rank_rays = [float(h) for h in hit.tolist()]
+            self.evals_rank = sum(self.rank_rays) * (self.S + self.S + self.I)
+            self.flop_rank = (self.rank_rays[0] * FLOP_SCENE + sum(self.rank_rays[1:]) * FLOP_OBJECT) * (self.S + self.S + self.I)
+            self.nominal_evals_rank = 3.0 * (self.hi - self.lo) * (self.S + self.S + self.I)
+            self.flop_per_eval = None
+            self.kernel = "objnerf::mlp_kernel<voxel,fused> scene-only (background set) and object-only (object sets) variants"
+        else:
+            self.kind = "rays"
+            rays = synth.preset_rays(self.preset, self.W, self.H, yaw_offset_deg=yaw)
+            with torch.no_grad():
+                if cfg_id in (2, 3):
+                    ids = synth.per_ray_ids(n)                                    # 5 ToyDesk ids, per ray (SURVEY §8d)
+                else:
+                    ids = torch.full((n,), 1, dtype=torch.long)                   # val_instance_id (toy_desk_2.yml:39)
+                codes = self.sc.code_library({"instance_ids": ids.to(dev)})["embedding_instance"]
+            # strong scaling keeps the whole frame on every rank (88 MB) and lets render_rays_sharded cut the band;
+            # weak scaling renders the rank's own whole frame
+            self.rays = rays.to(dev).contiguous()
+            self.codes = codes.contiguous()
+            fi = cfg_id != 0
+            self.kw = dict(N_samples=self.S, N_importance=self.I, perturb=0, noise_std=0, white_back=False,
+                           forward_instance=fi, frustum_bound_th=self.preset["frustum_bound_th"], is_eval=True)
+            if cfg_id in (2, 3):
+                self.kw["rays_in_bbox"] = True
+            self.flop_per_eval = FLOP_BOTH if fi else FLOP_SCENE
+            self.evals_rank = float(self.hi - self.lo) * (self.S + (self.S + self.I if self.I > 0 else 0))
+            self.nominal_evals_rank = self.evals_rank
+            self.flop_rank = self.evals_rank * self.flop_per_eval
+            self.kernel = "objnerf::mlp_kernel<voxel,fused,%s>" % ("scene,object" if fi else "scene")
+        self.evals_per_ray = self.S + (self.S + self.I if self.I > 0 else 0)
+        self.last = None
+
+    def _ray_sets(self, band=True):
+        sets = [self.R.generate_rays(self.H, self.W, self.focal, self.poses[0], self.preset["near"], self.preset["far"])]
+        for p in self.poses[1:]:
+            sets.append(self.R.generate_rays(self.H, self.W, self.focal, p, box=self.box, bbox_enlarge=0.06))
+        return [s[self.lo:self.hi] for s in sets] if band else sets      # contiguous pixel band of every set
+
+    def _mark(self):
+        if self.R.device.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        return time.perf_counter()
+
+    def step(self):
+        """strong scaling: the library's sharded entry points (object_nerf_amd/distributed.py) cut the FULL frame at this
+        rank's bounds, render the band, and all-gather the pixel maps in one collective; weak scaling: this rank's own
+        frame, then the same collective over all frames."""
+        from object_nerf_amd.distributed import gather_pixel_maps, render_rays_multi_sharded, render_rays_sharded
+        t = [self._mark(), None, None]
+
+        def rendered(res):
+            t[1] = self._mark()
+            self.last = res
+        if self.scaling == "strong":
+            if self.kind == "multi":
+                out = render_rays_multi_sharded(
+                    lambda rays_list, **kw: self.R.render_rays_multi(self.sc, rays_list, self.obj_ids, **kw),
+                    self._ray_sets(band=False), gather_keys=self.gather_keys, on_rendered=rendered, **self.kw)
+            else:
+                out = render_rays_sharded(lambda rays, **kw: self.R.render_rays(self.sc, rays, **kw), self.rays,
+                                          {"embedding_instance": self.codes}, gather_keys=self.gather_keys,
+                                          on_rendered=rendered, **self.kw)
+        else:
+            if self.kind == "multi":
+                res = self.R.render_rays_multi(self.sc, self._ray_sets(), self.obj_ids, **self.kw)
+            else:
+                res = self.R.render_rays(self.sc, self.rays, embedding_instance=self.codes, **self.kw)
+            rendered(res)
+            out = gather_pixel_maps({k: res[k] for k in self.gather_keys}, self.n_pixels * self.world)
+        t[2] = self._mark()
+        self.marks.append(tuple(t))
+        return out
+
+    def phase_ms(self):
+        """mean (render ms, gather ms) per step over the recorded marks; call after a synchronise"""
+        if not self.marks:
+            return 0.0, 0.0
+        if self.R.device.type == "cuda":
+            r = [a.elapsed_time(b) for a, b, _ in self.marks]
+            g = [b.elapsed_time(c) for _, b, c in self.marks]
+        else:
+            r = [(b - a) * 1e3 for a, b, _ in self.marks]
+            g = [(c - b) * 1e3 for _, b, c in self.marks]
+        return sum(r) / len(r), sum(g) / len(g)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run(args, renderer=None, backend="nccl", argv=None):
+    """The benchmark proper.  `renderer` / `backend` are injection points for tests/test_bench_gloo.py (CPU, gloo,
+    oracle-backed renderer); the command line always runs the HIP renderer over RCCL."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if renderer is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        renderer = HipRenderer(torch.device("cuda", local_rank))
+    R = renderer
+    dev = R.device
+    on_gpu = dev.type == "cuda"
     dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("OBJNERF_BENCH_FORCE_DIST") == "1":
-        # launched by torch.distributed.run: exercise the RCCL path even at world size 1
+    if world > 1 or args.dist or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
+        if not dist_mod.is_initialized():
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
 
-    import object_nerf_amd as A
-    from object_nerf_amd import synth, _lib
-    from object_nerf_amd.distributed import gather_pixels
-
-    S, I = 64, args.n_importance
-    preset = synth.TOYDESK_LIKE
-    sc = synth.build_scene(A, use_voxel=True, preset=preset, max_voxels=800_000, device=dev, n_importance=I)
-    # rank r renders its own camera (frame r of the batch)
-    rays = synth.camera_rays(args.width, args.height, near=preset["near"], far=preset["far"],
-                             yaw_deg=35.0 + 20.0 * rank).to(dev)
-    n = rays.shape[0]
-    with torch.no_grad():
-        ids = torch.full((n,), 1, dtype=torch.long, device=dev)     # val_instance_id = 1 (config/toy_desk_2.yml:39)
-        codes = sc.code_library({"instance_ids": ids})["embedding_instance"].contiguous()
-    kw = dict(N_samples=S, N_importance=I, perturb=0, noise_std=0, white_back=False, forward_instance=True,
-              embedding_instance=codes, frustum_bound_th=preset["frustum_bound_th"], is_eval=True)
-
-    last = {}
-
-    def step():
-        with torch.no_grad():
-            r = A.render_rays(sc.models, sc.embeddings, rays, **kw)
-            last["rgb_fine"] = r["rgb_fine"]
-            if dist is not None:
-                return gather_pixels(r["rgb_fine"])
-            return r["rgb_fine"]
+    cfg_id = args.config if args.config is not None else (1 if world == 1 else 3)
+    scaling = args.scaling or ("strong" if (cfg_id in (3, 4) or world == 1) else "weak")
+    wl = Workload(cfg_id, args, R, rank, world, scaling, dist)
+    lib = None
+    if on_gpu:
+        from object_nerf_amd import _lib
+        lib = _lib.lib()
 
     def fence():
-        torch.cuda.synchronize()
+        R.sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        R.sync()
 
-    log("scene ready: %d rays/frame, world %d" % (n, world))
+    log("config %d (%s scaling), %d pixels/frame, rays [%d, %d) on rank 0, world %d" % (cfg_id, scaling, wl.n_pixels, wl.lo, wl.hi, world))
     for _ in range(args.warmup):
-        step()
+        wl.step()
     fence()
-    log("warmup done")
-    lib = _lib.lib()
-    lib.objnerf_timing_enable(1)
+    wl.marks.clear()
+    if lib is not None:
+        lib.objnerf_timing_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = wl.step()
     fence()
     t1 = time.perf_counter()
     launches, kms = C.c_int64(0), C.c_double(0.0)
-    lib.objnerf_timing_read(C.byref(launches), C.byref(kms))
-    lib.objnerf_timing_enable(0)
-
+    if lib is not None:
+        lib.objnerf_timing_read(C.byref(launches), C.byref(kms))
+        lib.objnerf_timing_enable(0)
+    render_ms, gather_ms = wl.phase_ms()
     log("timed region done: %.3f s for %d steps" % (t1 - t0, args.steps))
+    if args.pmc_child:            # a rocprofv3 --pmc pass of this workload: the counters are all that is wanted
+        if dist is not None:
+            dist.destroy_process_group()
+        return None
 
-    # Not part of `value`: the same frame in the opt-in split-bf16 arithmetic mode (OBJNERF_MFMA=bf16x3: the fp32
-    # contraction carried out on the bf16 matrix pipe with exactly split operands), reported beside
-    # the fp32-MFMA headline with its distance from the fp32 path's pixels.
-    extra = None
-    if args.split_bf16_steps > 0:
-        ref_rgb = last["rgb_fine"].clone()
-        os.environ["OBJNERF_MFMA"] = "bf16x3"
-        try:
-            step()
-            fence()
-            lib.objnerf_timing_enable(1)
-            tb0 = time.perf_counter()
-            for _ in range(args.split_bf16_steps):
-                step()
-            fence()
-            tb1 = time.perf_counter()
-            bl, bms = C.c_int64(0), C.c_double(0.0)
-            lib.objnerf_timing_read(C.byref(bl), C.byref(bms))
-            lib.objnerf_timing_enable(0)
-            eb = torch.tensor([tb1 - tb0], dtype=torch.float64, device=dev)
-            if dist is not None:
-                dist.all_reduce(eb, op=dist.ReduceOp.MAX)
-            eb = eb.item()
-            mse = ((last["rgb_fine"].double() - ref_rgb.double()) ** 2).mean().item()
-            import math
-            extra = {"value": world * n * (S + S + I) * args.split_bf16_steps / eb, "unit": "ray-samples/s",
-                     "ms_per_step": 1e3 * eb / args.split_bf16_steps, "steps": args.split_bf16_steps,
-                     "dtype": "f32 operands split exactly into 3 x bf16, 6 of 9 products on the bf16 matrix pipe, f32 accumulate",
-                     "mlp_tflops_f32_equivalent": float(n * (S + S + I)) * args.split_bf16_steps * FLOP_PER_EVAL_BOTH_VOXEL / (bms.value / 1e3) / 1e12,
-                     "psnr_vs_f32_mfma_path_db": -10.0 * math.log10(max(mse, 1e-30)),
-                     "max_abs_diff_vs_f32_mfma_path": (last["rgb_fine"] - ref_rgb).abs().max().item()}
-        except Exception as e:      # the optional mode must never cost the headline line
-            extra = {"error": "%s: %s" % (type(e).__name__, e)}
-            try:
-                lib.objnerf_timing_enable(0)
-            except Exception:
-                pass
-        finally:
-            os.environ.pop("OBJNERF_MFMA", None)
-        last["rgb_fine"] = ref_rgb
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    def allreduce(x, op):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return t.item()
+
+    def allgather_list(x):
+        if dist is None:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        o = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(o, t)
+        return o.tolist()
+
+    elapsed = allreduce(t1 - t0, "MAX")
+    evals_job = allreduce(wl.evals_rank, "SUM")               # evaluated sample points of all ranks per step
+    nominal_job = allreduce(wl.nominal_evals_rank, "SUM")
+    per_rank_render = allgather_list(render_ms)
+    per_rank_gather = allgather_list(gather_ms)
+    per_rank_step = allgather_list(1e3 * (t1 - t0) / args.steps)
+
+    # the collective alone (after the timed region): barrier, then 10 back-to-back pixel all-gathers
+    gather_alone_ms = None
     if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = elapsed.item()
-    evals_per_ray = S + (S + I)
-    evals_step_rank = n * evals_per_ray
-    value = world * evals_step_rank * args.steps / elapsed
+        from object_nerf_amd.distributed import gather_pixel_maps
+        local = {k: wl.last[k] for k in wl.gather_keys}
+        n_total = wl.n_pixels if scaling == "strong" else wl.n_pixels * world
+        fence()
+        tg = time.perf_counter()
+        for _ in range(10):
+            gather_pixel_maps(local, n_total)
+        R.sync()
+        gather_alone_ms = allreduce((time.perf_counter() - tg) / 10 * 1e3, "MAX")
+
+    # ---- opt-in split-bf16 arithmetic mode, reported beside the fp32 headline (never part of `value`) ----
+    extra = None
+    if on_gpu and args.split_bf16_steps > 0:
+        extra = split_bf16_leg(wl, args, lib, fence, allreduce, evals_job)
 
     res = None
     if rank == 0:
-        mlp_s = kms.value / 1e3
-        flop = float(evals_step_rank) * args.steps * FLOP_PER_EVAL_BOTH_VOXEL
-        achieved = flop / mlp_s / 1e12 if mlp_s > 0 else 0.0
+        value = evals_job * args.steps / elapsed
         res = {
-            "metric": "ray-samples/sec (MLP-evaluated sample points, 64c+64f, scene+object, 256-wide MLP)",
+            "metric": "ray-samples/sec (MLP-evaluated sample points, 64c+64f, scene+object, 256-wide MLP)" if cfg_id == 1 else
+                      "ray-samples/sec (MLP-evaluated sample points)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ToyDesk-2-like %dx%d frame per GPU, scene+object branches, "
-                                   "%d coarse + %d fine, voxel embedding (800000x24 table), eval mode, W1 random-init weights"
-                                   % (args.width, args.height, S, I),
-                       "rays_per_step_per_gpu": n, "evals_per_ray": evals_per_ray,
-                       "rays_per_s": world * n * args.steps / elapsed,
-                       "collective": "all_gather_into_tensor(rgb_fine) over RCCL" if dist is not None else "none"},
-            "roofline": {"bound": "mfma", "kernel": "objnerf::mlp_kernel<voxel,fused,scene,object>",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **pmc_traffic(),
-                         "launches": int(launches.value), "avg_launch_ms": kms.value / max(1, launches.value),
-                         "flop_per_eval": FLOP_PER_EVAL_BOTH_VOXEL, "mlp_time_frac_of_step": mlp_s / elapsed},
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": CONFIG_TEXT[cfg_id] % ((args.width, args.height, wl.S) + ((wl.I,) if cfg_id != 0 else ()))
+                            + "; W1 random-init weights, %dx24 voxel table" % args.max_voxels,
+                "baseline_config_index": cfg_id, "pixels_per_frame": wl.n_pixels, "frames_per_step": wl.frames_per_step,
+                "rays_per_step_rank0": wl.hi - wl.lo, "evals_per_ray": wl.evals_per_ray,
+                "evals_per_step_all_ranks": evals_job, "rays_per_s": wl.frames_per_step * wl.n_pixels * args.steps / elapsed,
+                "collective": ("one all_gather_into_tensor of [%s] per step over %s" % (", ".join(wl.gather_keys), backend_name(backend)))
+                              if dist is not None else "none"},
         }
+        if cfg_id == 4:
+            res["config"]["evaluated_vs_nominal"] = (
+                "value counts the sample points the MLP kernel EVALUATES: rays that miss their object's box (near = far = 0) are "
+                "compacted away on the device, the reference evaluates them and then forces sigma = -1e5 (zero weight). "
+                "Nominal K*N*(S+S+I) per step: %.0f; evaluated: %.0f" % (nominal_job, evals_job))
+            res["config"]["nominal_ray_samples_per_s"] = nominal_job * args.steps / elapsed
+        if lib is not None:
+            mlp_s = kms.value / 1e3
+            flop = wl.flop_rank * args.steps
+            achieved = flop / mlp_s / 1e12 if mlp_s > 0 else 0.0
+            res["roofline"] = {"bound": "mfma", "kernel": wl.kernel, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "launches": int(launches.value), "avg_launch_ms": kms.value / max(1, launches.value),
+                               "flop_per_eval": wl.flop_per_eval if wl.flop_per_eval else {"scene": FLOP_SCENE, "object": FLOP_OBJECT},
+                               "flop_per_launch_avg": flop / max(1, launches.value), "mlp_time_frac_of_step": mlp_s / (t1 - t0),
+                               "measured_on": "rank 0"}
+        if dist is not None:
+            res["multi_gpu"] = {"world_size": world, "backend": backend_name(backend), "scaling": scaling,
+                                "per_rank_render_ms": per_rank_render, "per_rank_gather_ms_incl_wait": per_rank_gather,
+                                "per_rank_ms_per_step": per_rank_step, "gather_alone_ms": gather_alone_ms,
+                                "gather_bytes_per_rank": 5 * 4 * (wl.hi - wl.lo),
+                                "note": "gather_ms_incl_wait = the all-gather as seen by the rank's stream: the collective plus the "
+                                        "wait for the slowest rank's render; gather_alone_ms = the same collective after a barrier"}
         if extra is not None:
             res["split_bf16_mode"] = extra
-        if world == 1 and args.cpu_rays > 0:
-            res["cpu_baseline"], psnr = cpu_baseline(sc, rays, codes, kw, args.cpu_rays, evals_per_ray, last["rgb_fine"])
-            # second half of BASELINE.json's metric ("+ PSNR vs ref"): utils/metrics.py:5-15 on the baseline's rays
-            res["psnr_vs_cpu_oracle_db"], res["psnr_delta_vs_reference_db"] = psnr
-        chk = float(out.float().mean().item())
-        res["config"]["mean_rgb_fine"] = chk
+    if rank == 0 and lib is not None:
+        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and cfg_id == 1)
+        res["roofline"].update(pmc_traffic(args, cfg_id, live=want_pmc and dist is None))
+    if rank == 0 and world == 1 and args.cpu_rays > 0:
+        res["cpu_baseline"], psnr = cpu_baseline(wl, args.cpu_rays)
+        res["psnr_vs_cpu_oracle_db"], res["psnr_delta_vs_reference_db"] = psnr
+    if rank == 0:
+        res["config"]["mean_" + wl.gather_keys[0]] = float(out[wl.gather_keys[0]].float().mean().item())
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        if backend == "nccl" or not os.environ.get("OBJNERF_BENCH_KEEP_PG"):
+            dist.destroy_process_group()
     return res
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the MLP kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2
-    gfx950 correction + WRITE_SIZE, separate passes; profiles/r*_pmc.json, tools/pmc_run.sh).  bench.py
-    cannot collect PMC counters on itself, so this is the latest profiled value of the same command."""
+def backend_name(backend):
+    return "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
+
+
+def split_bf16_leg(wl, args, lib, fence, allreduce, evals_job):
+    """The same steps in the opt-in split-bf16 arithmetic mode (OBJNERF_MFMA=bf16x3: the fp32 contraction carried out on
+    the bf16 matrix pipe with exactly split operands) with ITS roofline: 6 bf16 MFMA products per
+    fp32 product, so the fp32-equivalent ceiling is 2500 / 6 = 416.7 TFLOP/s."""
+    key = wl.gather_keys[0]
+    ref_rgb = wl.last[key].clone()
+    os.environ["OBJNERF_MFMA"] = "bf16x3"
+    try:
+        wl.step()
+        fence()
+        lib.objnerf_timing_enable(1)
+        tb0 = time.perf_counter()
+        for _ in range(args.split_bf16_steps):
+            wl.step()
+        fence()
+        tb1 = time.perf_counter()
+        bl, bms = C.c_int64(0), C.c_double(0.0)
+        lib.objnerf_timing_read(C.byref(bl), C.byref(bms))
+        lib.objnerf_timing_enable(0)
+        eb = allreduce(tb1 - tb0, "MAX")
+        mse = ((wl.last[key].double() - ref_rgb.double()) ** 2).mean().item()
+        eq = wl.flop_rank * args.split_bf16_steps / (bms.value / 1e3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        return {"value": evals_job * args.split_bf16_steps / eb, "unit": "ray-samples/s",
+                "ms_per_step": 1e3 * eb / args.split_bf16_steps, "steps": args.split_bf16_steps,
+                "dtype": "f32 operands split exactly into 3 x bf16, 6 of 9 products on the bf16 matrix pipe, f32 accumulate",
+                "roofline": {"bound": "mfma", "achieved": eq, "peak": peak, "unit": "TFLOP/s (fp32-equivalent: bf16 MFMA rate / 6 products)",
+                             "frac": eq / peak, "launches": int(bl.value), "avg_launch_ms": bms.value / max(1, bl.value)},
+                "psnr_vs_f32_mfma_path_db": -10.0 * math.log10(max(mse, 1e-30)),
+                "max_abs_diff_vs_f32_mfma_path": (wl.last[key] - ref_rgb).abs().max().item()}
+    except Exception as e:      # the optional mode must never cost the headline line
+        try:
+            lib.objnerf_timing_enable(0)
+        except Exception:
+            pass
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        os.environ.pop("OBJNERF_MFMA", None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline.traffic: HBM bytes per launch of the MLP kernel from PMC counters
+# ---------------------------------------------------------------------------------------------------------------------
+def pmc_traffic(args, cfg_id, live):
+    """Two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE need separate passes: TCC counter slots) of ONE step of this same
+    workload, counters only (no trace domains).  gfx950 corrections as MI355X_MICROARCH.md "HBM [CDNA4]" prescribes:
+    FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -- this kernel's
+    weight DMA and feature-row gathers -- so it is doubled; WRITE_SIZE as reported.  Falls back to the latest committed
+    profile of the same command when rocprofv3 is unavailable or the passes fail."""
+    import csv
     import glob
+    import shutil
+    import tempfile
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)      # already inside rocprofv3
+    if live and shutil.which("rocprofv3") and not under_profiler:
+        try:
+            base = tempfile.mkdtemp(prefix="objnerf_pmc_", dir="/tmp")
+            child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg_id), "--width", str(args.width),
+                     "--height", str(args.height), "--max-voxels", str(args.max_voxels), "--steps", "1", "--warmup", "0",
+                     "--cpu-rays", "0", "--split-bf16-steps", "0", "--pmc", "off", "--pmc-child"]
+            tot = {}
+            t0 = time.perf_counter()
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(base, ctr)
+                cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child
+                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, timeout=240)
+                if p.returncode != 0:
+                    raise RuntimeError("rocprofv3 --pmc %s exited %d" % (ctr, p.returncode))
+                n, s = 0, 0.0
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if "mlp_kernel" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                            s += float(row["Counter_Value"])
+                            n += 1
+                if n == 0:
+                    raise RuntimeError("no %s rows for the MLP kernel" % ctr)
+                tot[ctr] = (s * 1024.0, n)
+            shutil.rmtree(base, ignore_errors=True)
+            fetch = 2.0 * tot["FETCH_SIZE"][0] / tot["FETCH_SIZE"][1]
+            write = tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1]
+            log("PMC passes: %.1f s" % (time.perf_counter() - t0))
+            return {"traffic": fetch + write, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KB -> B)",
+                    "traffic_fetch_bytes_per_launch": fetch, "traffic_write_bytes_per_launch": write,
+                    "traffic_source": "rocprofv3 --pmc passes run by this bench.py invocation (1 step each)"}
+        except Exception as e:
+            log("live PMC collection failed (%s: %s); using the committed profile" % (type(e).__name__, e))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
         return {"traffic": None}
     try:
         d = json.load(open(files[-1]))["derived"]
         return {"traffic": d["hbm_traffic_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",
-                "traffic_bytes_per_eval": d["hbm_traffic_bytes_per_eval"], "traffic_source": os.path.relpath(files[-1], ROOT)}
+                "traffic_bytes_per_eval": d["hbm_traffic_bytes_per_eval"],
+                "traffic_source": "committed profile %s (config 1 frame; not collected in this run)" % os.path.relpath(files[-1], ROOT)}
     except Exception:
         return {"traffic": None}
 
 
-def cpu_baseline(sc, rays, codes, kw, n_sample, evals_per_ray, gpu_rgb_fine):
-    """Times the oracle (CPU restatement of the reference's PyTorch path; bit-exact with the
-    reference on CPU, tests/test_oracle_vs_reference.py) on `n_sample` rays spread over the frame, and
-    returns PSNR(GPU rgb_fine, oracle rgb_fine) on those rays."""
-    from oracle import objnerf_oracle as O
-    # host cores actually available to this process (cgroup/affinity aware), not the machine total
+# ---------------------------------------------------------------------------------------------------------------------
+# cpu_baseline: the oracle on the host cores, bounded sample of the same workload
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(wl, n_sample):
+    """Times the oracle (CPU restatement of the reference's PyTorch path; bit-exact with the reference on CPU,
+    tests/test_oracle_vs_reference.py) on `n_sample` rays spread over the frame -- same weights, grid, codes, flags as the
+    GPU just rendered -- and returns PSNR(GPU pixels, oracle pixels) on those rays."""
+    from oracle.bench_adapter import OracleRenderer        # checker / baseline only: never in the timed region
+    Ro = OracleRenderer()
     try:
-        avail = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))       # host cores available to this process (cgroup/affinity aware)
     except AttributeError:
         avail = os.cpu_count() or 1
-    idx = torch.linspace(0, rays.shape[0] - 1, n_sample).long()
-    r_cpu = rays[idx.to(rays.device)].cpu()
-    c_cpu = codes[idx.to(rays.device)].cpu()
-    g_cpu = gpu_rgb_fine[idx.to(rays.device)].cpu()
-    ev = sc.embeddings["xyz"]
-    grid = dict(voxel_idx_map=ev.voxel_idx_map.cpu(), table=ev.embedding_space_ftr.weight.detach().cpu(),
-                voxel_offset=ev.voxel_offset.cpu(), voxel_size=ev.voxel_size.cpu(), voxel_shape=ev.voxel_shape.cpu())
-    pc = {k: v.detach().cpu() for k, v in sc.models["coarse"].state_dict().items()}
-    pf = {k: v.detach().cpu() for k, v in sc.models["fine"].state_dict().items()}
-    okw = dict(N_samples=kw["N_samples"], N_importance=kw["N_importance"], embedding_instance=c_cpu,
-               frustum_bound_th=kw["frustum_bound_th"], is_eval=True)
+    key = wl.gather_keys[0]
+    dev = wl.R.device
+    n_local = wl.hi - wl.lo
+    idx = torch.linspace(0, n_local - 1, min(n_sample, n_local)).long()
+    g_cpu = wl.last[key][idx.to(dev)].cpu()
+    off = wl.lo if wl.scaling == "strong" else 0          # wl.rays / wl.codes hold the whole frame
+    if wl.kind == "multi":
+        sets = [s[idx.to(dev)].cpu() for s in wl._ray_sets()]
+
+        def run(m):
+            return Ro.render_rays_multi(wl.sc, [s[:m] for s in sets], wl.obj_ids, **wl.kw)
+        evals_of = lambda m: sum(float((s[:m, 7] > 0).sum()) for s in sets) * wl.evals_per_ray   # noqa: E731
+    else:
+        r_cpu, c_cpu = wl.rays[(idx + off).to(dev)].cpu(), wl.codes[(idx + off).to(dev)].cpu()
+
+        def run(m):
+            return Ro.render_rays(wl.sc, r_cpu[:m], embedding_instance=c_cpu[:m], **wl.kw)
+        evals_of = lambda m: float(m) * wl.evals_per_ray   # noqa: E731
+    # The reference's path is hundreds of small ATen ops per chunk: more threads is not faster.  Probe a few thread
+    # counts on a 128-ray slab and keep the best (reported as `cores`).
+    best = None
+    for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(nt)
+        run(128)
+        t0 = time.perf_counter()
+        run(128)
+        dt = time.perf_counter() - t0
+        log("cpu_baseline probe: %d threads -> %.1f ms/ray" % (nt, dt / 128 * 1e3))
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    ncpu, per_ray = best[0], best[1] / 128
+    torch.set_num_threads(ncpu)
+    m = int(max(128, min(idx.numel(), 8.0 / max(per_ray, 1e-6))))      # ~8 s per repetition
     times = []
-    with torch.no_grad():
-        # The reference's path is hundreds of small ATen ops per chunk: more threads is not faster.
-        # Probe a few thread counts on a 128-ray slab and keep the best (reported as `cores`).
-        best = None
-        for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
-            torch.set_num_threads(nt)
-            O.render_rays(pc, pf, grid, r_cpu[:128], **dict(okw, embedding_instance=c_cpu[:128]))   # warm-up
-            t0 = time.perf_counter()
-            O.render_rays(pc, pf, grid, r_cpu[:128], **dict(okw, embedding_instance=c_cpu[:128]))
-            dt = time.perf_counter() - t0
-            log("cpu_baseline probe: %d threads -> %.1f ms/ray" % (nt, dt / 128 * 1e3))
-            if best is None or dt < best[1]:
-                best = (nt, dt)
-        ncpu, per_ray = best[0], best[1] / 128
-        torch.set_num_threads(ncpu)
-        # bound the sample to ~8 s per repetition
-        n_fit = int(max(128, min(n_sample, 8.0 / max(per_ray, 1e-6))))
-        if n_fit < n_sample:
-            log("cpu_baseline: shrinking sample %d -> %d rays (%.1f ms/ray)" % (n_sample, n_fit, per_ray * 1e3))
-            n_sample = n_fit
-            r_cpu, c_cpu, g_cpu = r_cpu[:n_sample], c_cpu[:n_sample], g_cpu[:n_sample]
-            okw["embedding_instance"] = c_cpu
-        for _ in range(3):
-            t0 = time.perf_counter()
-            o_cpu = O.render_rays(pc, pf, grid, r_cpu, **okw)
-            times.append(time.perf_counter() - t0)
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o_cpu = run(m)
+        times.append(time.perf_counter() - t0)
     med = sorted(times)[1]
-    import math
 
     def psnr_of(a, b):
         return -10.0 * math.log10(max(((a.double() - b.double()) ** 2).mean().item(), 1e-30))
-    ref = o_cpu["rgb_fine"]
+    ref = o_cpu[key]
+    g_cpu = g_cpu[:m]
     psnr = psnr_of(g_cpu, ref)
     # "PSNR within 0.1 dB of the reference" (BASELINE north_star; utils/metrics.py:5-15): there are no ground-truth
     # images here, so both renders are scored against one synthetic target T = reference render + N(0, 0.05) noise
     tgt = (ref + 0.05 * torch.randn(ref.shape, generator=torch.Generator().manual_seed(7))).clamp(0, 1)
     delta = abs(psnr_of(g_cpu, tgt) - psnr_of(ref, tgt))
-    return {"value": n_sample * evals_per_ray / med, "unit": "ray-samples/s", "cores": ncpu, "cores_available": avail, "kind": "port",
-            "sample": "%d rays evenly spread over the frame, same weights/grid/codes, median of 3 (%.2f s each)"
-                      % (n_sample, med)}, (psnr, delta)
+    return {"value": evals_of(m) / med, "unit": "ray-samples/s", "cores": ncpu, "cores_available": avail, "kind": "port",
+            "sample": "%d rays evenly spread over the frame, same weights/grid/codes/flags, median of 3 (%.2f s each)"
+                      % (m, med)}, (psnr, delta)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        rc = self_launch(args, argv)
+        if rc != 0:
+            raise SystemExit(rc)
+        return None
+    return run(args, argv=argv)
 
 
 if __name__ == "__main__":

@@ -29,8 +29,10 @@ def shard_bounds(n_rays: int, rank: int, world: int) -> Tuple[int, int]:
 
 def shard_rays(rays: torch.Tensor, extras: Dict[str, torch.Tensor] = None, rank: int = None, world: int = None):
     """This rank's slice of the rays and of every per-ray tensor in `extras`."""
-    rank = dist.get_rank() if rank is None else rank
-    world = dist.get_world_size() if world is None else world
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
     lo, hi = shard_bounds(rays.shape[0], rank, world)
     ex = {}
     for k, v in (extras or {}).items():
@@ -60,18 +62,41 @@ def gather_pixels(local: torch.Tensor, n_total: int = None) -> torch.Tensor:
     return out.reshape(-1) if squeeze else out
 
 
+def gather_pixel_maps(local: Dict[str, torch.Tensor], n_total: int = None) -> Dict[str, torch.Tensor]:
+    """All-gathers several per-ray maps ((n_local,) or (n_local, C) each) in ONE collective: the maps are packed side by
+    side into one (n_local, sum C) message -- rgb + depth + opacity = 20 B/ray -- because on xGMI a ring all-gather is
+    latency-bound at this size (<1 MB per rank) and three launches cost three latencies.  Returns {key: (n_total, ...)}."""
+    keys = list(local)
+    if not dist.is_initialized() or not keys:
+        return dict(local)
+    cols = [int(torch.Size(local[k].shape[1:]).numel()) for k in keys]          # 1 for (n_local,) maps
+    n_local = local[keys[0]].shape[0]
+    packed = torch.cat([local[k].reshape(n_local, c) for k, c in zip(keys, cols)], 1) if len(keys) > 1 else \
+        local[keys[0]].reshape(n_local, cols[0])
+    full = gather_pixels(packed, n_total)
+    out, off = {}, 0
+    for k, c in zip(keys, cols):
+        piece = full[:, off:off + c]
+        out[k] = piece.reshape(-1) if local[k].dim() == 1 else piece.reshape(full.shape[0], *local[k].shape[1:])
+        off += c
+    return out
+
+
 def render_rays_sharded(render_fn, rays: torch.Tensor, per_ray: Dict[str, torch.Tensor] = None,
-                        gather_keys: Iterable[str] = ("rgb_fine", "depth_fine", "opacity_fine"), **kwargs):
+                        gather_keys: Iterable[str] = ("rgb_fine", "depth_fine", "opacity_fine"), on_rendered=None, **kwargs):
     """Renders this rank's band of `rays` with `render_fn(rays=..., **per_ray_slices, **kwargs)`
-    and returns {key: full-frame tensor} for `gather_keys` (identical on every rank)."""
+    and returns {key: full-frame tensor} for `gather_keys` (identical on every rank); one collective per call.
+    on_rendered(local_results): optional hook between the render and the collective (bench.py records an event there)."""
     n = rays.shape[0]
     r_local, ex = shard_rays(rays, per_ray)
     res = render_fn(rays=r_local, **ex, **kwargs)
-    return {k: gather_pixels(res[k], n) for k in gather_keys if k in res}
+    if on_rendered is not None:
+        on_rendered(res)
+    return gather_pixel_maps({k: res[k] for k in gather_keys if k in res}, n)
 
 
 def render_rays_multi_sharded(render_fn, rays_list, gather_keys: Iterable[str] = ("rgb_fine", "depth_fine", "opacity_fine"),
-                              **kwargs):
+                              on_rendered=None, **kwargs):
     """The same for `render_rays_multi` (BASELINE configs[4], the editing demo on N GPUs): every ray set of the list
     describes the same pixels through a different object transform, so all sets are cut at the same row bounds and
     each rank composites its band of pixels over all sets; one pixel all-gather per frame, as above."""
@@ -82,7 +107,9 @@ def render_rays_multi_sharded(render_fn, rays_list, gather_keys: Iterable[str] =
     world = dist.get_world_size() if dist.is_initialized() else 1
     lo, hi = shard_bounds(n, rank, world)
     res = render_fn(rays_list=[r[lo:hi] for r in rays_list], **kwargs)
-    return {k: gather_pixels(res[k], n) for k in gather_keys if k in res}
+    if on_rendered is not None:
+        on_rendered(res)
+    return gather_pixel_maps({k: res[k] for k in gather_keys if k in res}, n)
 
 
 class GradientSync:
@@ -98,13 +125,29 @@ class GradientSync:
     (e.g. an object code no local ray used) contribute zeros, so ranks never disagree on the message layout.
     """
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
+                 active_rows: Dict[torch.nn.Parameter, int] = None, reduce_at_world1: bool = False):
+        """active_rows: {parameter: n} -- only the first n rows of that (2-D) parameter can ever receive a gradient, so only
+        `grad[:n]` travels.  This is the sparse handling of the voxel feature table: the renderer only
+        reads rows the index map points at, i.e. rows < number of occupied voxels (`EmbeddingVoxel.active_rows()`); the
+        reference's `max_voxels` = 800000 rows (76.8 MB of gradient) are mostly padding -- 103.6k rows = 9.9 MB in the
+        ScanNet-like scene, 10.8k rows = 1 MB in the ToyDesk-2-like one.  Contiguous prefix: no index exchange, no
+        host synchronisation.  reduce_at_world1: issue the collectives even in a 1-rank group (tests of the RCCL path on
+        one GPU); by default a 1-rank sync is a no-op."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
+        self.reduce_at_world1 = bool(reduce_at_world1)
+        ar = {id(p): int(n) for p, n in (active_rows or {}).items()}
+        self.rows: List[int] = []                    # rows of params[i] that travel (-1 = the whole tensor)
+        for p in self.params:
+            n = ar.get(id(p), -1)
+            if n >= 0 and (p.dim() != 2 or n > p.shape[0]):
+                raise ValueError("active_rows: parameter must be 2-D with at least that many rows")
+            self.rows.append(n)
         self.buckets: List[List[int]] = []          # indices into self.params
         cur, cur_bytes = [], 0
         for i, p in enumerate(self.params):
-            nbytes = p.numel() * 4
+            nbytes = self._numel(i) * 4
             if cur and cur_bytes + nbytes > bucket_bytes:
                 self.buckets.append(cur)
                 cur, cur_bytes = [], 0
@@ -114,13 +157,25 @@ class GradientSync:
             self.buckets.append(cur)
         self._flat: List[torch.Tensor] = [None] * len(self.buckets)
 
+    def _numel(self, i: int) -> int:
+        p = self.params[i]
+        return p.numel() if self.rows[i] < 0 else self.rows[i] * p.shape[1]
+
+    def message_bytes(self) -> List[int]:
+        """bytes of each all-reduce message"""
+        return [4 * sum(self._numel(i) for i in idx) for idx in self.buckets]
+
     def _buffer(self, b: int) -> torch.Tensor:
         idx = self.buckets[b]
-        n = sum(self.params[i].numel() for i in idx)
+        n = sum(self._numel(i) for i in idx)
         dev = self.params[idx[0]].device
         if self._flat[b] is None or self._flat[b].device != dev:
             self._flat[b] = torch.empty(n, dtype=torch.float32, device=dev)
         return self._flat[b]
+
+    def _travelling(self, i: int, t: torch.Tensor) -> torch.Tensor:
+        """the part of params[i]-shaped tensor t that is exchanged, flattened"""
+        return t.reshape(-1) if self.rows[i] < 0 else t[: self.rows[i]].reshape(-1)
 
     @torch.no_grad()
     def sync(self) -> None:
@@ -128,7 +183,7 @@ class GradientSync:
         if not dist.is_initialized():
             return
         world = dist.get_world_size(self.group)
-        if world == 1:
+        if world == 1 and not self.reduce_at_world1:
             return
         works = []
         for b, idx in enumerate(self.buckets):
@@ -136,12 +191,13 @@ class GradientSync:
             off = 0
             for i in idx:
                 p = self.params[i]
-                view = flat[off:off + p.numel()]
+                n = self._numel(i)
+                view = flat[off:off + n]
                 if p.grad is None:
                     view.zero_()
                 else:
-                    view.copy_(p.grad.reshape(-1))
-                off += p.numel()
+                    view.copy_(self._travelling(i, p.grad))
+                off += n
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         inv = 1.0 / world
         for b, idx in enumerate(self.buckets):
@@ -150,9 +206,10 @@ class GradientSync:
             off = 0
             for i in idx:
                 p = self.params[i]
-                g = flat[off:off + p.numel()].view_as(p)
+                n = self._numel(i)
+                g = flat[off:off + n]
                 if p.grad is None:
-                    p.grad = g.mul(inv)
-                else:
-                    torch.mul(g, inv, out=p.grad)
-                off += p.numel()
+                    p.grad = torch.zeros_like(p)
+                dst = self._travelling(i, p.grad)        # a view of p.grad (grads are contiguous)
+                torch.mul(g, inv, out=dst)
+                off += n

@@ -145,6 +145,12 @@ class EmbeddingVoxel(nn.Module):
         g.n_rows = table.shape[0]
         return g
 
+    def active_rows(self):
+        """Rows of embedding_space_ftr.weight the index map can point at (= occupied voxels, enumerated from 0 by
+        generate_voxel_idx_map, embedding_helper.py:187-200): only these rows are read by the renderer and only they
+        can receive a gradient -- distributed.GradientSync(active_rows=...) exchanges just this prefix."""
+        return int(self.voxel_idx_map.max().item()) + 1
+
     def invalidate_grid_cache(self):
         self._idx32 = None
         self._idx32_key = None

@@ -19,7 +19,13 @@ from .config import AttrDict, default_model_config
 SCANNET_LIKE = dict(near=0.15, far=3.0, scale_factor=2.0, voxel_size=0.1, scene_center=[2.0, 2.0, 0.0],
                     frustum_bound_th=0.025)
 TOYDESK_LIKE = dict(near=0.05, far=1.5, scale_factor=2.0, voxel_size=0.1, scene_center=[2.0, 2.0, 0.0],
-                    frustum_bound_th=-1.0 / 16)
+                    frustum_bound_th=-1.0 / 16)     # round-1 bench preset: the room with ToyDesk near/far only
+# config/toy_desk_2.yml:8-11,15,61-62,64 as they reach the renderer: near/far 0.8/24 and voxel_size 0.3 in reconstruction
+# units divided by scale_factor 16 (generic_dataset.py:444-447, embedding_helper.py:102-103); frustum_bound -1 -> disabled
+TOYDESK2 = dict(near=0.8 / 16.0, far=24.0 / 16.0, scale_factor=16.0, voxel_size=0.3, scene_center=[0.2, 1.4, 7.1],
+                frustum_bound_th=-1.0 / 16.0, cloud="desk", cam_origin=(0.34, -0.28, 0.34), cam_target=(0.0, 0.0, 0.03))
+SCANNET_LIKE.update(cloud="room", cam_origin=None, cam_target=None)
+TOYDESK_LIKE.update(cloud="room", cam_origin=None, cam_target=None)
 
 
 def room_point_cloud(n_points=200_000, seed=0):
@@ -30,8 +36,22 @@ def room_point_cloud(n_points=200_000, seed=0):
     return pts
 
 
+def desk_point_cloud(n_points=200_000, seed=0, center=(0.2, 1.4, 7.1)):
+    """ToyDesk-2-like cloud in reconstruction units ("desk real width 1.06m, recon width 8.3", toy_desk_2.yml:5):
+    half of the points on the 8.3 x 8.3 desk top, half in the 3-unit-high volume of the objects standing on it, placed at
+    the config's scene_center."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform([-4.15, -4.15, 0.0], [4.15, 4.15, 3.0], size=(n_points, 3))
+    pts[: n_points // 2, 2] = 0.0
+    return pts + np.asarray(center, dtype=np.float64)
+
+
 def dataset_extra(preset=SCANNET_LIKE, n_points=200_000, seed=0):
-    return AttrDict(pcd_xyz=room_point_cloud(n_points, seed), scene_center=preset["scene_center"],
+    if preset.get("cloud", "room") == "desk":
+        cloud = desk_point_cloud(n_points, seed, preset["scene_center"])
+    else:
+        cloud = room_point_cloud(n_points, seed)
+    return AttrDict(pcd_xyz=cloud, scene_center=preset["scene_center"],
                     scale_factor=preset["scale_factor"], voxel_size=preset["voxel_size"], neighbor_marks=3)
 
 
@@ -54,6 +74,36 @@ def camera_rays(W=640, H=480, fov_x_deg=60.0, near=0.15, far=3.0, origin=(0.5, 0
     o = torch.tensor(origin, dtype=torch.float32).expand_as(d)
     n = d.shape[0]
     return torch.cat([o, d, torch.full((n, 1), near), torch.full((n, 1), far)], -1).contiguous()
+
+
+def look_at_rays(W, H, origin, target, near, far, fov_x_deg=60.0, up=(0.0, 0.0, 1.0)):
+    """The same pinhole model as `camera_rays` with the pose given as eye point / look-at point (normalised units)."""
+    f = 0.5 * W / math.tan(0.5 * math.radians(fov_x_deg))
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    dirs = torch.stack([(i - W / 2) / f, -(j - H / 2) / f, -torch.ones_like(i)], -1).reshape(-1, 3)
+    o = torch.tensor(origin, dtype=torch.float64)
+    fwd = torch.tensor(target, dtype=torch.float64) - o
+    fwd = fwd / fwd.norm()
+    right = torch.linalg.cross(fwd, torch.tensor(up, dtype=torch.float64))
+    right = right / right.norm()
+    upv = torch.linalg.cross(right, fwd)
+    R = torch.stack([right, upv, -fwd], 1).float()         # camera x, y, z axes as columns (camera looks along -z)
+    d = dirs @ R.T
+    d = d / d.norm(dim=-1, keepdim=True)
+    n = d.shape[0]
+    return torch.cat([o.float().expand_as(d), d, torch.full((n, 1), float(near)), torch.full((n, 1), float(far))], -1).contiguous()
+
+
+def preset_rays(preset, W=640, H=480, yaw_offset_deg=0.0):
+    """The bench / golden camera of a preset: 640x480, 60 degrees, inside the room (ScanNet-like) or looking at the desk
+    from 0.54 normalised units = 8.6 reconstruction units (ToyDesk-2: 88 % of the pixels see the desk volume).  yaw_offset_deg rotates the view (one camera per rank in weak scaling)."""
+    if preset.get("cam_origin") is not None:
+        o, t = preset["cam_origin"], preset["cam_target"]
+        a = math.radians(yaw_offset_deg)
+        ox, oy = o[0] - t[0], o[1] - t[1]
+        o2 = (t[0] + ox * math.cos(a) - oy * math.sin(a), t[1] + ox * math.sin(a) + oy * math.cos(a), o[2])
+        return look_at_rays(W, H, o2, t, preset["near"], preset["far"])
+    return camera_rays(W, H, near=preset["near"], far=preset["far"], yaw_deg=35.0 + yaw_offset_deg)
 
 
 def fill_w1(model, seed):
@@ -133,3 +183,32 @@ def oriented_box(center, size, yaw_deg, scene_center, scale_factor):
     half = 0.5 * np.asarray(size, dtype=np.float64)
     return dict(scale_factor=float(scale_factor), R_avg=np.eye(3), t_avg=np.asarray(scene_center, dtype=np.float64),
                 R_box=R, t_box=t, bmin=-half, bmax=half)
+
+
+def edit_demo_geometry(preset, W):
+    """Camera, object box and the two object poses of the duplicating + moving demo (test/demo_editable_render.py:33-42
+    shape: each copy gets a small x/y offset and a z rotation; render_tools/editable_renderer.py:231-263 turns a pose T
+    into the camera-to-object matrix inv(T) @ Twc).  A sofa-sized box (1.0 x 0.8 x 1.0 m) 2.6 m in front of the camera:
+    the moved object covers 21 % of the 640x480 frame, its duplicate 19 %, the background set all of it."""
+    focal = (W / 2) / np.tan(math.radians(60.0) / 2)                       # editable_renderer.py:214
+    cy, sy = math.cos(math.radians(35.0)), math.sin(math.radians(35.0))
+    cp, sp = math.cos(math.radians(75.0)), math.sin(math.radians(75.0))
+    R = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]]) @ np.array([[1.0, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    eye = np.array([0.5, 0.5, 0.6])
+    Twc = np.concatenate([R, eye[:, None]], 1)
+    cn = eye + 1.3 * (R @ np.array([0.0, 0.0, -1.0]))                      # object centre, normalised units, on the view axis
+    cn[2] = 0.25
+    center_w = cn * preset["scale_factor"] + np.asarray(preset["scene_center"], dtype=np.float64)
+    box = oriented_box(center_w, [1.0, 0.8, 1.0], 20.0, preset["scene_center"], preset["scale_factor"])
+
+    def moved(dx, dy, dz, yaw):
+        c, s = math.cos(math.radians(yaw)), math.sin(math.radians(yaw))
+        Rz, A, B, D, M = np.eye(4), np.eye(4), np.eye(4), np.eye(4), np.eye(4)
+        Rz[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+        A[:3, 3], B[:3, 3], D[:3, 3] = cn, -cn, [dx, dy, dz]              # rotate about the object's centre, then shift
+        M[:3] = Twc
+        return (np.linalg.inv(D @ A @ Rz @ B) @ M)[:3]
+    # the small lifts keep the two copies' top / bottom faces on different planes: with equal planes both ray sets leave
+    # their boxes at the SAME depth on many pixels, and the order of exactly tied depths in the joint sort is unspecified
+    # in the reference (unstable torch.sort, multi_rendering.py:112) -- parity could not be pinned on such pixels
+    return focal, [Twc, moved(0.05, 0.2, 0.013, 10.0), moved(-0.25, 0.15, 0.031, -10.0)], box

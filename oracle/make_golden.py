@@ -119,6 +119,39 @@ def main():
                                     N_samples=m["N_samples"], N_importance=0, perturb=0, noise_std=0,
                                     chunk=32768, white_back=True, background_skip_bbox=None)
         save("multi_coarse_only_white", dict(out))
+        # ---- bench.py --config 4: the editing demo's ray sets, generated by the reference's own ray / box code ----
+        sc = scene("scannet_800k")
+        bm = cases.BENCH_MULTI
+        focal, poses, box = cases.bench_multi_geometry()
+        pix = cases.bench_multi_pixels()
+        w_, h_ = bm["frame"]
+        directions = ref.get_ray_directions(h_, w_, focal)
+        helper = ref_import.make_box(box)
+        sets = []
+        for k, Toc in enumerate(poses):
+            rays_o, rays_d = ref.get_rays(directions, torch.from_numpy(np.asarray(Toc)).float())
+            rays_o, rays_d = rays_o[pix], rays_d[pix]
+            if k == 0:
+                pre = synth.SCANNET_LIKE
+                nf = [pre["near"] * torch.ones_like(rays_o[:, :1]), pre["far"] * torch.ones_like(rays_o[:, :1])]
+            else:
+                mask, bn, bf = helper.get_ray_bbox_intersections(rays_o, rays_d, box["scale_factor"], bbox_enlarge=bm["bbox_enlarge"])
+                bn[~mask] = torch.zeros_like(bn[~mask])
+                bf[~mask] = torch.zeros_like(bf[~mask])
+                nf = [bn, bf]
+                assert 0 < int(mask.sum()) < mask.numel(), "config-4 golden: object set %d hits %d of %d" % (k, int(mask.sum()), mask.numel())
+            sets.append(torch.cat([rays_o, rays_d] + nf, 1))
+        out = ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets], bm["obj_ids"],
+                                    N_samples=bm["N_samples"], N_importance=bm["N_importance"], perturb=0, noise_std=0,
+                                    chunk=32768, white_back=False, background_skip_bbox={4: helper})
+        out = dict(out)
+        for typ in ("coarse", "fine"):     # no exact cross-set depth ties away from z == 0 (their order is unspecified in the reference)
+            zz = out["z_vals_" + typ]
+            assert not ((zz[:, 1:] == zz[:, :-1]) & (zz[:, 1:] != 0)).any(), "config-4 golden: tied depths in the %s pass" % typ
+        for k, s_ in enumerate(sets):
+            out["_rays_%d" % k] = s_
+        save("multi_bench_edit_demo", out)
+
         # ---- editor ray generation (row f2) ----
         h, w, focal, Toc, box = cases.raygen_inputs()
         rg = cases.RAYGEN

@@ -18,8 +18,11 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 N_RAYS = 48
 MAX_VOXELS = 120_000
 
-# scene variants: name -> (use_voxel, n_points of the synthetic cloud)
-SCENES = {"voxel": (True, 200_000), "plain": (False, 0), "sparse": (True, 1500)}
+# scene variants: name -> (use_voxel, n_points of the synthetic cloud[, preset, rows of the voxel table])
+SCENES = {"voxel": (True, 200_000), "plain": (False, 0), "sparse": (True, 1500),
+          # the scenes bench.py measures on (its presets, its 800000-row table)
+          "toydesk2_800k": (True, 200_000, synth.TOYDESK2, 800_000),
+          "scannet_800k": (True, 200_000, synth.SCANNET_LIKE, 800_000)}
 
 # render_rays cases: scene, kwargs for render_rays, extras
 RENDER_CASES = {
@@ -44,17 +47,36 @@ RENDER_CASES = {
                          kw=dict(N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0, is_eval=False,
                                  frustum_bound_th=0.025)),
     "plain_odd_sizes": dict(scene="plain", kw=dict(N_samples=40, N_importance=24, is_eval=True)),
+    # ---- the workloads bench.py measures, on 48 rays spread over ITS 640x480 camera (bench.py --config 1 / 2) ----
+    # BASELINE configs[1]: true ToyDesk-2 geometry (config/toy_desk_2.yml:8-11,61-64: scale 16, voxel 0.3, near/far 0.8/24,
+    # frustum bound disabled), one object code (val_instance_id = 1), 64 + 64, 800000-row table
+    "bench_toydesk2": dict(scene="toydesk2_800k", frame=(640, 480), ids=1,
+                           kw=dict(N_samples=64, N_importance=64, is_eval=True, white_back=False, forward_instance=True,
+                                   frustum_bound_th=synth.TOYDESK2["frustum_bound_th"])),
+    # BASELINE configs[2]/[3]: ScanNet-0113-multi-like, 5 object codes per ray, 64 + 128, frustum bound, rays_in_bbox
+    "bench_scannet_multi": dict(scene="scannet_800k", frame=(640, 480), ids="five",
+                                kw=dict(N_samples=64, N_importance=128, is_eval=True, white_back=False, forward_instance=True,
+                                        frustum_bound_th=0.025, rays_in_bbox=True)),
 }
 
 
 def scene_for(types, name, device="cpu"):
-    use_voxel, n_points = SCENES[name]
-    return synth.build_scene(types, use_voxel, max_voxels=MAX_VOXELS, n_points=max(n_points, 1), device=device)
+    use_voxel, n_points = SCENES[name][:2]
+    preset, max_voxels = (SCENES[name][2], SCENES[name][3]) if len(SCENES[name]) > 2 else (synth.SCANNET_LIKE, MAX_VOXELS)
+    return synth.build_scene(types, use_voxel, preset=preset, max_voxels=max_voxels, n_points=max(n_points, 1), device=device)
 
 
 def render_inputs(case):
     """rays (N,8), per-ray ids (N), pass_through_mask (N,1) or None, randoms dict or None"""
     c = RENDER_CASES[case]
+    if "frame" in c:       # bench workload: rays spread over the bench camera's full frame, bench.py's code assignment
+        w, h = c["frame"]
+        rays_all = synth.preset_rays(SCENES[c["scene"]][2], w, h)
+        idx = torch.arange(0, w * h, 6421)[:N_RAYS]
+        rays = rays_all[idx].contiguous()
+        n = rays.shape[0]
+        ids = synth.per_ray_ids(w * h)[idx] if c["ids"] == "five" else torch.full((n,), int(c["ids"]), dtype=torch.long)
+        return rays, ids, None, None
     far = c.get("far", 3.0)
     rays_all = synth.camera_rays(64, 48, far=far)
     idx = torch.arange(0, rays_all.shape[0], 61)[:N_RAYS]
@@ -138,6 +160,20 @@ def multi_inputs():
     box = synth.oriented_box(center=[2.9, 3.1, 0.5], size=[1.0, 0.8, 1.0], yaw_deg=20.0,
                              scene_center=synth.SCANNET_LIKE["scene_center"], scale_factor=synth.SCANNET_LIKE["scale_factor"])
     return sets, [box]
+
+
+# ---- bench.py --config 4 (BASELINE configs[4]): the editing demo's three ray sets of the 640x480 frame, 40 strided pixels ----
+BENCH_MULTI = dict(obj_ids=[0, 4, 4], N_samples=64, N_importance=64, frame=(640, 480), n_rays=40, stride=6911, bbox_enlarge=0.06)
+
+
+def bench_multi_geometry():
+    """(focal, [Toc of the background set, of object 4, of its moved copy], removed-object box) of bench.py's config 4"""
+    return synth.edit_demo_geometry(synth.SCANNET_LIKE, BENCH_MULTI["frame"][0])
+
+
+def bench_multi_pixels():
+    w, h = BENCH_MULTI["frame"]
+    return torch.arange(0, w * h, BENCH_MULTI["stride"])[:BENCH_MULTI["n_rays"]]
 
 
 # ---- editor ray generation (row f2): one background set and one object set with an enlarged box ----

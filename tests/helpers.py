@@ -59,3 +59,74 @@ def sampler_residual(bins, weights, u, z, eps=1e-5):
     z64 = O.sample_pdf(bins.double(), weights.double(), u.shape[1], det=False, eps=eps, u=u.double())
     rz = (z.double() - z64).abs() / bins.double().abs().max()
     return torch.minimum((q - u.double()).abs(), rz)
+
+
+def fine_pass_on_reference_depths(sc, case, g, device="cuda"):
+    """Teacher forcing: the fine MLP + compositing (stage entry points of the C ABI) evaluated on the REFERENCE's fine
+    depths g["z_vals_fine"] of render case `case`.  Returns {golden key: tensor} for the seven fine-pass maps."""
+    import ctypes as C
+    import cases
+    from object_nerf_amd import _lib
+    from object_nerf_amd.rendering import mfma_mode
+    c = cases.RENDER_CASES[case]
+    use_voxel = cases.SCENES[c["scene"]][0]
+    rays, ids, ptm, _ = cases.render_inputs(case)
+    kw = c["kw"]
+    n, S = g["z_vals_fine"].shape
+    l = _lib.lib()
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": ids.to(device)})["embedding_instance"].contiguous()
+    z = g["z_vals_fine"].to(device).contiguous()
+    rays_d = rays.to(device)
+    b3 = mfma_mode() == "bf16x3"
+    blob, aux = sc.models["fine"].packed(split_bf16=b3)
+    buf = {k: torch.empty(n, S, *sh, device=device) for k, sh in dict(sigma=(), rgb=(3,), isig=(), irgb=(3,)).items()}
+    a = _lib.MlpArgs()
+    a.use_voxel, a.do_scene, a.do_object, a.mfma_bf16x3 = int(use_voxel), 1, 1, int(b3)
+    a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
+    a.rays, a.z_vals, a.n_rays, a.S = rays_d.data_ptr(), z.data_ptr(), n, S
+    a.codes, a.code_stride = codes.data_ptr(), 64
+    if use_voxel:
+        a.grid = sc.embeddings["xyz"].grid_struct()
+    a.sigma, a.rgb, a.inst_sigma, a.inst_rgb = (buf[k].data_ptr() for k in ("sigma", "rgb", "isig", "irgb"))
+    _lib.check(l.objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval")
+    out = {k: torch.empty(n, *sh, device=device) for k, sh in dict(weights=(S,), opacity=(), rgb_map=(3,), depth=(),
+                                                                    rgb_inst=(3,), depth_inst=(), opacity_inst=()).items()}
+    ca = _lib.CompositeArgs()
+    ca.n_rays, ca.S, ca.z_vals = n, S, z.data_ptr()
+    ca.sigma, ca.rgb, ca.inst_sigma, ca.inst_rgb = (buf[k].data_ptr() for k in ("sigma", "rgb", "isig", "irgb"))
+    ca.white_back = int(kw.get("white_back", False))
+    ca.occlusion = int((not kw.get("is_eval", False)) and kw.get("frustum_bound_th", 0) > 0)
+    ca.frustum_bound_th = kw.get("frustum_bound_th", 0.0)
+    ptm8 = ptm.reshape(-1).to(torch.uint8).to(device) if ptm is not None else None
+    if ptm8 is not None:
+        ca.pass_through_mask = ptm8.data_ptr()
+    ca.rays_in_bbox = int(kw.get("rays_in_bbox", False))
+    for k, t in out.items():
+        setattr(ca, k, t.data_ptr())
+    _lib.check(l.objnerf_composite(C.byref(ca), _lib.stream_ptr()), "composite")
+    torch.cuda.synchronize()
+    names = dict(weights="weights_fine", opacity="opacity_fine", rgb_map="rgb_fine", depth="depth_fine",
+                 rgb_inst="rgb_instance_fine", depth_inst="depth_instance_fine", opacity_inst="opacity_instance_fine")
+    return {gk: out[k] for k, gk in names.items()}
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+import pytest  # noqa: E402
+
+MFMA_MODES = ["f32", "bf16x3"]
+
+
+@pytest.fixture(autouse=True, params=MFMA_MODES)
+def mfma_mode(request, monkeypatch):
+    """GPU test modules import this autouse fixture: every test in them runs once per arithmetic mode of the fused MLP
+    kernels (OBJNERF_MFMA: fp32 MFMA, and the opt-in split-bf16 mode), same tolerances.  Tests that never reach those
+    kernels are marked `single_mode` and run once."""
+    if request.node.get_closest_marker("single_mode") is not None and request.param != "f32":
+        pytest.skip("mode-independent test")
+    monkeypatch.setenv("OBJNERF_MFMA", request.param)
+    return request.param

@@ -1,0 +1,111 @@
+"""CPU, world_size 2 over gloo: bench.py's OWN N > 1 code path -- workload construction, the library's sharded entry
+points (render_rays_sharded / render_rays_multi_sharded), the packed pixel all-gather, timing marks, the JSON line -- with
+the oracle-backed renderer standing in for the HIP one (oracle/bench_adapter.py; the renderer needs a GPU, the plumbing
+does not).  Strong scaling must reproduce the single-process frame exactly: every pixel is rendered by exactly one rank
+with the same arithmetic."""
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ARGV = ["--steps", "2", "--warmup", "1", "--width", "12", "--height", "9", "--max-voxels", "120000", "--cpu-rays", "0",
+        "--split-bf16-steps", "0", "--pmc", "off"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, extra, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import bench
+    from oracle.bench_adapter import OracleRenderer
+    args = bench.parse(ARGV + ["--gpus", str(world)] + extra)
+    res = bench.run(args, renderer=OracleRenderer(), backend="gloo")
+    if rank == 0:
+        q.put(json.dumps(res))
+
+
+def _run(world, extra):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, extra, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    return json.loads(q.get())
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_strong_scaling_world2_equals_world1(cfg):
+    one = _run(1, ["--config", str(cfg), "--dist"])
+    two = _run(2, ["--config", str(cfg)])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and one["n_gpus"] == 1
+    assert two["config"]["baseline_config_index"] == cfg
+    mg = two["multi_gpu"]
+    assert mg["world_size"] == 2 and len(mg["per_rank_render_ms"]) == 2 and len(mg["per_rank_gather_ms_incl_wait"]) == 2
+    assert mg["gather_alone_ms"] is not None and all(v > 0 for v in mg["per_rank_render_ms"])
+    # one frame per step whatever the world size; rank 0 renders the first band
+    assert two["config"]["frames_per_step"] == 1 and two["config"]["rays_per_step_rank0"] == (12 * 9 + 1) // 2
+    assert two["config"]["evals_per_step_all_ranks"] == one["config"]["evals_per_step_all_ranks"]
+    key = [k for k in two["config"] if k.startswith("mean_rgb")][0]
+    assert two["config"][key] == one["config"][key]          # identical pixels, identical mean
+    assert "one all_gather_into_tensor" in two["config"]["collective"]
+
+
+def test_weak_scaling_world2_renders_two_frames():
+    two = _run(2, ["--config", "1"])
+    assert two["scaling"] == "weak" and two["config"]["frames_per_step"] == 2
+    assert two["config"]["evals_per_step_all_ranks"] == 2 * 12 * 9 * 192
+    assert two["config"]["rays_per_step_rank0"] == 12 * 9
+
+
+def test_default_config_follows_world_size():
+    import bench
+    a = bench.parse(["--gpus", "8"])
+    assert a.config is None and a.scaling is None      # resolved in run(): 3 / strong at N > 1, 1 at N = 1
+    one = _run(1, [])
+    assert one["config"]["baseline_config_index"] == 1 and "multi_gpu" not in one
+
+
+def test_self_launch_starts_every_rank_and_propagates_failures(tmp_path):
+    """`python bench.py --gpus N` without a launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; a failing
+    rank stops the others and becomes the exit code (stand-in child: the real one needs N GPUs)"""
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, time\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "open(os.path.join(sys.argv[1], 'rank%d.of%d' % (r, w)), 'w').write(' '.join(sys.argv[2:]))\n"
+        "if 'fail' in sys.argv and r == 1: sys.exit(7)\n"
+        "if 'fail' in sys.argv: time.sleep(30)\n")
+    args = bench.parse(["--gpus", "3"])
+    assert bench.self_launch(args, [str(tmp_path), "--gpus", "3"], cmd=[sys.executable, str(child)]) == 0
+    assert sorted(os.listdir(tmp_path)) == ["child.py", "rank0.of3", "rank1.of3", "rank2.of3"]
+    assert (tmp_path / "rank2.of3").read_text() == "--gpus 3"
+    import time
+    t0 = time.time()
+    assert bench.self_launch(args, [str(tmp_path), "fail"], cmd=[sys.executable, str(child)]) == 7
+    assert time.time() - t0 < 20          # the sleeping ranks were stopped, not waited for
+    # and without GPUs the real launch refuses loudly instead of hanging
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit, match="GPU"):
+            bench.main(["--gpus", "2"])

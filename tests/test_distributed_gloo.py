@@ -96,6 +96,17 @@ def _grad_worker(rank, world, port, q):
             ok = ok and torch.allclose(p.grad, want, atol=1e-6) and p.grad.shape == p.shape
         sync.sync()                                                     # second step reuses the flat buffers
         ok = ok and torch.allclose(params[0].grad, sum(grads[r][0] for r in range(world)) / world, atol=1e-6)
+        # voxel-table handling: only the rows the index map can reach (a prefix) travel
+        table = torch.nn.Parameter(torch.zeros(1000, 24))
+        tg = [torch.randn(300, 24, generator=g) for _ in range(world)]
+        table.grad = torch.zeros(1000, 24)
+        table.grad[:300] = tg[rank]
+        table.grad[900] = float(rank + 1)          # outside the active prefix: stays local (never happens in the renderer)
+        s2 = GradientSync([params[1], table], active_rows={table: 300})
+        ok = ok and s2.message_bytes() == [4 * (256 + 300 * 24)]
+        s2.sync()
+        ok = ok and torch.allclose(table.grad[:300], sum(tg) / world, atol=1e-6)
+        ok = ok and bool((table.grad[900] == float(rank + 1)).all()) and bool((table.grad[300:900] == 0).all())
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -18,6 +18,7 @@ import torch
 
 import cases
 import helpers as H
+from helpers import mfma_mode  # noqa: F401  (autouse: every test below runs in both arithmetic modes)
 import object_nerf_amd as A
 from object_nerf_amd import synth
 from object_nerf_amd.multi_rendering import render_rays_multi
@@ -94,57 +95,23 @@ def test_render_rays_matches_reference(case):
     assert abs(psnr(out["rgb_" + last].cpu(), target) - psnr(g["rgb_" + last], target)) <= 0.1
 
 
-@pytest.mark.parametrize("case", ["voxel_eval", "plain_eval", "voxel_train_flags", "voxel_imp128", "plain_odd_sizes"])
+TEACHER_FORCED_CASES = ["voxel_eval", "plain_eval", "voxel_train_flags", "voxel_imp128", "plain_odd_sizes",
+                        "bench_toydesk2", "bench_scannet_multi"]
+
+
+@pytest.mark.parametrize("case", TEACHER_FORCED_CASES)
 def test_fine_pass_teacher_forced(case):
     """the fine MLP + compositing on the REFERENCE's fine depths (stage entry points of the C ABI):
     removes the sampler's sensitivity, so the tight fp32-roundoff bound applies to the fine pass too"""
-    from object_nerf_amd import _lib
     c = cases.RENDER_CASES[case]
-    sc = scene(c["scene"])
-    use_voxel = cases.SCENES[c["scene"]][0]
     g = cases.load_golden("render_" + case)
-    rays, ids, ptm, _ = cases.render_inputs(case)
-    kw = c["kw"]
-    n, S = g["z_vals_fine"].shape
-    l = _lib.lib()
-    with torch.no_grad():
-        codes = sc.code_library({"instance_ids": ids.to(DEV)})["embedding_instance"].contiguous()
-    z = g["z_vals_fine"].to(DEV).contiguous()
-    rays_d = rays.to(DEV)
-    blob, aux = sc.models["fine"].packed()
-    buf = {k: torch.empty(n, S, *sh, device=DEV) for k, sh in dict(sigma=(), rgb=(3,), isig=(), irgb=(3,)).items()}
-    a = _lib.MlpArgs()
-    a.use_voxel, a.do_scene, a.do_object = int(use_voxel), 1, 1
-    a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
-    a.rays, a.z_vals, a.n_rays, a.S = rays_d.data_ptr(), z.data_ptr(), n, S
-    a.codes, a.code_stride = codes.data_ptr(), 64
-    if use_voxel:
-        a.grid = sc.embeddings["xyz"].grid_struct()
-    a.sigma, a.rgb, a.inst_sigma, a.inst_rgb = (buf[k].data_ptr() for k in ("sigma", "rgb", "isig", "irgb"))
-    _lib.check(l.objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval")
-    out = {k: torch.empty(n, *sh, device=DEV) for k, sh in dict(weights=(S,), opacity=(), rgb_map=(3,), depth=(),
-                                                                 rgb_inst=(3,), depth_inst=(), opacity_inst=()).items()}
-    ca = _lib.CompositeArgs()
-    ca.n_rays, ca.S, ca.z_vals = n, S, z.data_ptr()
-    ca.sigma, ca.rgb, ca.inst_sigma, ca.inst_rgb = (buf[k].data_ptr() for k in ("sigma", "rgb", "isig", "irgb"))
-    ca.white_back = int(kw.get("white_back", False))
-    ca.occlusion = int((not kw.get("is_eval", False)) and kw.get("frustum_bound_th", 0) > 0)
-    ca.frustum_bound_th = kw.get("frustum_bound_th", 0.0)
-    ptm8 = ptm.reshape(-1).to(torch.uint8).to(DEV) if ptm is not None else None
-    if ptm8 is not None:
-        ca.pass_through_mask = ptm8.data_ptr()
-    ca.rays_in_bbox = int(kw.get("rays_in_bbox", False))
-    for k, t in out.items():
-        setattr(ca, k, t.data_ptr())
-    _lib.check(l.objnerf_composite(C.byref(ca), _lib.stream_ptr()), "composite")
-    torch.cuda.synchronize()
-    names = dict(weights="weights_fine", opacity="opacity_fine", rgb_map="rgb_fine", depth="depth_fine",
-                 rgb_inst="rgb_instance_fine", depth_inst="depth_instance_fine", opacity_inst="opacity_instance_fine")
-    for k, gk in names.items():
-        err = H.normwise(out[k], g[gk])
+    out = H.fine_pass_on_reference_depths(scene(c["scene"]), case, g)
+    for gk, v in out.items():
+        err = H.normwise(v, g[gk])
         assert err <= 1e-4, "%s/%s teacher-forced: %.3e" % (case, gk, err)
 
 
+@pytest.mark.single_mode
 @pytest.mark.parametrize("case", ["voxel_eval", "plain_eval", "voxel_imp128", "plain_odd_sizes", "voxel_random"])
 def test_sample_pdf_merge_teacher_forced(case):
     """inverse-CDF sampling + merge on the REFERENCE's coarse weights / depths"""
@@ -204,6 +171,41 @@ def test_render_rays_multi_matches_reference(gname, ni, white, use_boxes):
         assert psnr(r["rgb_fine"].cpu(), g["rgb_fine"]) >= 60.0
 
 
+def test_render_rays_multi_bench_edit_demo_matches_reference():
+    """bench.py --config 4 end to end on the device: objnerf_generate_rays for the three ray sets of the 640x480 frame, 40
+    strided pixels of each through render_rays_multi, against the reference (its own ray / box code and render)"""
+    from object_nerf_amd.ray_utils import generate_rays
+    g = cases.load_golden("multi_bench_edit_demo")
+    bm = cases.BENCH_MULTI
+    sc = scene("scannet_800k")
+    focal, poses, box = cases.bench_multi_geometry()
+    pix = cases.bench_multi_pixels().to(DEV)
+    w, h = bm["frame"]
+    pre = synth.SCANNET_LIKE
+    sets = []
+    for k, Toc in enumerate(poses):
+        full = generate_rays(h, w, focal, Toc, pre["near"], pre["far"]) if k == 0 else \
+            generate_rays(h, w, focal, Toc, box=box, bbox_enlarge=bm["bbox_enlarge"])
+        sets.append(full[pix].contiguous())
+        assert torch.equal(sets[-1][:, 7].cpu() > 0, g["_rays_%d" % k][:, 7] > 0)
+        assert H.normwise(sets[-1], g["_rays_%d" % k]) < 2e-6
+    with torch.no_grad():
+        r = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [g["_rays_%d" % k].to(DEV) for k in range(3)],
+                              bm["obj_ids"], N_samples=bm["N_samples"], N_importance=bm["N_importance"], perturb=0,
+                              noise_std=0, background_skip_bbox={4: box})
+    for k in g:
+        if k.startswith("_"):
+            continue
+        if k == "obj_ids_coarse":
+            nz = g["z_vals_coarse"] != 0
+            assert torch.equal(r[k].cpu()[nz], g[k][nz])
+            continue
+        err = H.normwise(r[k], g[k])
+        tol = 1e-4 if k.endswith("coarse") else 2e-2
+        assert err <= tol, "bench edit demo/%s %.3e" % (k, err)
+    assert psnr(r["rgb_fine"].cpu(), g["rgb_fine"]) >= 60.0
+
+
 def test_full_frame_properties():
     """640x480 (BASELINE size): properties that need no reference + a strided sample against the oracle"""
     sc = cases.scene_for(A, "voxel", device=DEV)
@@ -253,6 +255,7 @@ def test_full_frame_properties():
     assert psnr(r["rgb_fine"][idx].cpu(), ro["rgb_fine"]) >= 60.0
 
 
+@pytest.mark.single_mode
 def test_split_bf16_mode_matches_f32_mfma_mode(monkeypatch):
     """OBJNERF_MFMA=bf16x3 (the fp32 contraction on the bf16 matrix pipe: operands split exactly into three bf16 pieces,
     6 of 9 products, fp32 accumulation) against the default fp32-MFMA kernel on a batch where every workgroup loops over

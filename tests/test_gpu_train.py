@@ -8,6 +8,7 @@ import torch
 
 import cases
 import helpers as H
+from helpers import mfma_mode  # noqa: F401  (autouse: every test below runs in both arithmetic modes)
 import object_nerf_amd as A
 from object_nerf_amd import _lib, synth
 from oracle import objnerf_oracle as O
@@ -21,6 +22,7 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+@pytest.mark.single_mode
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 0), (0, 1)])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 271), (1000, 3, 128), (1, 256, 5000), (257, 129, 33), (64, 527, 70000)])
 def test_gemm_matches_torch(akc, bkc, M, N, K):
@@ -134,14 +136,6 @@ def test_render_rays_gradients_match_oracle_autograd(case):
     print(case, "worst parameter-gradient rel L2 error %.2e" % worst)
 
 
-@pytest.mark.parametrize("case", ["voxel_train", "plain_train"])
-def test_gradients_in_split_bf16_mode(case, monkeypatch):
-    """OBJNERF_MFMA=bf16x3 also switches the two fused training kernels (forward with saved activations, dgrad chain)
-    to the split-bf16 arithmetic; the GEMMs stay fp32.  Same oracle comparison, same tolerances."""
-    monkeypatch.setenv("OBJNERF_MFMA", "bf16x3")
-    test_render_rays_gradients_match_oracle_autograd(case)
-
-
 def test_training_step_updates_weights_and_repacks():
     """an optimizer step on the HIP gradients changes the render, through the automatic weight repack"""
     sc = cases.scene_for(A, "plain", device=DEV)
@@ -198,6 +192,7 @@ def _stage_inputs(sc, use_voxel, n, S, seed=3):
                 code_pts=codes.repeat_interleave(S, 0), grid=grid)
 
 
+@pytest.mark.single_mode
 @pytest.mark.parametrize("sname,fi", [("voxel", True), ("plain", True), ("voxel", False)])
 def test_training_kernels_against_layerwise_gemms(sname, fi):
     """C ABI level, 1500 rays x 128 depths = 1500 tiles of 128 points on 256 workgroups (every workgroup loops over
@@ -291,6 +286,7 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
     print(sname, fi, "fused dgrad chain vs GEMM chain: worst rel L2 %.2e" % worst)
 
 
+@pytest.mark.single_mode
 @pytest.mark.parametrize("S", [128, 192])
 def test_composite_backward_opaque_surface(S):
     """objnerf_composite_backward at fine-pass sample counts with an OPAQUE slab in the middle of every ray (alpha rounds
