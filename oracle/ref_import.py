@@ -52,6 +52,47 @@ def _read_point_cloud(path):
     raise FileNotFoundError(path)
 
 
+def install_stubs():
+    """Stub modules for the reference's un-installed, off-path dependencies (idempotent)."""
+    for name in ("torch_optimizer", "ipdb"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if "open3d" not in sys.modules:
+        o3d = types.ModuleType("open3d")
+        o3d.io = types.ModuleType("open3d.io")
+        o3d.io.read_point_cloud = _read_point_cloud
+        sys.modules["open3d"] = o3d
+        sys.modules["open3d.io"] = o3d.io
+
+    if not torch.cuda.is_available():
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+    if "datasets" not in sys.modules:
+        # a package object whose __path__ is the reference's datasets/ directory: submodules
+        # (geo_utils.py, ray_utils.py) import from the REAL files, datasets/__init__.py is never run
+        ds = types.ModuleType("datasets")
+        ds.__path__ = [os.path.join(REF_ROOT, "datasets")]
+        sys.modules["datasets"] = ds
+    if "numba" not in sys.modules:      # datasets/geo_utils.py:2,111,126: @nb.jit(nopython=True) -> plain Python
+        nb = types.ModuleType("numba")
+        nb.jit = lambda *a, **k: (lambda f: f)
+        sys.modules["numba"] = nb
+    if "kornia" not in sys.modules:
+        # datasets/ray_utils.py:2,17 uses kornia.create_meshgrid (requirements.txt pins kornia==0.4.1, not
+        # vendored, not installed here).  Restatement of its published behaviour for normalized_coordinates=False:
+        # grid[0, y, x] = (x, y) as float32.
+        kn = types.ModuleType("kornia")
+
+        def create_meshgrid(height, width, normalized_coordinates=True, device=None):
+            assert not normalized_coordinates
+            xs = torch.linspace(0, width - 1, width, dtype=torch.float)
+            ys = torch.linspace(0, height - 1, height, dtype=torch.float)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            return torch.stack([gx, gy], -1)[None]
+
+        kn.create_meshgrid = create_meshgrid
+        sys.modules["kornia"] = kn
+
+
 _loaded = None
 
 
@@ -69,18 +110,7 @@ def load_reference():
         if name in sys.modules and not getattr(sys.modules[name], "__file__", "").startswith(REF_ROOT):
             raise RuntimeError("module %r already imported from elsewhere" % name)
 
-    for name in ("torch_optimizer", "ipdb"):
-        sys.modules.setdefault(name, types.ModuleType(name))
-    if "open3d" not in sys.modules:
-        o3d = types.ModuleType("open3d")
-        o3d.io = types.ModuleType("open3d.io")
-        o3d.io.read_point_cloud = _read_point_cloud
-        sys.modules["open3d"] = o3d
-        sys.modules["open3d.io"] = o3d.io
-
-    if not torch.cuda.is_available():
-        torch.Tensor.cuda = lambda self, *a, **k: self
-        torch.nn.Module.cuda = lambda self, *a, **k: self
+    install_stubs()
 
     cwd = os.getcwd()
     sys.path.insert(0, REF_ROOT)
@@ -91,31 +121,6 @@ def load_reference():
         # kornia, torchvision).  Only `bbox_intersection_batch` is taken from it and the hot path
         # (check_in_any_boxes / check_xyz_in_bounds, bbox_utils.py:158-207) never calls it, so a stub
         # `datasets` package lets the REAL utils/bbox_utils.py import unmodified.
-        if "datasets" not in sys.modules:
-            # a package object whose __path__ is the reference's datasets/ directory: submodules
-            # (geo_utils.py, ray_utils.py) import from the REAL files, datasets/__init__.py is never run
-            ds = types.ModuleType("datasets")
-            ds.__path__ = [os.path.join(REF_ROOT, "datasets")]
-            sys.modules["datasets"] = ds
-        if "numba" not in sys.modules:      # datasets/geo_utils.py:2,111,126: @nb.jit(nopython=True) -> plain Python
-            nb = types.ModuleType("numba")
-            nb.jit = lambda *a, **k: (lambda f: f)
-            sys.modules["numba"] = nb
-        if "kornia" not in sys.modules:
-            # datasets/ray_utils.py:2,17 uses kornia.create_meshgrid (requirements.txt pins kornia==0.4.1, not
-            # vendored, not installed here).  Restatement of its published behaviour for normalized_coordinates=False:
-            # grid[0, y, x] = (x, y) as float32.
-            kn = types.ModuleType("kornia")
-
-            def create_meshgrid(height, width, normalized_coordinates=True, device=None):
-                assert not normalized_coordinates
-                xs = torch.linspace(0, width - 1, width, dtype=torch.float)
-                ys = torch.linspace(0, height - 1, height, dtype=torch.float)
-                gy, gx = torch.meshgrid(ys, xs, indexing="ij")
-                return torch.stack([gx, gy], -1)[None]
-
-            kn.create_meshgrid = create_meshgrid
-            sys.modules["kornia"] = kn
         import datasets.geo_utils as geo_utils
         import datasets.ray_utils as ray_utils
         import utils.bbox_utils as bbox_utils

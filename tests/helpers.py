@@ -16,10 +16,20 @@ def state(m):
     return {k: v.detach().cpu() for k, v in m.state_dict().items()}
 
 
-def oracle_grid(ev):
-    """plain-tensor view of an EmbeddingVoxel for oracle.objnerf_oracle"""
-    return dict(voxel_idx_map=ev.voxel_idx_map.cpu(), table=ev.embedding_space_ftr.weight.detach().cpu(),
+def oracle_grid(ev, keep_graph=False):
+    """plain-tensor view of an EmbeddingVoxel for oracle.objnerf_oracle (keep_graph: the table stays the Parameter, so
+    that autograd through the oracle reaches it)"""
+    table = ev.embedding_space_ftr.weight if keep_graph else ev.embedding_space_ftr.weight.detach().cpu()
+    return dict(voxel_idx_map=ev.voxel_idx_map.cpu(), table=table,
                 voxel_offset=ev.voxel_offset.cpu(), voxel_size=ev.voxel_size.cpu(), voxel_shape=ev.voxel_shape.cpu())
+
+
+def box_dict_from_helper(b):
+    """synth.oriented_box-style dict of a reference BBoxRayHelper-shaped object (utils/bbox_utils.py:9-34 attributes)"""
+    import numpy as np
+    pa, aa = np.asarray(b.pose_avg, dtype=np.float64).squeeze(), np.asarray(b.axis_align_mat, dtype=np.float64)
+    return dict(scale_factor=float(b.scale_factor), R_avg=pa[:3, :3], t_avg=pa[:3, 3], R_box=aa[:3, :3], t_box=aa[:3, 3],
+                bmin=np.asarray(b.bbox_bounds[0], dtype=np.float64), bmax=np.asarray(b.bbox_bounds[1], dtype=np.float64))
 
 
 def test_rays(n=96, w=64, h=48, stride=29, **kw):

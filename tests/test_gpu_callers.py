@@ -1,0 +1,168 @@
+"""GPU: the calls the reference's own CALLERS make (b), replayed through the HIP entry points.
+
+tests/golden/callers_calls.npz holds every call that the REAL train.py::ObjectNeRFSystem (validation_step and
+training_step -> forward's ray-chunk loop, train.py:73-105) and the REAL render_tools/editable_renderer.py
+(render_edit 203-294, render_origin -> scene_inference 112-151) made to `render_rays` / `render_rays_multi` when they ran
+over `dropin/` in the build container (oracle/ref_callers.py; tests/test_reference_callers.py re-derives the file there
+and asserts it is unchanged).  tests/golden/callers_outputs.npz holds what the same callers returned over the
+reference's own models/* -- per-scenario result dicts after the callers' own chunk concatenation, the loss, dLoss/dresult
+and parameter gradients of training_step.  The GPU box has no reference, so here the recorded calls are issued to the
+product on the GPU in the recorded order, chunk results are concatenated the way the callers do (train.py:101-104,
+editable_renderer.py:143-150, 289-292), and everything is compared with the callers' outputs."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import helpers as H
+from helpers import mfma_mode  # noqa: F401  (autouse: both arithmetic modes)
+import object_nerf_amd as A
+from object_nerf_amd.multi_rendering import render_rays_multi
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def load_calls():
+    z = np.load(cases.GOLDEN_DIR + "/callers_calls.npz")
+    meta = json.loads(bytes(z["meta"]).decode())
+    calls = []
+    for i, m in enumerate(meta):
+        calls.append(dict(m, tens={k: torch.from_numpy(z["c%d_%s" % (i, k)]) for k in m["tensors"]}))
+    return calls
+
+
+@pytest.fixture(scope="module")
+def scene():
+    # oracle/ref_callers.py::fill_system == the seeded fill of cases scene "voxel" (same cloud, table rows, seeds)
+    return cases.scene_for(A, "voxel", device=DEV)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return cases.load_golden("callers_outputs")
+
+
+def issue_render_rays(sc, call, codes=None):
+    t, kw = call["tens"], dict(call["scalars"])
+    kw.pop("chunk", None)
+    rnd = None
+    if "perturb_rand" in t:
+        rnd = dict(perturb_rand=t["perturb_rand"].to(DEV), u_rand=t["u_rand"].to(DEV), noise=[t["noise%d" % i].to(DEV) for i in range(4)])
+    ptm = t["pass_through_mask"].to(DEV) if "pass_through_mask" in t else None
+    return A.render_rays(models=sc.models, embeddings=sc.embeddings, rays=t["rays"].to(DEV),
+                         embedding_instance=codes if codes is not None else t["embedding_instance"].to(DEV),
+                         pass_through_mask=ptm, chunk=call["scalars"]["chunk"], _randoms=rnd, **kw)
+
+
+def grade(out, gold, prefix, coarse_tol=1e-4, fine_tol=2e-2):
+    keys = [k[len(prefix):] for k in gold if k.startswith(prefix) and not k.startswith(prefix + "_") and
+            not k.startswith(prefix + "dL_") and not k.startswith(prefix + "grad")]
+    assert sorted(out) == sorted(keys)
+    for k in keys:
+        g = gold[prefix + k]
+        assert out[k].shape == g.shape, k
+        if k == "obj_ids_coarse":
+            nz = gold[prefix + "z_vals_coarse"] != 0
+            assert torch.equal(out[k].cpu()[nz], g[nz])
+            continue
+        err = H.normwise(out[k], g)
+        assert err <= (coarse_tol if k.endswith("coarse") else fine_tol), "%s%s: %.3e" % (prefix, k, err)
+
+
+def test_validation_step_chunk_loop(scene, gold):
+    calls = [c for c in load_calls() if c["scenario"] == "validation_step"]
+    assert [c["tens"]["rays"].shape[0] for c in calls] == [16, 16, 8]          # train.chunk = 16 over 40 rays: ragged tail
+    with torch.no_grad():
+        chunks = [issue_render_rays(scene, c) for c in calls]
+    out = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}          # train.py:101-104
+    grade(out, gold, "val_")
+    # the numbers validation_step derives from the result dict (models/losses.py, utils/metrics.py)
+    mse = ((out["rgb_fine"].cpu() - gold["val_rgb_fine"]) ** 2).mean()
+    assert -10 * torch.log10(mse.clamp_min(1e-20)) > 60.0
+
+
+def test_training_step_forward_and_backward(scene, gold):
+    """training_step's render (perturb = 1, noise_std = 1, occlusion + pass-through masks) on the recorded random draws,
+    then backward from the reference loss's own dLoss/dresult (models/losses.py ran in the build container)."""
+    calls = [c for c in load_calls() if c["scenario"] == "training_step"]
+    table = scene.code_library.embedding_instance.weight
+    params = [p for m in (scene.models["coarse"], scene.models["fine"], scene.code_library, scene.embeddings["xyz"])
+              for p in m.parameters()]
+    flags = [p.requires_grad for p in params]
+    for p in params:
+        p.requires_grad_(True)
+        p.grad = None
+    try:
+        chunks = []
+        for c in calls:
+            rows = c["tens"]["embedding_instance"].to(DEV)
+            ids = (rows[:, None, :] == table.detach()[None]).all(-1).float().argmax(1)     # the ids the caller looked up
+            assert torch.equal(table.detach()[ids], rows)
+            chunks.append(issue_render_rays(scene, c, codes=scene.code_library({"instance_ids": ids})["embedding_instance"]))
+        out = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}
+        grade({k: v.detach() for k, v in out.items()}, gold, "train_")
+        heads = [k for k in out if ("train_dL_" + k) in gold]
+        assert "rgb_fine" in heads and "opacity_instance_coarse" in heads
+        torch.autograd.backward([out[k] for k in heads], [gold["train_dL_" + k].to(DEV) for k in heads])
+        torch.cuda.synchronize()
+        named = {}
+        for pre, m in (("nerf_coarse.", scene.models["coarse"]), ("nerf_fine.", scene.models["fine"]),
+                       ("code_library.", scene.code_library)):
+            named.update({pre + k: p for k, p in m.named_parameters()})
+        worst = {}
+        for name, p in named.items():
+            g = gold["train_grad_" + name]
+            flat = p.grad.detach().reshape(-1).cpu()
+            mine = flat[::max(1, flat.numel() // 1000)]
+            assert mine.shape == g.shape, name
+            gn = gold["train_gradnorm_" + name].item()
+            # strided sample against the reference's, scaled by the whole gradient's norm; and the norm itself.
+            # The coarse model only sees the coarse pass (the sampler is detached, rendering.py:307): fp32-roundoff class.
+            # Fine-model gradients inherit the importance sampler's sensitivity (module docstring of test_gpu_render.py).
+            tol = 2e-4 if name.startswith("nerf_coarse.") else 5e-2
+            scale = gn * (g.numel() / max(flat.numel(), 1)) ** 0.5 + 1e-30
+            err = (mine.double() - g.double()).norm().item() / scale
+            worst[name] = err
+            assert err <= tol, "%s: sampled gradient error %.3e (of the expected sample norm)" % (name, err)
+            assert abs(flat.double().norm().item() - gn) <= tol * gn + 1e-30, name
+        tg = scene.embeddings["xyz"].embedding_space_ftr.weight.grad
+        rows, vals = gold["train_grad__table_rows"], gold["train_grad__table_vals"]
+        mine = tg[rows.to(DEV)].cpu()
+        assert H.rel_l2(mine, vals) <= 5e-2
+        touched = tg.abs().sum(1).nonzero().squeeze(1).cpu()
+        # the same table rows receive gradient (coarse depths are identical; fine depths may cross a cell face)
+        common = np.intersect1d(touched.numpy(), rows.numpy()).size
+        assert common >= 0.97 * rows.numel() and touched.numel() <= 1.03 * rows.numel()
+        print("training_step replay: worst coarse %.2e, worst fine %.2e" % (
+            max(v for k, v in worst.items() if k.startswith("nerf_coarse.")),
+            max(v for k, v in worst.items() if not k.startswith("nerf_coarse."))))
+    finally:
+        for p, f in zip(params, flags):
+            p.grad = None
+            p.requires_grad_(f)
+
+
+def box_from_row(row):
+    r = row.numpy()
+    return dict(scale_factor=float(r[0]), R_avg=r[1:10].reshape(3, 3), t_avg=r[10:13], R_box=r[13:22].reshape(3, 3),
+                t_box=r[22:25], bmin=r[25:28], bmax=r[28:31])
+
+
+@pytest.mark.parametrize("scenario,prefix,n_sets", [("render_edit", "edit_", 3), ("render_origin", "origin_", 1)])
+def test_editable_renderer_chunk_loops(scene, gold, scenario, prefix, n_sets):
+    calls = [c for c in load_calls() if c["scenario"] == scenario]
+    assert [c["tens"]["rays_0"].shape[0] for c in calls] == [50, 50, 20]        # config.chunk = 50 over 10 x 12 pixels
+    chunks = []
+    with torch.no_grad():
+        for c in calls:
+            kw = dict(c["scalars"])
+            assert len(kw["obj_instance_ids"]) == n_sets
+            boxes = {str(i): box_from_row(r) for i, r in enumerate(c["tens"]["boxes"])}
+            chunks.append(render_rays_multi(models=scene.models, embeddings=scene.embeddings, code_library=scene.code_library,
+                                            rays_list=[c["tens"]["rays_%d" % i].to(DEV) for i in range(n_sets)],
+                                            background_skip_bbox=boxes if boxes else None, **kw))
+    out = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}          # editable_renderer.py:289-292 / 143-150
+    grade(out, gold, prefix)
