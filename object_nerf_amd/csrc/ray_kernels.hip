@@ -17,6 +17,28 @@ namespace objnerf {
 // ------------------------------------------------------------------------------------------
 // wave helpers
 // ------------------------------------------------------------------------------------------
+// float64 wave primitives (two 32-bit lane moves per value)
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl_xor((int)(b & 0xffffffffll), m), hi = __shfl_xor((int)(b >> 32), m);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl_up((int)(b & 0xffffffffll), d), hi = __shfl_up((int)(b >> 32), d);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl((int)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_f64(v, o);
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -235,25 +257,32 @@ __device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf
                                                int nb, const float* __restrict__ u, int I, float eps,
                                                float* out_lds, float* __restrict__ out_glb, int lane) {
   const int nw = nb - 1;
-  // weights + eps, row sum  (rendering.py:30-31)
-  float part = 0.f;
-  for (int i = lane; i < nw; i += 64) part += wts[i] + eps;
-  const float tot = wave_sum(part);
-  // cdf = cat([0, cumsum(pdf)]) in the reference's SEQUENTIAL order (rendering.py:32-33).  Every lane runs the same
-  // chain of adds on wave-uniform operands (v_readlane of the pdf value of element i), so all lanes hold the running
-  // sum and lane i keeps it at step i: ~3 instructions per element and no memory round trip inside the chain.
-  float run = 0.f;
+  // weights + eps, row sum (rendering.py:30-31).  The reference's CPU kernels (ATen) sum fp32 rows with a cascade that
+  // is within an ulp of the exact sum; here the row is summed in float64 and rounded once.
+  double part = 0.0;
+  for (int i = lane; i < nw; i += 64) part += (double)(wts[i] + eps);
+  const float tot = (float)wave_sum_f64(part);
+  // cdf = cat([0, cumsum(pdf)]) (rendering.py:32-33).  ATen's CPU cumsum keeps its running sum in the accumulate type of
+  // fp32, which is float64, and rounds every prefix to fp32 on store.  The same here: a wave-parallel inclusive scan in
+  // float64 (6 shuffle steps per 64 elements + a float64 carry), each prefix rounded to fp32.  A float64 prefix of <= 1023
+  // fp32 terms is exact to ~1e-16 relative in any association order, so the fp32-rounded prefixes equal the sequential
+  // ones except when a float64 sum lies within that distance of an fp32 rounding boundary (probability ~1e-9 per
+  // element).  Why it matters: u = 1 (the last deterministic sample) lands in the last bin or one bin earlier depending
+  // on whether cdf[-1] is <= 1 or > 1 -- a whole-bin discontinuity decided by the last ulp of this sum; an
+  // fp32 running sum drifts several ulps from 1 and flips that decision on ~40 % of opaque rays.
+  double carry = 0.0;
   if (lane == 0) cdf_lds[0] = 0.f;
   for (int base = 0; base < nw; base += 64) {
     const int idx = base + lane;
-    const float pdf = idx < nw ? __fdiv_rn(wts[idx] + eps, tot) : 0.f;     // x + 0 = x: padding lanes do not disturb the chain
-    float mine = 0.f;
+    double v = idx < nw ? (double)__fdiv_rn(wts[idx] + eps, tot) : 0.0;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      run = run + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pdf), i));
-      mine = lane == i ? run : mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const double t = shfl_up_f64(v, o);
+      v += lane >= o ? t : 0.0;
     }
-    if (idx < nw) cdf_lds[idx + 1] = mine;
+    v += carry;
+    if (idx < nw) cdf_lds[idx + 1] = (float)v;
+    carry = shfl_f64(v, 63);
   }
   __builtin_amdgcn_wave_barrier();
   for (int j = lane; j < I; j += 64) {

@@ -121,6 +121,18 @@ def fine_pass_on_reference_depths(sc, case, g, device="cuda"):
     return {gk: out[k] for k, gk in names.items()}
 
 
+def moved_rays(z_ours, z_ref, z_coarse, frac=0.25):
+    """Per-ray mask: some fine depth differs from the reference's by more than `frac` of the ray's smallest coarse
+    spacing -- an importance sample that landed in a different place of its bin or in another bin (the discontinuities
+    of rendering.py:43-60: the searchsorted decision, the denom < eps branch, and u = 1 against cdf[-1]).
+    Everything on such a ray that is indexed by sample position (weights_, z_vals_) is then shifted, not perturbed."""
+    zo, zr, zc = z_ours.detach().cpu().double(), z_ref.detach().cpu().double(), z_coarse.detach().cpu().double()
+    gap = (zc[:, 1:] - zc[:, :-1]).abs()
+    gap = torch.where(gap > 0, gap, torch.full_like(gap, float("inf"))).min(-1)[0]
+    gap = torch.where(torch.isfinite(gap), gap, torch.ones_like(gap))
+    return (zo - zr).abs().max(-1)[0] > frac * gap
+
+
 def rel_l2(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

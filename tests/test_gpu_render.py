@@ -2,16 +2,19 @@
 reference outputs, and size-independent properties at the full 640x480 BASELINE size.
 
 Tolerances.  Coarse-pass keys are held to the BASELINE contract, 1e-4 normwise; measured they are
-1e-6..6e-5, i.e. 0.1-0.9x the distance between the reference's own fp32 and fp64 results.
-Fine-pass keys sit on the importance-sampling noise floor: the reference's own fp32 result moves by
-1e-4..1e-1 (normwise, weights_/z_vals_/depth_) when the same code runs in fp64 (a
-1-ulp change of a coarse weight can move a fine depth across a bin), so end to end they are graded
-as: error vs the fp32 reference <= max(20x the fp32-vs-fp64 distance of the oracle on the same
-inputs, 2e-2) -- a max-norm over 48 rays is a heavy-tailed statistic -- plus PSNR(ours, reference)
->= 60 dB and |dPSNR| <= 0.1 dB against a fixed synthetic target.  The fine pass itself is held to
-the same 1e-4 bound by test_fine_pass_teacher_forced (reference depths fed in), and the sampler by
-test_sample_pdf_merge_teacher_forced (reference weights fed in)."""
+1e-6..6e-5, i.e. 0.1-0.9x the distance between the reference's own fp32 and fp64 results ("floor":
+the oracle run in float64 on the same inputs).  Fine-pass keys sit on the importance-sampling noise
+floor: the reference's own fp32 result moves by 1e-4..1e-1 (normwise, weights_/z_vals_/depth_) when
+the same code runs in fp64, so end to end they are graded against that floor:
+error vs the fp32 reference <= 3x floor in the fp32-MFMA mode and <= 5x floor in the split-bf16 mode
+(measured worst ratios 1.84 and 2.49, profiles/r02_parity.md; round 1 needed 20x because its sampler
+summed the cdf in fp32 where the reference's CPU cumsum accumulates in float64 -- DESIGN.md §4),
+plus: no more rays whose importance samples MOVED (helpers.moved_rays) than the float64 oracle
+itself has + 1, PSNR(ours, reference) >= 60 dB and |dPSNR| <= 0.1 dB against a fixed synthetic
+target.  The fine pass itself is held to 1e-4 by test_fine_pass_teacher_forced (reference depths fed
+in), and the sampler by test_sample_pdf_merge_teacher_forced (reference weights fed in)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -27,6 +30,37 @@ from oracle import objnerf_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 _scenes = {}
+FLOOR_FACTOR = {"f32": 3.0, "bf16x3": 5.0}     # fine-pass tolerance in units of the reference's fp32-vs-fp64 distance
+
+
+def grade_multi(r, g, what):
+    """render_rays_multi against the reference.  Coarse keys: 1e-4.  Fine keys: rays whose importance samples stayed
+    where the reference's are (|dz| <= 1e-4 of the depth range: "settled") are held to 5e-3; the others -- samples of a
+    set with an eps-dominated pdf shift by ~1e-3 for a 1e-6 change of the coarse weights, and a sample that crosses a
+    face of the removed object's box switches between its sigma and -1e5 (multi_rendering.py:239-241) -- may be at
+    most 5 % of the rays and still have to give the same pixel to 2e-2."""
+    zf = "z_vals_fine" in g
+    settled = None
+    if zf:
+        dz = (r["z_vals_fine"].cpu().double() - g["z_vals_fine"].double()).abs().max(-1)[0] / g["z_vals_fine"].abs().max().item()
+        settled = dz <= 1e-4
+        assert int((~settled).sum()) <= max(1, settled.numel() // 20), "%s: %d unsettled rays" % (what, int((~settled).sum()))
+    for k in g:
+        if k.startswith("_"):
+            continue
+        if k == "obj_ids_coarse":
+            nz = g["z_vals_coarse"] != 0          # tie order at z == 0 is unspecified in the reference
+            assert torch.equal(r[k].cpu()[nz], g[k][nz])
+            continue
+        if k.endswith("coarse"):
+            assert H.normwise(r[k], g[k]) <= 1e-4, "%s/%s %.3e" % (what, k, H.normwise(r[k], g[k]))
+            continue
+        scale = g[k].double().abs().max().clamp_min(1e-30)
+        d = (r[k].cpu().double() - g[k].double()).abs()
+        d = d.reshape(d.shape[0], -1).max(-1)[0] / scale
+        assert d[settled].max().item() <= 5e-3, "%s/%s settled rays %.3e" % (what, k, d[settled].max().item())
+        if k in ("rgb_fine", "opacity_fine", "depth_fine"):
+            assert d.max().item() <= 2e-2, "%s/%s %.3e" % (what, k, d.max().item())
 
 
 def scene(name):
@@ -85,10 +119,14 @@ def test_render_rays_matches_reference(case):
         floor = H.normwise(g[k], f64[k])
         # keys downstream of the data-dependent sampling (fine pass; everything when the depths are perturbed)
         noisy = k.endswith("fine") or (randoms is not None)
-        tol = max(20.0 * floor, 2e-2) if noisy else 1e-4
+        tol = max(FLOOR_FACTOR[os.environ.get("OBJNERF_MFMA", "f32")] * floor, 2e-5) if noisy else 1e-4
         report.append("%s %.2e (floor %.2e)" % (k, err, floor))
         assert err <= tol, "%s/%s: normwise %.3e > tol %.3e (fp64 floor %.3e)" % (case, k, err, tol, floor)
     print(case, "; ".join(report))
+    if kw["N_importance"] > 0:
+        moved = int(H.moved_rays(out["z_vals_fine"], g["z_vals_fine"], g["z_vals_coarse"]).sum())
+        moved64 = int(H.moved_rays(f64["z_vals_fine"], g["z_vals_fine"], g["z_vals_coarse"]).sum())
+        assert moved <= moved64 + 1, "%s: %d rays' importance samples moved (float64 oracle: %d)" % (case, moved, moved64)
     last = "fine" if kw["N_importance"] > 0 else "coarse"
     assert psnr(out["rgb_" + last].cpu(), g["rgb_" + last]) >= 60.0
     target = torch.rand(g["rgb_" + last].shape, generator=torch.Generator().manual_seed(3))
@@ -159,14 +197,7 @@ def test_render_rays_multi_matches_reference(gname, ni, white, use_boxes):
                               white_back=white, background_skip_bbox={4: boxes[0]} if use_boxes else None)
     assert sorted(r) == sorted(g)
     assert r["obj_ids_coarse"].dtype == torch.float32 and r["weights_coarse"].shape == (40, 192)
-    for k in g:
-        if k == "obj_ids_coarse":
-            nz = g["z_vals_coarse"] != 0          # tie order at z == 0 is unspecified in the reference
-            assert torch.equal(r[k].cpu()[nz], g[k][nz])
-            continue
-        err = H.normwise(r[k], g[k])
-        tol = 1e-4 if k.endswith("coarse") else 2e-2
-        assert err <= tol, "%s/%s %.3e" % (gname, k, err)
+    grade_multi(r, g, gname)
     if ni:
         assert psnr(r["rgb_fine"].cpu(), g["rgb_fine"]) >= 60.0
 
@@ -193,16 +224,7 @@ def test_render_rays_multi_bench_edit_demo_matches_reference():
         r = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [g["_rays_%d" % k].to(DEV) for k in range(3)],
                               bm["obj_ids"], N_samples=bm["N_samples"], N_importance=bm["N_importance"], perturb=0,
                               noise_std=0, background_skip_bbox={4: box})
-    for k in g:
-        if k.startswith("_"):
-            continue
-        if k == "obj_ids_coarse":
-            nz = g["z_vals_coarse"] != 0
-            assert torch.equal(r[k].cpu()[nz], g[k][nz])
-            continue
-        err = H.normwise(r[k], g[k])
-        tol = 1e-4 if k.endswith("coarse") else 2e-2
-        assert err <= tol, "bench edit demo/%s %.3e" % (k, err)
+    grade_multi(r, g, "bench edit demo")
     assert psnr(r["rgb_fine"].cpu(), g["rgb_fine"]) >= 60.0
 
 
