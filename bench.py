@@ -446,7 +446,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
         res["cpu_baseline"], psnr = cpu_baseline(wl, args.cpu_rays)
         res["psnr_vs_cpu_oracle_db"], res["psnr_delta_vs_reference_db"] = psnr
     if rank == 0:
-        res["config"]["mean_" + wl.gather_keys[0]] = float(out[wl.gather_keys[0]].float().mean().item())
+        res["config"]["mean_" + wl.gather_keys[0]] = float(out[wl.gather_keys[0]].double().mean().item())   # float64: independent of layout / reduction order
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

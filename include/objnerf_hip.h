@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 3
+#define OBJNERF_ABI_VERSION 4
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -136,6 +136,13 @@ typedef struct {
   int32_t sigma_only;
   /* fused form only: `blob` is an objnerf_pack_weights_b3() stream and the MLP runs in the split-bf16 mode above */
   int32_t mfma_bf16x3;
+  /* fused form only, optional (both or neither): evaluate a SUBSET of the rays.  ray_index: int32 ray numbers,
+   * ascending or not; n_active: DEVICE pointer to how many of them are valid -- read by the kernel, so the count can
+   * be produced on the stream (objnerf_compact_rays) without a host round trip.  Points of unlisted rays are neither
+   * read nor written.  Replaces the "evaluate, then overwrite sigma" of rays that missed their object's box in
+   * render_tools/multi_rendering.py:40,83,92. */
+  const int32_t* ray_index;
+  const int32_t* n_active;
 } objnerf_mlp_args;
 int objnerf_mlp_eval(const objnerf_mlp_args* args, void* stream);
 
@@ -194,6 +201,16 @@ int objnerf_sample_pdf(const float* bins, const float* weights, const float* u, 
  * where the sample point rays_o + rays_d * z lies inside any box (multi_rendering.py:239-241). */
 int objnerf_mask_sigma(float* sigma, const float* rays, const float* z_vals, int64_t n_rays, int S,
                        const double* boxes, int n_boxes, void* stream);
+/* the same, and additionally rgb[n, s, :] = 0 on the rays with z_vals[n, S-1] == 0 (rgb may be NULL): for rays that
+ * objnerf_compact_rays culled before the MLP kernel, whose sigma / rgb were never written */
+int objnerf_mask_sigma_rgb(float* sigma, float* rgb, const float* rays, const float* z_vals, int64_t n_rays, int S,
+                           const double* boxes, int n_boxes, void* stream);
+/* Ray culling without a host round trip: ray_index[0 .. *n_active) = the rays with z_vals[n, S-1] != 0 (the complement of
+ * multi_rendering.py:40's zero_mask), ascending; both written on the stream.  scratch: objnerf_compact_scratch_ints(n_rays)
+ * int32.  Feed ray_index / n_active to objnerf_mlp_args. */
+int64_t objnerf_compact_scratch_ints(int64_t n_rays);
+int objnerf_compact_rays(const float* z_vals, int64_t n_rays, int S, int32_t* ray_index, int32_t* n_active,
+                         int32_t* scratch, void* stream);
 /* check_in_any_boxes (bbox_utils.py:189-207) on explicit points: xyz (n,3) -> inside (n) uint8 */
 int objnerf_points_in_boxes(const float* xyz, int64_t n, const double* boxes, int n_boxes,
                             uint8_t* inside, void* stream);
@@ -277,6 +294,53 @@ int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_
 int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* in,
                         const objnerf_render_out* coarse, const objnerf_render_out* fine,
                         void* stream);
+
+/* ---- whole render_rays_multi (render_tools/multi_rendering.py:160-325) in one enqueue ----
+ * K ray sets of the same pixels (obj id 0 = background: scene branch; id > 0: object branch with row `id` of the code
+ * table), per set coarse depths -> culling of the rays that missed their box (objnerf_compact_rays; no host round
+ * trip) -> one branch of the fused MLP kernel over the surviving rays -> sigma masks (culled rays, samples inside the
+ * removed objects' boxes for id 0) -> joint depth-sorted compositing -> per-set importance sampling from the set's own
+ * weights -> the same again with the fine model.  Nothing is synchronised or allocated. */
+typedef struct {
+  int32_t use_voxel;
+  int32_t N_samples;
+  int32_t N_importance;
+  int32_t use_disp;
+  float perturb;             /* != 0: the importance samples use u_rand instead of linspace (multi_rendering.py:276) */
+  float noise_std;
+  int32_t white_back;
+  int32_t mfma_bf16x3;
+} objnerf_render_multi_cfg;
+
+typedef struct {
+  int64_t n_rays;
+  int32_t K;
+  const float* const* h_rays;      /* HOST array of K device pointers, each (N,8) [o, d, near, far] */
+  const int32_t* h_obj_ids;        /* HOST array of K ids */
+  const float* code_table;         /* (N_max_objs, 64) code_library.embedding_instance.weight (multi_rendering.py:46) */
+  const float* blob_coarse; const float* aux_coarse;
+  const float* blob_fine; const float* aux_fine;
+  objnerf_voxel_grid grid;
+  const float* z_steps;            /* linspace(0,1,N_samples) */
+  const float* u_det;              /* linspace(0,1,N_importance) */
+  const float* u_rand;             /* (K,N,I) uniform draws, read when perturb != 0 */
+  const float* noise_coarse;       /* (N,K*S) N(0,1) draws, read when noise_std != 0 */
+  const float* noise_fine;         /* (N,K*(S+I)) */
+  const double* boxes;             /* n_boxes x OBJNERF_BOX_DOUBLES: background_skip_bbox, applied to id-0 sets */
+  int32_t n_boxes;
+  void* workspace;                 /* objnerf_render_multi_workspace_bytes() */
+} objnerf_render_multi_in;
+
+typedef struct {
+  /* (N, K*S_typ) */ float* z_vals; float* weights; float* obj_ids;   /* obj_ids: coarse pass only, may be NULL */
+  /* (N) */ float* opacity; float* depth;
+  /* (N,3) */ float* rgb;
+} objnerf_render_multi_out;
+
+int64_t objnerf_render_multi_workspace_bytes(const objnerf_render_multi_cfg* cfg, int32_t K, int64_t n_rays);
+int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf_render_multi_in* in,
+                              const objnerf_render_multi_out* coarse, const objnerf_render_multi_out* fine,
+                              void* stream);
 
 /* ---- training path: differentiable stages behind train.py:147-180 ---- */
 

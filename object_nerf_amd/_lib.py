@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 3     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 4     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -45,6 +45,7 @@ class MlpArgs(C.Structure):
         ("n_points", C.c_int64),
         ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
         ("sigma_only", C.c_int32), ("mfma_bf16x3", C.c_int32),
+        ("ray_index", C.c_void_p), ("n_active", C.c_void_p),
     ]
 
 
@@ -116,6 +117,33 @@ class RenderIn(C.Structure):
     ]
 
 
+class RenderMultiCfg(C.Structure):
+    _fields_ = [
+        ("use_voxel", C.c_int32), ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("use_disp", C.c_int32),
+        ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32), ("mfma_bf16x3", C.c_int32),
+    ]
+
+
+class RenderMultiIn(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_int64), ("K", C.c_int32),
+        ("h_rays", C.POINTER(C.c_void_p)), ("h_obj_ids", C.POINTER(C.c_int32)), ("code_table", C.c_void_p),
+        ("blob_coarse", C.c_void_p), ("aux_coarse", C.c_void_p), ("blob_fine", C.c_void_p), ("aux_fine", C.c_void_p),
+        ("grid", VoxelGrid),
+        ("z_steps", C.c_void_p), ("u_det", C.c_void_p), ("u_rand", C.c_void_p),
+        ("noise_coarse", C.c_void_p), ("noise_fine", C.c_void_p),
+        ("boxes", C.c_void_p), ("n_boxes", C.c_int32),
+        ("workspace", C.c_void_p),
+    ]
+
+
+class RenderMultiOut(C.Structure):
+    _fields_ = [
+        ("z_vals", C.c_void_p), ("weights", C.c_void_p), ("obj_ids", C.c_void_p),
+        ("opacity", C.c_void_p), ("depth", C.c_void_p), ("rgb", C.c_void_p),
+    ]
+
+
 # every symbol include/objnerf_hip.h declares: (restype, argtypes)
 _VP = C.c_void_p
 SIGNATURES = {
@@ -143,11 +171,17 @@ SIGNATURES = {
     "objnerf_sample_pdf_merge": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP]),
     "objnerf_sample_pdf": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP]),
     "objnerf_mask_sigma": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_int, _VP]),
+    "objnerf_mask_sigma_rgb": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_int, _VP]),
+    "objnerf_compact_scratch_ints": (C.c_int64, [C.c_int64]),
+    "objnerf_compact_rays": (C.c_int, [_VP, C.c_int64, C.c_int, _VP, _VP, _VP, _VP]),
     "objnerf_points_in_boxes": (C.c_int, [_VP, C.c_int64, _VP, C.c_int, _VP, _VP]),
     "objnerf_composite_multi": (C.c_int, [C.POINTER(CompositeMultiArgs), _VP]),
     "objnerf_generate_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, C.c_float, C.c_float, _VP, C.c_double, _VP, _VP]),
     "objnerf_render_workspace_bytes": (C.c_int64, [C.POINTER(RenderCfg), C.c_int64]),
     "objnerf_render_rays": (C.c_int, [C.POINTER(RenderCfg), C.POINTER(RenderIn), C.POINTER(RenderOut), C.POINTER(RenderOut), _VP]),
+    "objnerf_render_multi_workspace_bytes": (C.c_int64, [C.POINTER(RenderMultiCfg), C.c_int32, C.c_int64]),
+    "objnerf_render_rays_multi": (C.c_int, [C.POINTER(RenderMultiCfg), C.POINTER(RenderMultiIn), C.POINTER(RenderMultiOut),
+                                            C.POINTER(RenderMultiOut), _VP]),
     "objnerf_gemm": (C.c_int, [_VP, C.c_int64, C.c_int, _VP, C.c_int64, C.c_int, _VP, C.c_int64, C.c_int64, C.c_int64,
                                C.c_int64, C.c_int, C.c_int, _VP, C.c_int, _VP]),
     "objnerf_train_workspace_floats": (C.c_int64, [C.c_int, C.c_int64]),

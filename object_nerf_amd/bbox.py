@@ -16,6 +16,9 @@ import torch
 from . import _lib
 
 
+_packed = {}
+
+
 def _box_row(box, scale_factor=None, bbox_enlarge=0.0):
     if isinstance(box, dict):
         sf = box["scale_factor"] if scale_factor is None else scale_factor
@@ -47,7 +50,15 @@ def pack_boxes(boxes, device, scale_factor=None, bbox_enlarge=0.0):
         return torch.zeros(0, _lib.BOX_DOUBLES, dtype=torch.float64, device=device)
     rows = np.stack([_box_row(b, scale_factor, bbox_enlarge) for b in seq])
     assert rows.shape[1] == _lib.BOX_DOUBLES
-    return torch.from_numpy(rows).to(device)
+    # the editor passes the same boxes with every ray chunk of a frame (editable_renderer.py:270-287): keep the device
+    # copy of the last few distinct box sets instead of a blocking host-to-device copy per call
+    key = (rows.tobytes(), str(device))
+    hit = _packed.get(key)
+    if hit is None:
+        if len(_packed) >= 16:
+            _packed.pop(next(iter(_packed)))
+        hit = _packed[key] = torch.from_numpy(rows).to(device)
+    return hit
 
 
 def check_in_any_boxes(boxes, xyz, scale_factor=None, bbox_enlarge=0.0):

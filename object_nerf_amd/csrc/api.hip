@@ -350,4 +350,108 @@ int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* 
   return render_pass(cfg, in, fine, in->blob_fine, in->aux_fine, S + I, in->noise[2], in->noise[3], stream);
 }
 
+// ---- whole render_rays_multi (render_tools/multi_rendering.py:160-325) in one enqueue ---------------------------
+// workspace per ray set k: zc (N*S) | zf (N*(S+I)) | sigma (N*Smax) | rgb (3*N*Smax) | own weights (N*S) | ray_index (N int32)
+// then: n_active (K int32, 256-byte slots) | compaction scratch
+namespace {
+struct MultiWs {
+  int64_t N; int S, I, Smax;
+  char* base;
+  int64_t set_floats() const { return N * ((int64_t)S + (S + I) + 4LL * Smax + S) + N; }
+  float* set(int k) const { return (float*)base + set_floats() * k; }
+  float* zc(int k) const { return set(k); }
+  float* zf(int k) const { return zc(k) + N * S; }
+  float* sigma(int k) const { return zf(k) + N * (S + I); }
+  float* rgb(int k) const { return sigma(k) + N * Smax; }
+  float* own(int k) const { return rgb(k) + 3 * N * Smax; }
+  int32_t* idx(int k) const { return (int32_t*)(own(k) + N * S); }
+  int32_t* count(int K, int k) const { return (int32_t*)((float*)base + set_floats() * K) + 64 * k; }
+  int32_t* scratch(int K) const { return count(K, K); }
+};
+}  // namespace
+
+int64_t objnerf_render_multi_workspace_bytes(const objnerf_render_multi_cfg* cfg, int32_t K, int64_t n_rays) {
+  if (!cfg || K < 1 || n_rays < 0) return -1;
+  const int I = cfg->N_importance > 0 ? cfg->N_importance : 0;
+  MultiWs w{n_rays, cfg->N_samples, I, cfg->N_samples + I, nullptr};
+  return 4 * (w.set_floats() * K + 64LL * K + objnerf_compact_scratch_ints(n_rays)) + 256;
+}
+
+int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf_render_multi_in* in,
+                              const objnerf_render_multi_out* coarse, const objnerf_render_multi_out* fine, void* stream) {
+  if (!cfg || !in || !coarse) return set_error(-1, "render_rays_multi: null argument");
+  const int K = in->K, S = cfg->N_samples, I = cfg->N_importance > 0 ? cfg->N_importance : 0;
+  const int64_t N = in->n_rays;
+  if (K < 1 || K > 16 || S < 1 || N < 0) return set_error(-1, "render_rays_multi: bad sizes (1 <= K <= 16)");
+  if (N == 0) return 0;
+  if (!in->h_rays || !in->h_obj_ids || !in->workspace || !in->blob_coarse || !in->aux_coarse || !in->z_steps)
+    return set_error(-1, "render_rays_multi: missing input");
+  if (I > 0 && (!fine || !in->blob_fine || !in->aux_fine)) return set_error(-1, "render_rays_multi: N_importance > 0 needs the fine model and outputs");
+  const bool det = cfg->perturb == 0.f;
+  if (I > 0 && (det ? !in->u_det : !in->u_rand)) return set_error(-1, "render_rays_multi: missing u_det / u_rand");
+  if (cfg->noise_std != 0.f && (!in->noise_coarse || (I > 0 && !in->noise_fine)))
+    return set_error(-1, "render_rays_multi: noise_std != 0 needs noise draws");
+  for (int k = 0; k < K; ++k) {
+    if (!in->h_rays[k]) return set_error(-1, "render_rays_multi: null ray set");
+    if (in->h_obj_ids[k] > 0 && !in->code_table) return set_error(-1, "render_rays_multi: object sets need the code table");
+    if (in->h_obj_ids[k] < 0) return set_error(-1, "render_rays_multi: negative object id");
+  }
+  MultiWs w{N, S, I, S + I, (char*)in->workspace};
+
+  auto one_pass = [&](bool is_fine, const float* blob, const float* aux, const objnerf_render_multi_out* out) -> int {
+    const int Sp = is_fine ? S + I : S;
+    const float *hz[16], *hs[16], *hr[16];
+    float* how[16];
+    for (int k = 0; k < K; ++k) {
+      float* z = is_fine ? w.zf(k) : w.zc(k);
+      int rc;
+      if (!is_fine) {
+        // coarse depths are never perturbed here (multi_rendering.py:203-210)
+        rc = objnerf_sample_coarse(in->h_rays[k], in->z_steps, nullptr, 0.f, cfg->use_disp, N, S, z, stream);
+      } else {
+        // importance sampling from the set's OWN weights of the joint compositing (multi_rendering.py:266-283)
+        rc = objnerf_sample_pdf_merge(w.zc(k), w.own(k), det ? in->u_det : in->u_rand + (int64_t)k * N * I, det ? 0 : I, N, S, I,
+                                      1e-5f, nullptr, z, stream);
+      }
+      if (rc) return rc;
+      // rays that missed their object's box (near = far = 0 => all depths 0): sigma is forced to -1e5 afterwards
+      // (multi_rendering.py:40,83,92), i.e. exactly zero weight -- they are culled before the MLP kernel instead
+      rc = objnerf_compact_rays(z, N, Sp, w.idx(k), w.count(K, k), w.scratch(K), stream);
+      if (rc) return rc;
+      const int oid = in->h_obj_ids[k];
+      objnerf_mlp_args m;
+      memset(&m, 0, sizeof(m));
+      m.use_voxel = cfg->use_voxel; m.mfma_bf16x3 = cfg->mfma_bf16x3;
+      m.blob = blob; m.aux = aux;
+      m.rays = in->h_rays[k]; m.z_vals = z; m.n_rays = N; m.S = Sp; m.grid = in->grid;
+      m.ray_index = w.idx(k); m.n_active = w.count(K, k);
+      if (oid > 0) {        // object branch with that id's code (multi_rendering.py:45-51, 63-69)
+        m.do_object = 1; m.codes = in->code_table + (int64_t)oid * 64; m.code_stride = 0;
+        m.inst_sigma = w.sigma(k); m.inst_rgb = w.rgb(k);
+      } else {              // background: scene branch
+        m.do_scene = 1; m.sigma = w.sigma(k); m.rgb = w.rgb(k);
+      }
+      rc = objnerf_mlp_eval(&m, stream);
+      if (rc) return rc;
+      const bool use_boxes = oid == 0 && in->n_boxes > 0;                       // multi_rendering.py:239-241
+      rc = objnerf_mask_sigma_rgb(w.sigma(k), w.rgb(k), in->h_rays[k], z, N, Sp, use_boxes ? in->boxes : nullptr,
+                                  use_boxes ? in->n_boxes : 0, stream);
+      if (rc) return rc;
+      hz[k] = z; hs[k] = w.sigma(k); hr[k] = w.rgb(k); how[k] = w.own(k);
+    }
+    objnerf_composite_multi_args c;
+    memset(&c, 0, sizeof(c));
+    c.n_rays = N; c.K = K; c.S = Sp; c.h_z = hz; c.h_sigma = hs; c.h_rgb = hr;
+    c.noise = is_fine ? in->noise_fine : in->noise_coarse; c.noise_std = cfg->noise_std; c.white_back = cfg->white_back;
+    c.z_sorted = out->z_vals; c.weights = out->weights; c.obj_ids = out->obj_ids;
+    c.opacity = out->opacity; c.rgb_map = out->rgb; c.depth = out->depth;
+    c.h_own_weights = (!is_fine && I > 0) ? how : nullptr;
+    return objnerf_composite_multi(&c, stream);
+  };
+
+  int rc = one_pass(false, in->blob_coarse, in->aux_coarse, coarse);
+  if (rc || I <= 0) return rc;
+  return one_pass(true, in->blob_fine, in->aux_fine, fine);
+}
+
 }  // extern "C"

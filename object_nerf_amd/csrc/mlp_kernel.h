@@ -710,8 +710,12 @@ struct TilePrologue {
   __device__ __forceinline__ void stage_a(const objnerf_mlp_args& a, long tile, long P, int wave, int lane) {
     const long p_raw = tile * 128 + wave * 32 + (lane & 31);
     valid = p_raw < P;
-    p = valid ? p_raw : P - 1;
-    ray = p / a.S;
+    const long pc = valid ? p_raw : P - 1;
+    const long slot = pc / a.S;
+    // ray subset (objnerf_mlp_args.ray_index): tiles walk the listed rays only; p stays the point's index in the
+    // full (n_rays, S) arrays, so depths are read and results written in place
+    ray = a.ray_index ? (long)a.ray_index[slot] : slot;
+    p = ray * a.S + (pc - slot * a.S);
     const float* r = a.rays + ray * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) rw[i] = r[i];
@@ -878,7 +882,7 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 // the kernel
 // ---------------------------------------------------------------------------------------------
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false>
-__global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles, float* const save_ws = nullptr) {
+__global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr) {
   static_assert(!B3 || (FUSED && !SIGMA_ONLY), "split-bf16 mode: fused form only");
   constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
@@ -895,11 +899,21 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   constexpr int kStart = DO_SCENE ? 0 : scene_chunks(VOXEL);
   constexpr int kEnd = SIGMA_ONLY ? layer_chunk_start(VOXEL, DO_SCENE ? L_SF : L_OF)
                                   : (DO_OBJ ? total_chunks(VOXEL) : scene_chunks(VOXEL));
+  // ray subset: the number of listed rays lives in device memory (written by objnerf_compact_rays earlier on the
+  // stream), so a caller can cull rays without a host round trip; the grid was sized for all n_rays
+  long P = FUSED ? a.n_rays * (long)a.S : a.n_points;
+  long ntiles = ntiles_arg;
+  if constexpr (FUSED && !SAVE) {
+    if (a.n_active) {
+      P = (long)(*a.n_active) * a.S;
+      ntiles = (P + 127) / 128;
+      if (P == 0) return;            // uniform across the grid; nothing has been issued yet
+    }
+  }
   WeightStreamT<kCB> st;
   st.init((const char*)a.blob + (size_t)kStart * kCB, kEnd - kStart,
           (lds_char*)ring_mem, tid);
 
-  const long P = FUSED ? a.n_rays * (long)a.S : a.n_points;
   const SaveWs ws{save_ws, P};
 #if OBJ_AUX_LDS
   // biases + head weights (16 KiB) are read by every wave every pass: stage them once in LDS

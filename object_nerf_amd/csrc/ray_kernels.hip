@@ -429,19 +429,75 @@ __device__ __forceinline__ bool in_any_box(float x, float y, float z, const doub
   return in;
 }
 
-__global__ void mask_sigma_kernel(float* __restrict__ sigma, const float* __restrict__ rays,
+__global__ void mask_sigma_kernel(float* __restrict__ sigma, float* __restrict__ rgb, const float* __restrict__ rays,
                                   const float* __restrict__ z_vals, long n_rays, int S,
                                   const double* __restrict__ boxes, int n_boxes) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rays * S) return;
   const long ray = idx / S;
   bool kill = z_vals[ray * S + S - 1] == 0.f;          // zero_mask, multi_rendering.py:40,83,92
+  if (kill && rgb) {
+    // the ray was not evaluated at all (objnerf_compact_rays): its colours are never weighted (alpha = 0 exactly) but
+    // must be finite for 0 * rgb
+    rgb[idx * 3] = 0.f; rgb[idx * 3 + 1] = 0.f; rgb[idx * 3 + 2] = 0.f;
+  }
   if (!kill && n_boxes > 0) {
     const float* r = rays + ray * 8;
     const float zv = z_vals[idx];
     kill = in_any_box(r[0] + r[3] * zv, r[1] + r[4] * zv, r[2] + r[5] * zv, boxes, n_boxes);   // :239-241
   }
   if (kill) sigma[idx] = -1e5f;
+}
+
+// Ray culling on the device (no host round trip): the rays whose last depth is non-zero, in ascending order.
+// Two launches: per-block counts, then every block sums the counts in front of it and writes its rays.
+constexpr int kCompactBlock = 1024;
+__global__ void __launch_bounds__(kCompactBlock) ray_count_kernel(const float* __restrict__ z_vals, long n_rays, int S,
+                                                                  int* __restrict__ block_counts) {
+  __shared__ int wave_cnt[kCompactBlock / 64];
+  const long ray = (long)blockIdx.x * kCompactBlock + threadIdx.x;
+  const bool on = ray < n_rays && !(z_vals[ray * S + S - 1] == 0.f);
+  const unsigned long long m = __ballot(on);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < kCompactBlock / 64; ++w) t += wave_cnt[w];
+    block_counts[blockIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(kCompactBlock) ray_compact_kernel(const float* __restrict__ z_vals, long n_rays, int S,
+                                                                    const int* __restrict__ block_counts,
+                                                                    int* __restrict__ ray_index, int* __restrict__ n_active) {
+  __shared__ int wave_cnt[kCompactBlock / 64];
+  __shared__ int part[kCompactBlock / 64];
+  __shared__ int base_sh;
+  // rays in front of this block, and (block 0) the grand total
+  int mine = 0, all = 0;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += kCompactBlock) {
+    const int c = block_counts[b];
+    all += c;
+    mine += b < (int)blockIdx.x ? c : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) { mine += __shfl_xor(mine, o); all += __shfl_xor(all, o); }
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = mine; wave_cnt[threadIdx.x >> 6] = all; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0, ta = 0;
+    for (int w = 0; w < kCompactBlock / 64; ++w) { t += part[w]; ta += wave_cnt[w]; }
+    base_sh = t;
+    if (blockIdx.x == 0) *n_active = ta;
+  }
+  __syncthreads();
+  const long ray = (long)blockIdx.x * kCompactBlock + threadIdx.x;
+  const bool on = ray < n_rays && !(z_vals[ray * S + S - 1] == 0.f);
+  const unsigned long long m = __ballot(on);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = __popcll(m);
+  __syncthreads();
+  int off = base_sh;
+  for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+  if (on) ray_index[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)ray;
 }
 
 __global__ void points_in_boxes_kernel(const float* __restrict__ xyz, long n, const double* __restrict__ boxes,
@@ -703,11 +759,30 @@ int objnerf_sample_pdf_merge(const float* z_coarse, const float* weights, const 
 
 int objnerf_mask_sigma(float* sigma, const float* rays, const float* z_vals, int64_t n_rays, int S,
                        const double* boxes, int n_boxes, void* stream) {
+  return objnerf_mask_sigma_rgb(sigma, nullptr, rays, z_vals, n_rays, S, boxes, n_boxes, stream);
+}
+
+int objnerf_mask_sigma_rgb(float* sigma, float* rgb, const float* rays, const float* z_vals, int64_t n_rays, int S,
+                           const double* boxes, int n_boxes, void* stream) {
   if (!sigma || !rays || !z_vals || S < 1 || (n_boxes > 0 && !boxes)) return set_error(-1, "mask_sigma: bad arguments");
   if (n_rays == 0) return 0;
   hipLaunchKernelGGL(mask_sigma_kernel, dim3(blocks_for(n_rays * S, 256)), dim3(256), 0, (hipStream_t)stream,
-                     sigma, rays, z_vals, (long)n_rays, S, boxes, n_boxes);
+                     sigma, rgb, rays, z_vals, (long)n_rays, S, boxes, n_boxes);
   return check_launch("mask_sigma");
+}
+
+int64_t objnerf_compact_scratch_ints(int64_t n_rays) { return (n_rays + kCompactBlock - 1) / kCompactBlock + 1; }
+
+int objnerf_compact_rays(const float* z_vals, int64_t n_rays, int S, int32_t* ray_index, int32_t* n_active,
+                         int32_t* scratch, void* stream) {
+  if (!z_vals || !ray_index || !n_active || !scratch || S < 1 || n_rays < 0 || n_rays > 0x7fffffffll)
+    return set_error(-1, "compact_rays: bad arguments");
+  const unsigned nb = blocks_for(n_rays, kCompactBlock);
+  if (nb == 0) return hipMemsetAsync(n_active, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? 0 : set_error(-2, "compact_rays: memset failed");
+  hipLaunchKernelGGL(ray_count_kernel, dim3(nb), dim3(kCompactBlock), 0, (hipStream_t)stream, z_vals, (long)n_rays, S, scratch);
+  hipLaunchKernelGGL(ray_compact_kernel, dim3(nb), dim3(kCompactBlock), 0, (hipStream_t)stream, z_vals, (long)n_rays, S,
+                     scratch, ray_index, n_active);
+  return check_launch("compact_rays");
 }
 
 int objnerf_points_in_boxes(const float* xyz, int64_t n, const double* boxes, int n_boxes, uint8_t* inside,

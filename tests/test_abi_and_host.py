@@ -168,3 +168,24 @@ def test_c_abi_argument_validation():
     assert l.objnerf_sample_pdf_merge(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None) < 0
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * 128 * 8 + 256
+
+
+def test_library_never_allocates_or_synchronises():
+    """include/objnerf_hip.h's contract: entry points only ENQUEUE on the caller's stream.  The one permitted wait is
+    objnerf_timing_read (bench.py's measurement hook) on its own events; there is no device allocation, no blocking copy
+    and no stream / device synchronisation anywhere under csrc/ -- in particular none inside objnerf_render_rays_multi,
+    whose ray culling counts on the device (objnerf_compact_rays) instead of reading a count back."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "object_nerf_amd", "csrc")
+    banned = re.compile(r"\b(hipMalloc\w*|hipFree\w*|hipMemcpy(?!Async)\w*|hipDeviceSynchronize|hipStreamSynchronize|"
+                        r"hipStreamWaitEvent|hipHostMalloc|hipMemcpyAsync)\b")
+    hits = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        for no, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            if banned.search(code):
+                hits.append("%s:%d %s" % (os.path.basename(path), no, code.strip()))
+    assert not hits, hits
+    waits = [ln for ln in open(os.path.join(csrc, "api.hip")) if "hipEventSynchronize" in ln.split("//")[0]]
+    assert len(waits) == 1            # objnerf_timing_read

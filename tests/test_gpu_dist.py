@@ -37,7 +37,8 @@ def test_bench_sharded_frame_over_rccl_world1_equals_plain_config2():
     dist = _bench(["--config", "3", "--dist"], env={"MASTER_PORT": "29533"})
     assert "multi_gpu" not in plain and dist["multi_gpu"]["world_size"] == 1
     assert "RCCL" in dist["multi_gpu"]["backend"] and "RCCL" in dist["config"]["collective"]
-    assert dist["config"]["mean_rgb_fine"] == plain["config"]["mean_rgb_fine"]
+    # identical pixels: the float64 mean is independent of the gathered tensor's layout / reduction order
+    assert abs(dist["config"]["mean_rgb_fine"] - plain["config"]["mean_rgb_fine"]) <= 1e-12 * plain["config"]["mean_rgb_fine"]
     assert dist["config"]["evals_per_step_all_ranks"] == plain["config"]["evals_per_step_all_ranks"] == 320 * 240 * 256
     assert abs(dist["value"] / plain["value"] - 1.0) < 0.05, (dist["value"], plain["value"])
     assert dist["roofline"]["frac"] > 0.5 and dist["roofline"]["flop_per_eval"] == 1776128

@@ -303,3 +303,26 @@ def test_split_bf16_mode_matches_f32_mfma_mode(monkeypatch):
     monkeypatch.setenv("OBJNERF_MFMA", "fp16")
     with pytest.raises(RuntimeError), torch.no_grad():
         A.render_rays(sc.models, sc.embeddings, rays[:8].contiguous(), **dict(kw, embedding_instance=codes[:8]))
+
+
+def test_render_rays_multi_is_one_enqueue_without_host_round_trips():
+    """the whole call -- depths, ray culling, 2K MLP launches, masks, compositing, importance sampling -- is issued
+    without the host ever waiting for the device (round 1 read the survivor count back per ray set and pass).  torch's
+    sync debug mode turns every synchronising torch call into an error; the library itself has no synchronising HIP
+    call (tests/test_abi_and_host.py::test_library_never_allocates_or_synchronises)."""
+    sc = scene("voxel")
+    sets, boxes = cases.multi_inputs()
+    dsets = [s.to(DEV) for s in sets]
+    m = cases.MULTI
+    kw = dict(N_samples=m["N_samples"], N_importance=m["N_importance"], perturb=0, noise_std=0, background_skip_bbox={4: boxes[0]})
+    with torch.no_grad():
+        warm = render_rays_multi(sc.models, sc.embeddings, sc.code_library, dsets, m["obj_ids"], **kw)   # packs weights, caches tables
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            r = render_rays_multi(sc.models, sc.embeddings, sc.code_library, dsets, m["obj_ids"], **kw)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+    for k in warm:
+        assert torch.equal(r[k], warm[k]), k          # and it is deterministic

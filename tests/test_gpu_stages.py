@@ -238,3 +238,70 @@ def test_generate_rays_matches_reference():
     assert torch.equal(hit.cpu(), g["hit"].bool())                                     # same rays hit / miss
     assert (obj[~hit][:, 6:] == 0).all()
     check(obj[:, 6:], g["object"][:, 6:], 2e-6, "box near/far")
+
+
+# ---- ray culling on the device + ray-subset evaluation (the pieces behind objnerf_render_rays_multi) ----
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 5000])
+def test_compact_rays_matches_nonzero(n):
+    g = torch.Generator().manual_seed(n)
+    S = 7
+    z = torch.rand(n, S, generator=g) + 0.1
+    dead = torch.rand(n, generator=g) < 0.4
+    z[dead, -1] = 0.0
+    if n == 63:
+        z[:, -1] = 0.0                      # nothing survives
+    zd = z.to(DEV)
+    idx = torch.full((n,), -7, dtype=torch.int32, device=DEV)
+    cnt = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+    l = _lib.lib()
+    scratch = torch.empty(l.objnerf_compact_scratch_ints(n), dtype=torch.int32, device=DEV)
+    _lib.check(l.objnerf_compact_rays(_lib.ptr(zd), n, S, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(scratch), _lib.stream_ptr()),
+               "compact_rays")
+    want = (z[:, -1] != 0).nonzero().squeeze(1).to(torch.int32)
+    assert int(cnt.item()) == want.numel()
+    assert torch.equal(idx.cpu()[:want.numel()], want)          # ascending
+    assert (idx.cpu()[want.numel():] == -7).all()               # nothing written past the count
+
+
+@pytest.mark.parametrize("branch", ["scene", "object"])
+def test_mlp_eval_on_a_ray_subset(branch):
+    """objnerf_mlp_args.ray_index / n_active: the listed rays get exactly the values of a full evaluation, the other
+    rays' outputs are not touched; an empty list launches and writes nothing"""
+    from helpers import mfma_mode as _m  # noqa: F401
+    from object_nerf_amd.rendering import mfma_mode
+    sc = scene("voxel")
+    rays = H.test_rays(97, stride=31).to(DEV)
+    n, S = rays.shape[0], 24
+    z = (rays[:, 6:7] + (rays[:, 7:8] - rays[:, 6:7]) * torch.linspace(0, 1, S, device=DEV)).contiguous()
+    b3 = mfma_mode() == "bf16x3"
+    blob, aux = sc.models["coarse"].packed(split_bf16=b3)
+    code = sc.code_library.embedding_instance.weight.detach()[4].contiguous()
+    l = _lib.lib()
+
+    def run(index, count, sigma, rgb):
+        a = _lib.MlpArgs()
+        a.use_voxel, a.mfma_bf16x3 = 1, int(b3)
+        a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
+        a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), z.data_ptr(), n, S
+        a.grid = sc.embeddings["xyz"].grid_struct()
+        if branch == "object":
+            a.do_object, a.codes, a.code_stride = 1, code.data_ptr(), 0
+            a.inst_sigma, a.inst_rgb = sigma.data_ptr(), rgb.data_ptr()
+        else:
+            a.do_scene, a.sigma, a.rgb = 1, sigma.data_ptr(), rgb.data_ptr()
+        if index is not None:
+            a.ray_index, a.n_active = index.data_ptr(), count.data_ptr()
+        _lib.check(l.objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval")
+        torch.cuda.synchronize()
+
+    full_s, full_c = torch.empty(n, S, device=DEV), torch.empty(n, S, 3, device=DEV)
+    run(None, None, full_s, full_c)
+    pick = torch.tensor([5, 0, 96, 17, 18, 40, 41, 42, 43, 64], dtype=torch.int32, device=DEV)      # not ascending: allowed
+    padded = torch.cat([pick, torch.full((n - pick.numel(),), 3, dtype=torch.int32, device=DEV)])  # entries past the count
+    for count in (pick.numel(), 0):
+        sub_s, sub_c = torch.full((n, S), 123.0, device=DEV), torch.full((n, S, 3), 123.0, device=DEV)
+        run(padded, torch.tensor([count], dtype=torch.int32, device=DEV), sub_s, sub_c)
+        on = torch.zeros(n, dtype=torch.bool, device=DEV)
+        on[pick[:count].long()] = True
+        assert torch.equal(sub_s[on], full_s[on]) and torch.equal(sub_c[on], full_c[on])
+        assert (sub_s[~on] == 123.0).all() and (sub_c[~on] == 123.0).all()
