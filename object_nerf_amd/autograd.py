@@ -196,8 +196,17 @@ class RenderRaysFn(torch.autograd.Function):
         d_codes = torch.zeros(n, 64, dtype=torch.float32, device=dev) if fi else None
         param_grads = []
         pk = meta.get("packed") or (None, None)
-        for typ, ps, pp, packed in zip(("coarse", "fine"), ctx.passes, (ctx.p_coarse, ctx.p_fine), pk):
-            gp = [torch.zeros_like(p) for p in pp]
+        # every parameter gradient of both models lives in ONE zero-initialised flat buffer (one memset per step instead
+        # of one per tensor; the kernels accumulate into it): views at 256-byte boundaries
+        all_p = list(ctx.p_coarse) + (list(ctx.p_fine) if len(ctx.passes) > 1 else [])
+        offs, tot = [], 0
+        for p in all_p:
+            offs.append(tot)
+            tot += (p.numel() + 63) // 64 * 64
+        flat_g = torch.zeros(tot, dtype=torch.float32, device=dev)
+        views = [flat_g[o:o + p.numel()].view(p.shape) for o, p in zip(offs, all_p)]
+        for i, (typ, ps, pp, packed) in enumerate(zip(("coarse", "fine"), ctx.passes, (ctx.p_coarse, ctx.p_fine), pk)):
+            gp = views[i * len(ctx.p_coarse):i * len(ctx.p_coarse) + len(pp)]
             param_grads.append(gp)
             P, Sx = ps.emb_xyz.shape[0], ps.S
 

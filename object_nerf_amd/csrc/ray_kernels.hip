@@ -598,16 +598,35 @@ __global__ void __launch_bounds__(64) composite_multi_kernel(const MultiPtrs ptr
   int* rk = (int*)(sm + 6 * M);   // M  rank of unsorted element
   const int lane = threadIdx.x;
   for (long ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
-    for (int i = lane; i < M; i += 64) zin[i] = ptrs.z[i / S][ray * S + (i % S)];
+    bool asc = true;
+    for (int i = lane; i < M; i += 64) {
+      const int s = i % S;
+      const float* zk = ptrs.z[i / S] + ray * S;
+      const float v = zk[s];
+      zin[i] = v;
+      asc = asc && (s == 0 || !(v < zk[s - 1]));       // every set's depths ascending (NaN counts as not)
+      asc = asc && v == v;
+    }
+    asc = __ballot(asc) == ~0ull;
     __syncthreads();
     for (int i = lane; i < M; i += 64) {
       const float v = zin[i];
-      int rank = 0;
-      for (int j = 0; j < M; ++j) {
-        const float o = zin[j];
-        rank += (o < v || (o == v && j < i)) ? 1 : 0;
-      }
       const int k = i / S, s = i % S;
+      int rank = 0;
+      if (asc) {
+        // K ascending runs: the stable rank (ties in concatenation order, as torch.sort(..., stable) would give and as
+        // the O(M^2) count below defines it) is the element's position in its own run plus, per other run, the number
+        // of its elements that go in front: <= v for the runs before it, < v for the runs behind it -- K binary
+        // searches of log2(S) steps instead of M comparisons
+        rank = s;
+        for (int kk = 0; kk < K; ++kk)
+          if (kk != k) rank += count_below(zin + kk * S, S, v, kk < k);
+      } else {
+        for (int j = 0; j < M; ++j) {
+          const float o = zin[j];
+          rank += (o < v || (o == v && j < i)) ? 1 : 0;
+        }
+      }
       rk[i] = rank;
       zs[rank] = v;
       sgs[rank] = ptrs.sigma[k][ray * S + s];

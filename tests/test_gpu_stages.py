@@ -267,7 +267,6 @@ def test_compact_rays_matches_nonzero(n):
 def test_mlp_eval_on_a_ray_subset(branch):
     """objnerf_mlp_args.ray_index / n_active: the listed rays get exactly the values of a full evaluation, the other
     rays' outputs are not touched; an empty list launches and writes nothing"""
-    from helpers import mfma_mode as _m  # noqa: F401
     from object_nerf_amd.rendering import mfma_mode
     sc = scene("voxel")
     rays = H.test_rays(97, stride=31).to(DEV)
@@ -305,3 +304,49 @@ def test_mlp_eval_on_a_ray_subset(branch):
         on[pick[:count].long()] = True
         assert torch.equal(sub_s[on], full_s[on]) and torch.equal(sub_c[on], full_c[on])
         assert (sub_s[~on] == 123.0).all() and (sub_c[~on] == 123.0).all()
+
+
+@pytest.mark.single_mode
+@pytest.mark.parametrize("variant", ["ascending_with_ties", "one_set_descending", "noise_white"])
+def test_composite_multi_matches_oracle(variant):
+    """objnerf_composite_multi (joint stable depth sort + compositing, multi_rendering.py:96-157) against the oracle:
+    exact cross-set and in-set ties (stable order = set order, then sample order), a non-ascending set (the general
+    rank-sort path instead of the K-run merge), noise and white background."""
+    g = torch.Generator().manual_seed(5)
+    n, K, S = 37, 3, 20
+    zs = [torch.sort(torch.rand(n, S, generator=g) * 3.0, -1)[0] for _ in range(K)]
+    zs[1][:, 3:6] = zs[0][:, 3:6]                 # exact ties across sets
+    zs[1] = torch.sort(zs[1], -1)[0]
+    zs[2][:, 7] = zs[2][:, 8]                     # a tie inside a set
+    zs[2][::5] = 0.0                              # rays that missed their box
+    if variant == "one_set_descending":
+        zs[1] = torch.flip(zs[1], [-1]).contiguous()
+    sg = [torch.randn(n, S, generator=g) * 3.0 for _ in range(K)]
+    cs = [torch.rand(n, S, 3, generator=g) for _ in range(K)]
+    noise = torch.randn(n, K * S, generator=g) if variant == "noise_white" else None
+    kw = dict(noise_std=0.7, white_back=True) if variant == "noise_white" else dict(noise_std=0.0, white_back=False)
+    ref = O.composite_multi([z.clone() for z in zs], cs, sg, noise=noise, **kw)
+    M = K * S
+    dz, dsg, dcs = [z.to(DEV).contiguous() for z in zs], [t.to(DEV) for t in sg], [t.to(DEV) for t in cs]
+    out = {k: torch.empty(n, *sh, device=DEV) for k, sh in dict(z=(M,), w=(M,), ids=(M,), opacity=(), rgb=(3,), depth=()).items()}
+    own = [torch.empty(n, S, device=DEV) for _ in range(K)]
+    a = _lib.CompositeMultiArgs()
+    a.n_rays, a.K, a.S = n, K, S
+    arr = C.c_void_p * K
+    hz, hs, hr, ho = (arr(*[t.data_ptr() for t in ts]) for ts in (dz, dsg, dcs, own))
+    a.h_z, a.h_sigma, a.h_rgb, a.h_own_weights = hz, hs, hr, ho
+    nd = noise.to(DEV) if noise is not None else None
+    a.noise = nd.data_ptr() if nd is not None else None
+    a.noise_std, a.white_back = kw["noise_std"], int(kw["white_back"])
+    a.z_sorted, a.weights, a.obj_ids = out["z"].data_ptr(), out["w"].data_ptr(), out["ids"].data_ptr()
+    a.opacity, a.rgb_map, a.depth = out["opacity"].data_ptr(), out["rgb"].data_ptr(), out["depth"].data_ptr()
+    _lib.check(_lib.lib().objnerf_composite_multi(C.byref(a), _lib.stream_ptr()), "composite_multi")
+    torch.cuda.synchronize()
+    assert torch.equal(out["z"].cpu(), ref["z_vals"]) and torch.equal(out["ids"].cpu(), ref["obj_ids"])    # same stable order
+    for k, rk in (("w", "weights"), ("opacity", "opacity"), ("rgb", "rgb"), ("depth", "depth")):
+        check(out[k], ref[rk], 2e-5, "composite_multi %s/%s" % (variant, rk))
+    for i in range(K):       # weights[obj_ids == i] in the set's own sample order (multi_rendering.py:269-271)
+        want = ref["weights"][ref["obj_ids"] == i].view(n, S)
+        if variant == "one_set_descending" and i == 1:
+            want = torch.flip(want, [-1])          # sorted order of a descending set is its reverse
+        check(own[i], want, 2e-5, "own weights %d" % i)

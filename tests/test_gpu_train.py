@@ -2,6 +2,7 @@
 compositing backward, voxel-embedding backward and the end-to-end gradients of render_rays -- against
 PyTorch autograd through the CPU oracle (oracle/objnerf_oracle.py is plain differentiable torch)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -61,19 +62,27 @@ def _loss(res, seed=0):
     return tot
 
 
-@pytest.mark.parametrize("case", ["voxel_train", "plain_train", "voxel_eval_flags", "voxel_random"])
+@pytest.mark.parametrize("case", ["voxel_train", "plain_train", "voxel_eval_flags", "voxel_random", "voxel_reference_batch"])
 def test_render_rays_gradients_match_oracle_autograd(case):
     cfgs = {
+        # the reference's training batch (config/default_conf.yml: batch_size 2048, N_samples 64, N_importance 64 -> 64 + 128
+        # points per ray = 393,216 sample points), training flags, random draws: ~1000 tiles of the persistent kernels,
+        # every workgroup busy, split-K weight gradients over 3072 k-blocks
+        "voxel_reference_batch": dict(scene="voxel", kw=dict(is_eval=False, frustum_bound_th=0.025, perturb=1.0, noise_std=1.0),
+                                      rnd=True, ptm=True, sizes=(64, 64, 2048)),
         "voxel_train": dict(scene="voxel", kw=dict(is_eval=False, frustum_bound_th=0.025, rays_in_bbox=False), ptm=True),
         "plain_train": dict(scene="plain", kw=dict(is_eval=False, frustum_bound_th=-1.0, white_back=True)),
         "voxel_eval_flags": dict(scene="sparse", kw=dict(is_eval=True, use_zero_as_last_delta=True, use_disp=True, rays_in_bbox=True)),
         "voxel_random": dict(scene="voxel", kw=dict(is_eval=False, frustum_bound_th=0.025, perturb=1.0, noise_std=1.0), rnd=True),
     }
     c = cfgs[case]
-    S, I, n = 16, 16, 24
+    if "sizes" in c and os.environ.get("OBJNERF_MFMA", "f32") != "f32":
+        pytest.skip("three 393k-point autograd passes of the CPU oracle: run once (the fused kernels' split-bf16 mode is "
+                    "covered by the other cases and test_gradients_in_split_bf16_mode)")
+    S, I, n = c.get("sizes", (16, 16, 24))
     sc = cases.scene_for(A, c["scene"], device=DEV)
     use_voxel = cases.SCENES[c["scene"]][0]
-    rays = H.test_rays(n, stride=97)
+    rays = H.test_rays(n, stride=97) if n <= 24 else H.test_rays(n, w=256, h=192, stride=23)
     ids = synth.per_ray_ids(n, seed=5)
     ptm = (torch.arange(n) % 3 == 0).view(n, 1) if c.get("ptm") else None
     randoms = None
@@ -100,39 +109,73 @@ def test_render_rays_gradients_match_oracle_autograd(case):
     _loss(res).backward()
 
     # ---- oracle autograd on the CPU
-    pc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sc.models["coarse"].state_dict().items()}
-    pf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sc.models["fine"].state_dict().items()}
-    ctab = sc.code_library.embedding_instance.weight.detach().cpu().clone().requires_grad_(True)
-    grid = None
-    if use_voxel:
-        grid = H.oracle_grid(sc.embeddings["xyz"])
-        grid["table"] = grid["table"].clone().requires_grad_(True)
-    # teacher-forced fine depths: both sides differentiate at the same sample points (the sampler itself carries no
-    # gradient, rendering.py:307, and its fp32 sensitivity is graded separately in test_gpu_render.py)
-    ro = O.render_rays(pc, pf, grid, rays, embedding_instance=ctab[ids], pass_through_mask=ptm, randoms=randoms,
-                       z_fine_override=res["z_vals_fine"].detach().cpu(), **{k: v for k, v in kw.items()})
-    _loss({k: v for k, v in ro.items()}).backward()
+    def oracle_grads(perturb_seed=None, z_fine=None):
+        """perturb_seed: every floating-point weight multiplied by (1 +- 2^-24): the oracle's own sensitivity to one ulp"""
+        gen = torch.Generator().manual_seed(perturb_seed) if perturb_seed is not None else None
+
+        def prep(sd):
+            out = {}
+            for k, v in sd.items():
+                v = v.detach().cpu().clone()
+                if gen is not None and v.is_floating_point():
+                    v = v * (1 + (torch.randint(0, 2, v.shape, generator=gen) * 2 - 1).float() * 2.0 ** -24)
+                out[k] = v.requires_grad_(True)
+            return out
+        pc, pf = prep(sc.models["coarse"].state_dict()), prep(sc.models["fine"].state_dict())
+        ctab = sc.code_library.embedding_instance.weight.detach().cpu().clone().requires_grad_(True)
+        grid = None
+        if use_voxel:
+            grid = H.oracle_grid(sc.embeddings["xyz"])
+            grid["table"] = grid["table"].clone().requires_grad_(True)
+        # teacher-forced fine depths: both sides differentiate at the same sample points (the sampler itself carries no
+        # gradient, rendering.py:307, and its fp32 sensitivity is graded separately in test_gpu_render.py)
+        ro = O.render_rays(pc, pf, grid, rays, embedding_instance=ctab[ids], pass_through_mask=ptm, randoms=randoms,
+                           z_fine_override=z_fine, **{k: v for k, v in kw.items()})
+        _loss({k: v for k, v in ro.items()}).backward()
+        return ro, pc, pf, ctab, grid
+
+    ro, pc, pf, ctab, grid = oracle_grads(z_fine=res["z_vals_fine"].detach().cpu())
 
     # forward values of the training path agree with the oracle as well
     for k in ro:
         assert H.normwise(res[k], ro[k]) < 1e-4, k
-    worst = 0.0
+    errs = {}
     for typ, mod, ref in (("coarse", sc.models["coarse"], pc), ("fine", sc.models["fine"], pf)):
         for name, p in mod.named_parameters():
             assert p.grad is not None, name
             if ref[name].grad is None:
                 assert p.grad.abs().max().item() == 0, name
                 continue
-            e = rel_l2(p.grad, ref[name].grad)
-            worst = max(worst, e)
-            assert e < 2e-4, "%s %s: rel L2 grad error %.3e" % (typ, name, e)
-    e = rel_l2(sc.code_library.embedding_instance.weight.grad, ctab.grad)
-    assert e < 2e-4, "codes: %.3e" % e
+            errs["%s.%s" % (typ, name)] = rel_l2(p.grad, ref[name].grad)
+    errs["codes"] = rel_l2(sc.code_library.embedding_instance.weight.grad, ctab.grad)
     if use_voxel:
         tg = sc.embeddings["xyz"].embedding_space_ftr.weight.grad
         assert tg is not None
-        e = rel_l2(tg, grid["table"].grad)
-        assert e < 2e-4, "voxel table: %.3e" % e
+        errs["voxel table"] = rel_l2(tg, grid["table"].grad)
+    worst = max(errs.values())
+    if "sizes" not in c:
+        # 24 rays x 32 points: no unit of any layer sits within roundoff of its LeakyReLU / ReLU kink -> fp32-roundoff class
+        for name, e in errs.items():
+            assert e < 2e-4, "%s: rel L2 grad error %.3e" % (name, e)
+    else:
+        # 393,216 points x ~4,500 (Leaky)ReLU units each: a few units DO sit within roundoff of their kink, the two sides
+        # take different branches there, and a heavy sample point then moves a gradient by 1e-4..1e-3 (first layers of the
+        # fine scene branch most: importance samples concentrate where the density switches on).  The same happens to the
+        # oracle against ITSELF when every weight moves by one ulp -- that distance is the yardstick (measured:
+        # HIP 1.7e-3 worst / oracle 8.8e-4 worst, same layers; the backward itself is compared on SHARED activations at
+        # this scale by test_training_kernels_against_layerwise_gemms).
+        _, pc2, pf2, ctab2, grid2 = oracle_grads(perturb_seed=11, z_fine=ro["z_vals_fine"].detach())
+        floor = {}
+        for typ, a, b in (("coarse", pc, pc2), ("fine", pf, pf2)):
+            for name in a:
+                if a[name].grad is not None:
+                    floor["%s.%s" % (typ, name)] = rel_l2(b[name].grad, a[name].grad)
+        floor["codes"], floor["voxel table"] = rel_l2(ctab2.grad, ctab.grad), rel_l2(grid2["table"].grad, grid["table"].grad)
+        rms = lambda d: (sum(v * v for v in d.values()) / len(d)) ** 0.5     # noqa: E731
+        print(case, "rms error %.2e (oracle self-distance %.2e), worst %.2e (%.2e)" % (rms(errs), rms(floor), worst, max(floor.values())))
+        assert rms(errs) <= 4.0 * rms(floor) + 2e-5 and worst <= 10.0 * max(floor.values()) + 2e-4
+        import statistics
+        assert statistics.median(errs.values()) < 2e-5          # the typical parameter is in the roundoff class
     print(case, "worst parameter-gradient rel L2 error %.2e" % worst)
 
 
