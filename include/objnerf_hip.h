@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 4
+#define OBJNERF_ABI_VERSION 5
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -185,6 +185,13 @@ int objnerf_sample_pdf_merge(const float* z_coarse, const float* weights, const 
                              int64_t u_stride, int64_t n_rays, int S, int I, float eps,
                              float* z_samples, float* z_fine, void* stream);
 
+/* the same with the depth clip of render_tools/multi_rendering.py:277-285 (ray sets with 10 columns): clip (N,2) =
+ * (bbox_mask_near, bbox_mask_far) per ray; merged depths strictly inside that interval are moved to its upper end.
+ * clip == NULL: identical to objnerf_sample_pdf_merge. */
+int objnerf_sample_pdf_merge_clip(const float* z_coarse, const float* weights, const float* u,
+                                  int64_t u_stride, int64_t n_rays, int S, int I, float eps,
+                                  float* z_samples, float* z_fine, const float* clip, void* stream);
+
 /* standalone sample_pdf (rendering.py:11-61): bins (N,nb), weights (N,nb-1) -> (N,I) */
 int objnerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_stride,
                        int64_t n_rays, int nb, int I, float eps, float* samples, void* stream);
@@ -326,6 +333,8 @@ typedef struct {
   const float* u_rand;             /* (K,N,I) uniform draws, read when perturb != 0 */
   const float* noise_coarse;       /* (N,K*S) N(0,1) draws, read when noise_std != 0 */
   const float* noise_fine;         /* (N,K*(S+I)) */
+  const float* const* h_clip;      /* NULL, or HOST array of K device pointers, each NULL or (N,2): columns 8:10 of a
+                                    * 10-column ray set (multi_rendering.py:277-285, objnerf_sample_pdf_merge_clip) */
   const double* boxes;             /* n_boxes x OBJNERF_BOX_DOUBLES: background_skip_bbox, applied to id-0 sets */
   int32_t n_boxes;
   void* workspace;                 /* objnerf_render_multi_workspace_bytes() */

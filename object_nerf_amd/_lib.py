@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 4     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 5     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -132,6 +132,7 @@ class RenderMultiIn(C.Structure):
         ("grid", VoxelGrid),
         ("z_steps", C.c_void_p), ("u_det", C.c_void_p), ("u_rand", C.c_void_p),
         ("noise_coarse", C.c_void_p), ("noise_fine", C.c_void_p),
+        ("h_clip", C.POINTER(C.c_void_p)),
         ("boxes", C.c_void_p), ("n_boxes", C.c_int32),
         ("workspace", C.c_void_p),
     ]
@@ -169,6 +170,7 @@ SIGNATURES = {
     "objnerf_mlp_eval": (C.c_int, [C.POINTER(MlpArgs), _VP]),
     "objnerf_composite": (C.c_int, [C.POINTER(CompositeArgs), _VP]),
     "objnerf_sample_pdf_merge": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP]),
+    "objnerf_sample_pdf_merge_clip": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP, _VP]),
     "objnerf_sample_pdf": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP]),
     "objnerf_mask_sigma": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_int, _VP]),
     "objnerf_mask_sigma_rgb": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_int, _VP]),

@@ -410,8 +410,8 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
         rc = objnerf_sample_coarse(in->h_rays[k], in->z_steps, nullptr, 0.f, cfg->use_disp, N, S, z, stream);
       } else {
         // importance sampling from the set's OWN weights of the joint compositing (multi_rendering.py:266-283)
-        rc = objnerf_sample_pdf_merge(w.zc(k), w.own(k), det ? in->u_det : in->u_rand + (int64_t)k * N * I, det ? 0 : I, N, S, I,
-                                      1e-5f, nullptr, z, stream);
+        rc = objnerf_sample_pdf_merge_clip(w.zc(k), w.own(k), det ? in->u_det : in->u_rand + (int64_t)k * N * I, det ? 0 : I, N,
+                                           S, I, 1e-5f, nullptr, z, in->h_clip ? in->h_clip[k] : nullptr, stream);
       }
       if (rc) return rc;
       // rays that missed their object's box (near = far = 0 => all depths 0): sigma is forced to -1e5 afterwards

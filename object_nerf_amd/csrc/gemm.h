@@ -43,6 +43,22 @@ constexpr int GTILE = GBM * GLDK;   // floats per staged operand tile (>= GBK * 
 #ifndef OBJ_GEMM_DOUBLE_BUFFER
 #define OBJ_GEMM_DOUBLE_BUFFER 0
 #endif
+#ifndef OBJ_GEMM_XCD
+// 1: the output tiles that stream the same operand panel get consecutive slots on ONE XCD (shared L2).  Measured
+// (tools/gemm_bench.py, round 2): wgrad 256 x 256 unchanged (0.78 of peak either way), forward / dgrad 0.60 -> 0.54 --
+// these products are not HBM-bound (a panel re-read from another XCD comes from the MALL), so the plain map stays.
+#define OBJ_GEMM_XCD 0
+#endif
+// 1-D launch grid of gemm_kernel for a problem (host side, train.hip)
+inline unsigned gemm_grid(long M, long N, int split_k) {
+  const unsigned nx = (unsigned)((N + 127) / 128), ny = (unsigned)((M + 127) / 128);
+#if OBJ_GEMM_XCD
+  const unsigned groups = split_k > 1 ? (unsigned)split_k : ny, per_group = split_k > 1 ? nx * ny : nx;
+  return 8u * per_group * ((groups + 7) / 8);
+#else
+  return nx * ny * (unsigned)split_k;
+#endif
+}
 
 // One operand of a workgroup: 128 "rows" (m for A', n for B') x 32 k per tile.  Global -> registers (16-byte loads
 // whenever the operand allows it) -> LDS in the layout its MFMA reads want; the fetch of tile t+1 is issued before
@@ -133,10 +149,23 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[NBUF * 2 * GTILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const long m0 = (long)blockIdx.y * GBM, n0 = (long)blockIdx.x * GBN;
+  // Workgroup -> (tile, k slice).  OBJ_GEMM_XCD (off, see above): workgroups are dealt round-robin to the 8 XCDs
+  // (linear id % 8); the output tiles that stream the SAME operand panel -- all tiles of one k slice (split-K: wgrad),
+  // or the tiles of one row panel (split_k == 1) -- get consecutive slots on ONE XCD.
+  const unsigned nx = (unsigned)((g.N + GBN - 1) / GBN), ny = (unsigned)((g.M + GBM - 1) / GBM);
+#if OBJ_GEMM_XCD
+  const unsigned groups = g.split_k > 1 ? (unsigned)g.split_k : ny, per_group = g.split_k > 1 ? nx * ny : nx;
+  const unsigned slot = blockIdx.x >> 3;
+  const unsigned grp = (slot / per_group) * 8 + (blockIdx.x & 7), t = slot % per_group;
+  if (grp >= groups) return;                       // padding of the last round of 8 groups
+  const unsigned bz = g.split_k > 1 ? grp : 0, bx = t % nx, by = g.split_k > 1 ? t / nx : grp;
+#else
+  const unsigned bx = blockIdx.x % nx, by = (blockIdx.x / nx) % ny, bz = blockIdx.x / (nx * ny);
+#endif
+  const long m0 = (long)by * GBM, n0 = (long)bx * GBN;
   // split-K slice of this workgroup
   const long kchunk = ((g.K + g.split_k - 1) / g.split_k + GBK - 1) / GBK * GBK;
-  const long kbeg = (long)blockIdx.z * kchunk;
+  const long kbeg = (long)bz * kchunk;
   const long kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
 
   f32x16 acc[2][2];
@@ -148,7 +177,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float rsum = 0.f;
-  const bool want_rowsum = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;     // uniform
+  const bool want_rowsum = !A_KC && g.rowsum != nullptr && bx == 0;     // uniform
   if (kbeg < kend) {          // uniform per workgroup
     GemmOperand<A_KC> opa;
     GemmOperand<B_KC> opb;    // B'[k][n]: "row" of the staged tile = n

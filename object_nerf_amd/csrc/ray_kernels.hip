@@ -337,7 +337,8 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __re
                                                                const float* __restrict__ weights,
                                                                const float* __restrict__ u, long u_stride,
                                                                long n_rays, int S, int I, float eps,
-                                                               float* __restrict__ z_samples, float* __restrict__ z_fine) {
+                                                               float* __restrict__ z_samples, float* __restrict__ z_fine,
+                                                               const float* __restrict__ clip) {
   extern __shared__ float pdf_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
   const int nb = S - 1;
@@ -364,6 +365,11 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __re
     sample_pdf_ray(bins_lds, cdf_lds, weights + ray * S + 1, nb, u + ray * u_stride, I, eps,
                    all_lds + S, z_samples ? z_samples + ray * I : nullptr, lane);
     float* out = z_fine + ray * M;
+    // optional per-ray (lo, hi): merged depths strictly inside the interval are moved to hi (the 10-column ray sets of
+    // render_rays_multi, multi_rendering.py:277-285); the row stays ascending (the moved run is contiguous and <= hi)
+    const bool do_clip = clip != nullptr;
+    const float clo = do_clip ? clip[ray * 2] : 0.f, chi = do_clip ? clip[ray * 2 + 1] : 0.f;
+    auto put = [&](int pos, float v) { out[pos] = (do_clip && v > clo && v < chi) ? chi : v; };
     // z_fine = torch.sort(torch.cat([z, z_]))[0], ties in concatenation order (stable)
     if (!coarse_sorted) {
       // general case (far < near): rank of every element among all M
@@ -374,7 +380,7 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __re
           const float o = all_lds[j];
           rank += (o < v || (o == v && j < i)) ? 1 : 0;
         }
-        out[rank] = v;
+        put(rank, v);
       }
     } else {
       // Both runs ascending -> two binary searches per element.  The new samples are ascending whenever u is
@@ -397,8 +403,8 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __re
         nw_ = sorted_new;
       }
       // a coarse depth goes behind the new samples strictly below it; a new sample behind the coarse depths <= it
-      for (int i = lane; i < S; i += 64) out[i + count_below(nw_, I, all_lds[i], false)] = all_lds[i];
-      for (int r = lane; r < I; r += 64) out[r + count_below(all_lds, S, nw_[r], true)] = nw_[r];
+      for (int i = lane; i < S; i += 64) put(i + count_below(nw_, I, all_lds[i], false), all_lds[i]);
+      for (int r = lane; r < I; r += 64) put(r + count_below(all_lds, S, nw_[r], true), nw_[r]);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -764,6 +770,12 @@ int objnerf_sample_pdf(const float* bins, const float* weights, const float* u, 
 int objnerf_sample_pdf_merge(const float* z_coarse, const float* weights, const float* u, int64_t u_stride,
                              int64_t n_rays, int S, int I, float eps, float* z_samples, float* z_fine,
                              void* stream) {
+  return objnerf_sample_pdf_merge_clip(z_coarse, weights, u, u_stride, n_rays, S, I, eps, z_samples, z_fine, nullptr, stream);
+}
+
+int objnerf_sample_pdf_merge_clip(const float* z_coarse, const float* weights, const float* u, int64_t u_stride,
+                                  int64_t n_rays, int S, int I, float eps, float* z_samples, float* z_fine,
+                                  const float* clip, void* stream) {
   if (!z_coarse || !weights || !u || !z_fine || S < 3 || S - 1 > kMaxBins || I < 1 || S + I > kMaxMerge)
     return set_error(-1, "sample_pdf_merge: bad arguments (3 <= S <= 1025, S + I <= 2048)");
   if (n_rays == 0) return 0;
@@ -772,7 +784,7 @@ int objnerf_sample_pdf_merge(const float* z_coarse, const float* weights, const 
   const long blocks = (n_rays + nwb - 1) / nwb;
   unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
   hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid), dim3(64 * nwb), per_wave * nwb, (hipStream_t)stream, z_coarse,
-                     weights, u, (long)u_stride, (long)n_rays, S, I, eps, z_samples, z_fine);
+                     weights, u, (long)u_stride, (long)n_rays, S, I, eps, z_samples, z_fine, clip);
   return check_launch("sample_pdf_merge");
 }
 

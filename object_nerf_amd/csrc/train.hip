@@ -19,7 +19,7 @@ namespace objnerf {
 int gemm_launch(const GemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return 0;
   if (g.K <= 0) return 0;
-  dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM), (unsigned)g.split_k);
+  dim3 grid(gemm_grid(g.M, g.N, g.split_k));
   if (g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
   else if (g.a_k_contig && !g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
   else if (!g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);

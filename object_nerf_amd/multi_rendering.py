@@ -47,17 +47,16 @@ def render_rays_multi(
     coarse = models["coarse"]
     coarse._check_no_grad(*rays_list)
 
-    rays_c = []
+    rays_c, clips = [], []
     for r in rays_list:
         _lib.require_cuda(r, "rays_list entry")
-        if r.dim() != 2 or r.shape[1] != 8:
-            # The reference also accepts 10 columns (bbox_mask_near / far clamp the fine depths,
-            # multi_rendering.py:277-285); its callers only ever build 8 (editable_renderer.py:160,177-179) and that
-            # variant is not built here -- silently dropping the two columns would change the result
-            raise NotImplementedError("render_rays_multi: ray sets must be (N, 8) [o, d, near, far]; got %s. The "
-                                      "10-column bbox-clamp variant of the reference is not implemented."
-                                      % (tuple(r.shape),))
-        rays_c.append(_lib.as_f32(r))
+        if r.dim() != 2 or r.shape[1] not in (8, 10):
+            raise RuntimeError("render_rays_multi: ray sets must be (N, 8) [o, d, near, far] or (N, 10) "
+                               "[..., bbox_mask_near, bbox_mask_far]; got %s" % (tuple(r.shape),))
+        r32 = _lib.as_f32(r)
+        # 10 columns: the last two clip the fine depths (multi_rendering.py:277-285); the kernels read (N, 8) rows
+        rays_c.append(r32 if r.shape[1] == 8 else r32[:, :8].contiguous())
+        clips.append(None if r.shape[1] == 8 else r32[:, 8:10].contiguous())
     n = rays_c[0].shape[0]
     dev = rays_c[0].device
     if any(r.shape[0] != n for r in rays_c):
@@ -104,6 +103,10 @@ def render_rays_multi(
             keep.append(nzf)
     if boxes is not None and boxes.shape[0] > 0:
         rin.boxes, rin.n_boxes = boxes.data_ptr(), boxes.shape[0]
+    if any(c is not None for c in clips):
+        h_clip = (C.c_void_p * K)(*[c.data_ptr() if c is not None else None for c in clips])
+        rin.h_clip = h_clip
+        keep += [clips, h_clip]
     rin.workspace = ws.data_ptr()
 
     def alloc(M, want_ids):

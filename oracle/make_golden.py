@@ -119,6 +119,13 @@ def main():
                                     N_samples=m["N_samples"], N_importance=0, perturb=0, noise_std=0,
                                     chunk=32768, white_back=True, background_skip_bbox=None)
         save("multi_coarse_only_white", dict(out))
+        # the 10-column ray sets (fine depths clipped to the far end of a per-ray interval, multi_rendering.py:277-285)
+        sets10, _ = cases.multi_inputs_clip()
+        out = ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets10], m["obj_ids"],
+                                    N_samples=m["N_samples"], N_importance=m["N_importance"], perturb=0, noise_std=0,
+                                    chunk=32768, white_back=False, background_skip_bbox=ref_boxes)
+        assert not torch.equal(out["z_vals_fine"], cases.load_golden("multi_scannet_dup")["z_vals_fine"])    # the clip bites
+        save("multi_scannet_clip10", dict(out))
         # ---- bench.py --config 4: the editing demo's ray sets, generated by the reference's own ray / box code ----
         sc = scene("scannet_800k")
         bm = cases.BENCH_MULTI

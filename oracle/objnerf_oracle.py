@@ -410,6 +410,10 @@ def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, o
             mid = 0.5 * (zs[i][:, :-1] + zs[i][:, 1:])
             z_new = sample_pdf(mid, w_own[:, 1:-1].detach(), N_importance, det=(perturb == 0))
             z = torch.sort(torch.cat([zs[i], z_new], -1), -1)[0]
+            if rays_list[i].shape[1] == 10:                               # :277-285 ray mask (e.g. bbox): clip z values
+                lo, hi = rays_list[i][:, 8:9], rays_list[i][:, 9:10]
+                inside = torch.logical_and(z > lo, z < hi)
+                z = torch.where(inside, hi.expand_as(z), z)
             c, sg = branch(params_fine, rays_list[i], z, obj_instance_ids[i])
             zf.append(z); cf.append(c); sf.append(sg)
         r = composite_multi(zf, cf, sf, noise_std, white_back)

@@ -162,6 +162,19 @@ def multi_inputs():
     return sets, [box]
 
 
+def multi_inputs_clip():
+    """the same ray sets with the two extra columns of the reference's 10-column variant (multi_rendering.py:277-285):
+    object sets carry (bbox_mask_near, bbox_mask_far) strictly inside their (near, far); the background set stays (N, 8)"""
+    sets, boxes = multi_inputs()
+    out = [sets[0]]
+    for k, r in enumerate(sets[1:]):
+        near, far = r[:, 6:7], r[:, 7:8]
+        lo = near + (0.30 + 0.05 * k) * (far - near)
+        hi = near + (0.55 + 0.05 * k) * (far - near)
+        out.append(torch.cat([r, lo, hi], 1).contiguous())
+    return out, boxes
+
+
 # ---- bench.py --config 4 (BASELINE configs[4]): the editing demo's three ray sets of the 640x480 frame, 40 strided pixels ----
 BENCH_MULTI = dict(obj_ids=[0, 4, 4], N_samples=64, N_importance=64, frame=(640, 480), n_rays=40, stride=6911, bbox_enlarge=0.06)
 

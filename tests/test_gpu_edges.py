@@ -116,13 +116,13 @@ def test_non_contiguous_and_float64_inputs_are_accepted():
 
 
 @pytest.mark.single_mode
-def test_ten_column_ray_sets_are_rejected_not_truncated():
-    """multi_rendering.py:277-285 clamps the fine depths with columns 8:10; that variant is not built, so it must not be
-    silently rendered as the 8-column one"""
+def test_ray_sets_of_other_widths_are_rejected():
+    """8 columns, or 10 with the fine-depth clip of multi_rendering.py:277-285 (tests/test_gpu_render.py grades that one
+    against the reference); anything else is an error, never a silent truncation"""
     sc = scene("voxel")
     base, _ = cases.multi_inputs()
-    wide = [torch.cat([s, s[:, 6:8]], 1).to(DEV) for s in base]
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="10-column"):
+    wide = [torch.cat([s, s[:, 6:8], s[:, 6:7]], 1).to(DEV) for s in base]          # 11 columns
+    with torch.no_grad(), pytest.raises(RuntimeError, match="ray sets must be"):
         render_rays_multi(sc.models, sc.embeddings, sc.code_library, wide, [0, 4, 4], N_samples=8, N_importance=0)
 
 

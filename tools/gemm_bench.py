@@ -22,7 +22,10 @@ def main(tags):
     for w in (256, 128):
         shapes += [("fwd  Y=X W^T  w=%d" % w, 1, 1, P, w, w, 1), ("dgrad dX=dY W w=%d" % w, 1, 0, P, w, w, 1),
                    ("wgrad dW=dY^T X w=%d" % w, 0, 0, w, w, P, max(2, 1024 // ((w // 128) ** 2)))]
-    shapes += [("fwd  in=95 -> 256", 1, 1, P, 256, 95, 1), ("wgrad 256 x 95", 0, 0, 256, 95, P, 512)]
+    shapes += [("fwd  in=95 -> 256", 1, 1, P, 256, 95, 1), ("wgrad 256 x 95", 0, 0, 256, 95, P, 512),
+               # the embedding-gradient product of the first scene layer (dX = dY W, 271 input columns: 3 column tiles
+               # that all stream the same P x 256 panel of dY) and its weight gradient, at the fine pass's point count
+               ("dgrad dX=dY W 256->271", 1, 0, 2048 * 128, 271, 256, 1), ("wgrad 256 x 271", 0, 0, 256, 271, 2048 * 128, 256)]
     libs = {t: load(t) for t in tags}
     for name, akc, bkc, M, N, K, split in shapes:
         a = torch.randn((M, K) if akc else (K, M), device=dev)
