@@ -63,6 +63,12 @@
 #ifndef OBJ_B3_GROUP
 #define OBJ_B3_GROUP 2       // split-bf16 mode: out tiles whose products are interleaved (no back-to-back dependent MFMAs)
 #endif
+#ifndef OBJ_B3_SPLIT_SPREAD
+#define OBJ_B3_SPLIT_SPREAD 0   // split-bf16 mode: the next s-step's operand split is spread over all MFMA groups of the s-step
+#endif
+#ifndef OBJ_B3_ADEPTH
+#define OBJ_B3_ADEPTH 1      // split-bf16 mode: MFMA groups between the LDS read of an A tile and its first use
+#endif
 #ifndef OBJ_NT_OUT
 #define OBJ_NT_OUT 1         // sigma / rgb output stores carry the non-temporal hint
 #endif
@@ -350,10 +356,11 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
   // DMA pieces per MFMA group (spread mode): front-loaded into the first half of the chunk's groups, so that the last
   // piece has half a chunk to land before the (early) barrier that opens its chunk
   constexpr int PPI = (Stream::kPieces + SPC * NGRP / 2 - 1) / (SPC * NGRP / 2);
-  auto split = [&](auto S_, B3Operand& b) __attribute__((always_inline)) {
+  // pairs [J0, J0 + NJ) of the four (k0, k1) pairs of an s-step
+  auto split_part = [&](auto S_, B3Operand& b, auto J0_, auto NJ_) __attribute__((always_inline)) {
     constexpr int s = decltype(S_)::value;
-    static_for<4>([&](auto J) __attribute__((always_inline)) {
-      constexpr int jj = decltype(J)::value;
+    static_for<decltype(NJ_)::value>([&](auto J) __attribute__((always_inline)) {
+      constexpr int jj = decltype(J0_)::value + decltype(J)::value;
       constexpr int k0 = 8 * s + 2 * jj, k1 = k0 + 1;
       float x0 = 0.f, x1 = 0.f;
       if constexpr (k0 < KS) x0 = src.template get<k0>();
@@ -367,6 +374,9 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
       b.lo[jj] = (bf16_trunc(t0) >> 16) | bf16_trunc(t1);
     });
   };
+  auto split = [&](auto S_, B3Operand& b) __attribute__((always_inline)) {
+    split_part(S_, b, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+  };
   auto load_a = [&](u32x4 (&a)[G][3], int sl, int grp) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < G; ++t)
@@ -375,7 +385,20 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
         a[t][pl] = *(const __attribute__((address_space(3))) u32x4*)(st.rd + ((sl * NT + grp * G + t) * 3 + pl) * 1024);
   };
   B3Operand bop[2];
-  u32x4 abuf[2][G][3];
+  constexpr int AD = OBJ_B3_ADEPTH;              // A tiles are fetched AD groups ahead of their MFMAs (ring of AD + 1 buffers)
+  constexpr int GPCH = SPC * NGRP;               // groups per chunk
+  constexpr int NGTOT = NS * NGRP;               // groups in the layer
+  static_assert(AD >= 1 && AD < GPCH, "prefetch distance must stay inside one chunk");
+  u32x4 abuf[AD + 1][G][3];
+  // buffer index of group gi is gi % (AD + 1); (s-step inside its chunk, tile group) of group gi
+  auto load_group_a = [&](auto GI) __attribute__((always_inline)) {
+    constexpr int gi = decltype(GI)::value;
+#ifdef OBJ_ABL_B3_ALOAD    // timing ablation only: A tiles read from LDS once per layer
+    if constexpr (gi <= AD) load_a(abuf[gi % (AD + 1)], 0, 0);
+#else
+    if constexpr (gi < NGTOT) load_a(abuf[gi % (AD + 1)], (gi / NGRP) % SPC, gi % NGRP);
+#endif
+  };
   split(std::integral_constant<int, 0>{}, bop[0]);
   static_for<NS>([&](auto S_) __attribute__((always_inline)) {
     constexpr int s = decltype(S_)::value;
@@ -386,7 +409,7 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
     if constexpr (s == 0) {
       st.next_chunk();
       after_barrier(std::integral_constant<int, 0>{});
-      load_a(abuf[0], 0, 0);
+      static_for<AD>([&](auto D) __attribute__((always_inline)) { load_group_a(D); });     // groups 0 .. AD-1 (same chunk: AD < GPCH)
     }
     const B3Operand& b = bop[s & 1];
     const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bm = __builtin_bit_cast(bf16x8, b.mid), bl = __builtin_bit_cast(bf16x8, b.lo);
@@ -395,26 +418,36 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
       constexpr int it = sl * NGRP + grp;                 // group index inside the chunk
       // A tiles are double-buffered across all groups of the layer: group number gi uses abuf[gi & 1]
       constexpr int gi = s * NGRP + grp;
-      u32x4 (&a)[G][3] = abuf[gi & 1];
-      constexpr bool last_of_chunk = (it == SPC * NGRP - 1);
-      constexpr bool more = (grp + 1 < NGRP) || (s + 1 < NS);
-      if constexpr (more && last_of_chunk) {
-        st.next_chunk();                                  // barrier: every wave holds its last A tiles of the old slot
-        after_barrier(std::integral_constant<int, s / SPC + 1>{});
-        load_a(abuf[(gi + 1) & 1], 0, 0);
-      } else if constexpr (grp + 1 < NGRP) {
-        load_a(abuf[(gi + 1) & 1], sl, grp + 1);
-      } else if constexpr (s + 1 < NS) {
-        load_a(abuf[(gi + 1) & 1], sl + 1, 0);
+      u32x4 (&a)[G][3] = abuf[gi % (AD + 1)];
+      // the group fetched now, gi + AD, opens a new chunk when it is that chunk's first group: by then the A tiles of
+      // every remaining group of the old chunk (gi .. gi + AD - 1) sit in registers, so the barrier may recycle the slot
+      constexpr bool opens = (gi + AD < NGTOT) && ((gi + AD) % GPCH == 0);
+      constexpr bool last_of_chunk = opens;               // (name kept: this group issues no DMA pieces, see below)
+      if constexpr (opens) {
+        st.next_chunk();
+        after_barrier(std::integral_constant<int, (gi + AD) / GPCH>{});
       }
+      load_group_a(std::integral_constant<int, gi + AD>{});
       // this chunk's share of the NEXT chunk's DMA: PPI 1-KiB pieces per wave in front of each MFMA group (the group
       // that opened the next chunk has already selected the chunk after it: its pieces start with that group's successor)
-      if constexpr (OBJ_B3_SPREAD_DMA && !last_of_chunk)
+      // (pieces belong to the chunk selected by the most recent next_chunk(): group `it` of a chunk carries pieces
+      // it * PPI .. of the chunk after it, and only groups in front of the opening one do: it < GPCH - AD)
+      if constexpr (OBJ_B3_SPREAD_DMA && !last_of_chunk && it < GPCH - AD)
         static_for<PPI>([&](auto Q) __attribute__((always_inline)) { st.template piece_now<it * PPI + decltype(Q)::value>(); });
       after_barrier.template group<gi>();
       // keep the loads above the MFMAs below (the compiler otherwise sinks them to their first use: exposed LDS latency)
       __builtin_amdgcn_sched_barrier(0);
+#ifdef OBJ_ABL_B3_SPLIT     // timing ablation only: the B operand is split once per layer
+      if constexpr (grp == 0 && s == 0) split(std::integral_constant<int, 0>{}, bop[1]);
+#elif OBJ_B3_SPLIT_SPREAD
+      // the next s-step's operand split, a share per MFMA group of this s-step (4 / NGRP of its four pairs): a filler
+      // stream of ~2 VALU per MFMA gap everywhere instead of ~6 in the first group and none in the others
+      if constexpr (s + 1 < NS)
+        split_part(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1], std::integral_constant<int, grp * (4 / NGRP)>{},
+                   std::integral_constant<int, 4 / NGRP>{});
+#else
       if constexpr (grp == 0 && s + 1 < NS) split(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1]);
+#endif
       bf16x8 ah[G], am[G], al[G];
 #pragma unroll
       for (int t = 0; t < G; ++t) {
@@ -445,7 +478,8 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
     });
     // last s-step of the layer: the pieces the (shorter) last chunk had no MFMA group for
     if constexpr (OBJ_B3_SPREAD_DMA && s == NS - 1) {
-      constexpr int done = ((sl + 1) * NGRP - (((sl + 1) * NGRP == SPC * NGRP) ? 1 : 0)) * PPI;
+      constexpr int ng = (sl + 1) * NGRP;                                       // groups of the layer's last chunk
+      constexpr int done = (ng < GPCH - AD ? ng : GPCH - AD) * PPI;            // pieces its groups have issued
       static_for<Stream::kPieces>([&](auto I) __attribute__((always_inline)) {
         if constexpr (decltype(I)::value >= done) st.template piece_now<decltype(I)::value>();
       });
