@@ -34,6 +34,7 @@ struct GemmArgs {
   int split_k;           // >= 1
   float* rowsum;         // optional, row-contiguous A' only: rowsum[m] += sum_k A'[m][k] (a Linear layer's bias gradient
                          // when A' = dY^T), accumulated with atomics by the workgroups of the first column of tiles
+  int bx0, nbx;          // column tiles [bx0, bx0 + nbx) of the problem are computed by this launch (set by gemm_launch)
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
@@ -43,15 +44,22 @@ constexpr int GTILE = GBM * GLDK;   // floats per staged operand tile (>= GBK * 
 #ifndef OBJ_GEMM_DOUBLE_BUFFER
 #define OBJ_GEMM_DOUBLE_BUFFER 0
 #endif
+#ifndef OBJ_GEMM_TAIL
+// 1: a ragged last column tile with at most 3 of its four 32-column sub-tiles live is computed by a second launch of the
+// TAIL instantiation: 4 x 1 wave layout, wave w owns row sub-tile w and the live column sub-tiles, so that tile costs
+// ncol / 4 of a full one instead of all of it (271 columns = 2 tiles + 15 columns: 9 units of work instead of 12).
+#define OBJ_GEMM_TAIL 1
+#endif
 #ifndef OBJ_GEMM_XCD
 // 1: the output tiles that stream the same operand panel get consecutive slots on ONE XCD (shared L2).  Measured
-// (tools/gemm_bench.py, round 2): wgrad 256 x 256 unchanged (0.78 of peak either way), forward / dgrad 0.60 -> 0.54 --
-// these products are not HBM-bound (a panel re-read from another XCD comes from the MALL), so the plain map stays.
+// (tools/gemm_bench.py, round 2, libraries interleaved after a warm-up): neutral -- forward 0.66 vs 0.65 of peak, dgrad
+// 0.69 vs 0.70, wgrad 256 x 256 0.78 vs 0.76: these products are not HBM-bound (a panel re-read by a workgroup on
+// another XCD comes from the MALL), so the plain map stays.
 #define OBJ_GEMM_XCD 0
 #endif
 // 1-D launch grid of gemm_kernel for a problem (host side, train.hip)
-inline unsigned gemm_grid(long M, long N, int split_k) {
-  const unsigned nx = (unsigned)((N + 127) / 128), ny = (unsigned)((M + 127) / 128);
+inline unsigned gemm_grid(long M, unsigned nx, int split_k) {
+  const unsigned ny = (unsigned)((M + 127) / 128);
 #if OBJ_GEMM_XCD
   const unsigned groups = split_k > 1 ? (unsigned)split_k : ny, per_group = split_k > 1 ? nx * ny : nx;
   return 8u * per_group * ((groups + 7) / 8);
@@ -143,7 +151,7 @@ struct GemmOperand {
   }
 };
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool TAIL = false>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   constexpr int NBUF = OBJ_GEMM_DOUBLE_BUFFER ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * 2 * GTILE];
@@ -152,7 +160,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   // Workgroup -> (tile, k slice).  OBJ_GEMM_XCD (off, see above): workgroups are dealt round-robin to the 8 XCDs
   // (linear id % 8); the output tiles that stream the SAME operand panel -- all tiles of one k slice (split-K: wgrad),
   // or the tiles of one row panel (split_k == 1) -- get consecutive slots on ONE XCD.
-  const unsigned nx = (unsigned)((g.N + GBN - 1) / GBN), ny = (unsigned)((g.M + GBM - 1) / GBM);
+  const unsigned nx = (unsigned)g.nbx, ny = (unsigned)((g.M + GBM - 1) / GBM);
 #if OBJ_GEMM_XCD
   const unsigned groups = g.split_k > 1 ? (unsigned)g.split_k : ny, per_group = g.split_k > 1 ? nx * ny : nx;
   const unsigned slot = blockIdx.x >> 3;
@@ -162,22 +170,23 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
 #else
   const unsigned bx = blockIdx.x % nx, by = (blockIdx.x / nx) % ny, bz = blockIdx.x / (nx * ny);
 #endif
-  const long m0 = (long)by * GBM, n0 = (long)bx * GBN;
+  const long m0 = (long)by * GBM, n0 = (long)(g.bx0 + bx) * GBN;
+  // TAIL: live 32-column sub-tiles of this (last, ragged) column tile
+  const int ncol = TAIL ? (int)((g.N - n0 + 31) / 32) : 4;
   // split-K slice of this workgroup
   const long kchunk = ((g.K + g.split_k - 1) / g.split_k + GBK - 1) / GBK * GBK;
   const long kbeg = (long)bz * kchunk;
   const long kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
 
-  f32x16 acc[2][2];
+  // full tile: 2 x 2 waves, each 2 x 2 MFMA tiles (acc[2 i + j]); TAIL: 4 x 1 waves, acc[j] = column sub-tile j
+  f32x16 acc[TAIL ? 3 : 4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (TAIL ? 3 : 4); ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   float rsum = 0.f;
-  const bool want_rowsum = !A_KC && g.rowsum != nullptr && bx == 0;     // uniform
+  const bool want_rowsum = !A_KC && g.rowsum != nullptr && g.bx0 + bx == 0;     // uniform
   if (kbeg < kend) {          // uniform per workgroup
     GemmOperand<A_KC> opa;
     GemmOperand<B_KC> opb;    // B'[k][n]: "row" of the staged tile = n
@@ -210,20 +219,38 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) rsum += As[((tid >> 7) * 16 + kk) * GLDR + (tid & 127)];
       }
+      if constexpr (TAIL) {
+        if (m0 + wave * 32 < g.M) {          // wave-uniform: this wave's row sub-tile exists
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {       // 4 MFMA steps per fragment read
-        f32x4 a[2], b[2];
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const f32x4 a = GemmOperand<A_KC>::frag(As, wave * 32 + rl, half, s4);
+            f32x4 b[3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = GemmOperand<A_KC>::frag(As, wm * 64 + i * 32 + rl, half, s4);
+            for (int j = 0; j < 3; ++j)
+              if (j < ncol) b[j] = GemmOperand<B_KC>::frag(Bs, j * 32 + rl, half, s4);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = GemmOperand<B_KC>::frag(Bs, wn * 64 + j * 32 + rl, half, s4);
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+              for (int j = 0; j < 3; ++j)
+                if (j < ncol) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j][s], acc[j], 0, 0, 0);
+          }
+        }
+      } else {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+        for (int s4 = 0; s4 < 4; ++s4) {       // 4 MFMA steps per fragment read
+          f32x4 a[2], b[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < 2; ++i) a[i] = GemmOperand<A_KC>::frag(As, wm * 64 + i * 32 + rl, half, s4);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[j] = GemmOperand<B_KC>::frag(Bs, wn * 64 + j * 32 + rl, half, s4);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[2 * i + j], 0, 0, 0);
+        }
       }
       if (NBUF == 2) {
         if (more) {                          // the other buffer was last read before the previous barrier
@@ -239,19 +266,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long n = n0 + wn * 64 + j * 32 + col;
+  for (int t = 0; t < (TAIL ? 3 : 4); ++t) {
+    {
+      const int i = t >> 1, j = t & 1;
+      if (TAIL && t >= ncol) continue;
+      const long n = TAIL ? n0 + t * 32 + col : n0 + wn * 64 + j * 32 + col;
       if (n >= g.N) continue;
       const bool lbwd = g.epilogue == EPI_LEAKY_BWD;
       const float bv = (g.epilogue != EPI_NONE && !lbwd && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+        const long m = (TAIL ? m0 + wave * 32 : m0 + wm * 64 + i * 32) + (r & 3) + 8 * (r >> 2) + rbase;
         if (m >= g.M) continue;
         float* c = g.C + m * g.ldc + n;
-        float v = acc[i][j][r];
+        float v = acc[t][r];
         if (g.split_k > 1) { atomicAdd(c, v); continue; }
         if (g.accumulate) v += *c;
         if (lbwd) {                  // leaky_relu backward on sign(output) = sign(input)
@@ -264,6 +292,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         *c = v;
       }
     }
+  }
 }
 
 // host launcher (train.hip)

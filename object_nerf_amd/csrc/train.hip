@@ -16,14 +16,30 @@
 
 namespace objnerf {
 
-int gemm_launch(const GemmArgs& g, hipStream_t s) {
-  if (g.M <= 0 || g.N <= 0) return 0;
-  if (g.K <= 0) return 0;
-  dim3 grid(gemm_grid(g.M, g.N, g.split_k));
-  if (g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
-  else if (g.a_k_contig && !g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
-  else if (!g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
+template <bool TAIL>
+static void gemm_launch_part(const GemmArgs& g, hipStream_t s) {
+  dim3 grid(gemm_grid(g.M, (unsigned)g.nbx, g.split_k));
+  if (g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, true, TAIL>), grid, dim3(256), 0, s, g);
+  else if (g.a_k_contig && !g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<true, false, TAIL>), grid, dim3(256), 0, s, g);
+  else if (!g.a_k_contig && g.b_k_contig) hipLaunchKernelGGL((gemm_kernel<false, true, TAIL>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<false, false, TAIL>), grid, dim3(256), 0, s, g);
+}
+
+int gemm_launch(const GemmArgs& g0, hipStream_t s) {
+  if (g0.M <= 0 || g0.N <= 0) return 0;
+  if (g0.K <= 0) return 0;
+  GemmArgs g = g0;
+  const int nx = (int)((g.N + GBN - 1) / GBN);
+  const long last = g.N - (long)(nx - 1) * GBN;              // columns of the last column tile
+  const bool tail = OBJ_GEMM_TAIL && last <= 96;             // at most 3 of its four 32-column sub-tiles are live
+  g.bx0 = 0;
+  g.nbx = tail ? nx - 1 : nx;
+  if (g.nbx > 0) gemm_launch_part<false>(g, s);
+  if (tail) {
+    g.bx0 = nx - 1;
+    g.nbx = 1;
+    gemm_launch_part<true>(g, s);
+  }
   return check_launch("gemm");
 }
 
