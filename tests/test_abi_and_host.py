@@ -168,6 +168,20 @@ def test_c_abi_argument_validation():
     assert l.objnerf_sample_pdf_merge(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None) < 0
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * 128 * 8 + 256
+    # the multi-object entry points (round 2)
+    assert l.objnerf_compact_rays(None, 10, 4, None, None, None, None) < 0 and b"compact_rays" in l.objnerf_last_error()
+    assert l.objnerf_compact_scratch_ints(5000) == 5 + 1
+    assert l.objnerf_sample_pdf_merge_clip(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None, None) < 0
+    mc = _lib.RenderMultiCfg(N_samples=64, N_importance=64)
+    per_set = 1000 * (64 + 128 + 4 * 128 + 64) + 1000            # depths, sigma / rgb, own weights, ray index
+    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * per_set + 64 * 3 + 2) + 256
+    rin, out = _lib.RenderMultiIn(), _lib.RenderMultiOut()
+    rin.n_rays, rin.K = 8, 0
+    assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0
+    assert b"bad sizes" in l.objnerf_last_error()
+    rin.K = 2
+    assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0
+    assert b"missing input" in l.objnerf_last_error()
 
 
 def test_library_never_allocates_or_synchronises():

@@ -22,7 +22,7 @@ def main(db, n=307200, S=64, I=64):
         if "sample_coarse" in name:
             b, note = n * (32 + 4 * S), ""
         elif "sample_pdf_merge" in name:
-            b, note = n * (8 * S + 4 * (S + I)), "not bandwidth-bound: one wave per ray, cdf summed in the reference's sequential order"
+            b, note = n * (8 * S + 4 * (S + I)), "not bandwidth-bound: one wave per ray (float64 prefix scan of the cdf, per-lane binary searches, merge)"
         else:
             # two launches per frame: S and S + I samples; report on the mean
             b, note = n * (40 * (S + S + I) / 2.0 + 40), "mean of the coarse (S) and fine (S + I) launch"
