@@ -44,6 +44,9 @@ constexpr int GTILE = GBM * GLDK;   // floats per staged operand tile (>= GBK * 
 #ifndef OBJ_GEMM_DOUBLE_BUFFER
 #define OBJ_GEMM_DOUBLE_BUFFER 0
 #endif
+#ifndef OBJ_GEMM_FRAG_PIPE
+#define OBJ_GEMM_FRAG_PIPE 0   // full tiles: LDS fragment reads software-pipelined one 16-MFMA group ahead
+#endif
 #ifndef OBJ_GEMM_TAIL
 // 1: a ragged last column tile with at most 3 of its four 32-column sub-tiles live is computed by a second launch of the
 // TAIL instantiation: 4 x 1 wave layout, wave w owns row sub-tile w and the live column sub-tiles, so that tile costs
@@ -236,6 +239,32 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
           }
         }
       } else {
+#if OBJ_GEMM_FRAG_PIPE
+        // fragments of group s4 + 1 are read from LDS before the 16 MFMAs of group s4 issue
+        f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[0][i] = GemmOperand<A_KC>::frag(As, wm * 64 + i * 32 + rl, half, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = GemmOperand<B_KC>::frag(Bs, wn * 64 + j * 32 + rl, half, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          if (s4 < 3) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[(s4 + 1) & 1][i] = GemmOperand<A_KC>::frag(As, wm * 64 + i * 32 + rl, half, s4 + 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[(s4 + 1) & 1][j] = GemmOperand<B_KC>::frag(Bs, wn * 64 + j * 32 + rl, half, s4 + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s4 & 1][i][s], fb[s4 & 1][j][s], acc[2 * i + j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {       // 4 MFMA steps per fragment read
           f32x4 a[2], b[2];
@@ -251,6 +280,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
               for (int j = 0; j < 2; ++j)
                 acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[2 * i + j], 0, 0, 0);
         }
+#endif
       }
       if (NBUF == 2) {
         if (more) {                          // the other buffer was last read before the previous barrier

@@ -328,3 +328,51 @@ def test_render_rays_multi_is_one_enqueue_without_host_round_trips():
         torch.cuda.synchronize()
     for k in warm:
         assert torch.equal(r[k], warm[k]), k          # and it is deterministic
+
+
+def test_full_frame_multi_properties():
+    """BASELINE configs[4] at its full size: the three ray sets of the 640x480 editing-demo frame generated on the device,
+    render_rays_multi over all 307,200 pixels (about two thirds of the object sets' rays miss their box and are culled on
+    the device).  Size-independent properties: run-to-run bitwise determinism; BATCH INDEPENDENCE -- a pixel's result does
+    not depend on which other pixels are in the call, although culling changes every surviving ray's place in the MLP
+    kernel's tile walk (the 40 strided pixels of the golden case rendered alone are bit-equal to the same pixels of the
+    frame); weights sum to the opacity; rays that missed their box carry exactly zero weight."""
+    from object_nerf_amd.ray_utils import generate_rays
+    bm = cases.BENCH_MULTI
+    sc = scene("scannet_800k")
+    focal, poses, box = cases.bench_multi_geometry()
+    w, h = bm["frame"]
+    pre = synth.SCANNET_LIKE
+    sets = [generate_rays(h, w, focal, Toc, pre["near"], pre["far"]) if k == 0 else
+            generate_rays(h, w, focal, Toc, box=box, bbox_enlarge=bm["bbox_enlarge"]) for k, Toc in enumerate(poses)]
+    n = w * h
+    kw = dict(N_samples=bm["N_samples"], N_importance=bm["N_importance"], perturb=0, noise_std=0, background_skip_bbox={4: box})
+    pix = cases.bench_multi_pixels().to(DEV)
+    with torch.no_grad():
+        r = render_rays_multi(sc.models, sc.embeddings, sc.code_library, sets, bm["obj_ids"], **kw)
+        r2 = render_rays_multi(sc.models, sc.embeddings, sc.code_library, sets, bm["obj_ids"], **kw)
+        rs = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s[pix].contiguous() for s in sets], bm["obj_ids"], **kw)
+    S, M = bm["N_samples"], 3 * (bm["N_samples"] + bm["N_importance"])
+    assert r["weights_fine"].shape == (n, M) and r["obj_ids_coarse"].shape == (n, 3 * S)
+    hit = [(s[:, 7] > 0) for s in sets]
+    assert hit[0].all() and 0.05 * n < int(hit[1].sum()) < 0.6 * n and 0.05 * n < int(hit[2].sum()) < 0.6 * n
+    for k in r:
+        assert torch.isfinite(r[k]).all(), k
+        assert torch.equal(r[k], r2[k]), "non-deterministic: " + k
+        if k == "obj_ids_coarse":          # order of the exactly tied depths (z = 0 of missed rays) is by set: deterministic too
+            assert torch.equal(r[k][pix], rs[k]), k
+            continue
+        assert torch.equal(r[k][pix], rs[k]), "batch-dependent: " + k
+    for typ in ("coarse", "fine"):
+        wts = r["weights_" + typ]
+        assert (wts >= 0).all() and torch.allclose(wts.sum(1), r["opacity_" + typ], atol=3e-5)
+        z = r["z_vals_" + typ]
+        assert (z[:, 1:] >= z[:, :-1]).all()
+    # a ray set that missed its box contributes nothing: every sample of that set has weight exactly 0
+    ids, wc = r["obj_ids_coarse"], r["weights_coarse"]
+    for k in (1, 2):
+        miss = ~hit[k]
+        assert (wc[miss][ids[miss] == k] == 0).all()
+    # and the golden pixels still match the reference
+    g = cases.load_golden("multi_bench_edit_demo")
+    grade_multi({k: v[pix] for k, v in r.items()}, g, "bench edit demo (pixels of the full frame)")
