@@ -207,7 +207,11 @@ struct WeightStreamT {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       cur = cur == 2 ? 0 : cur + 1;
-      issue(cur == 0 ? 2 : cur - 1);     // slot of the chunk consumed before the current one
+      // slot of the chunk consumed before the current one.  Spread mode: only selected here, its pieces are issued
+      // between this chunk's MFMA groups; at the NEXT barrier they are the newest CB/4096 VMEM operations of the wave
+      // (or older than later prologue loads), which is exactly what the counted vmcnt above leaves in flight
+      if constexpr (CB == kChunkBytes && OBJ_SPREAD_DMA) select(cur == 0 ? 2 : cur - 1);
+      else issue(cur == 0 ? 2 : cur - 1);
     }
     rd = ring + cur * CB + (tid & 63) * 16;
   }
@@ -266,7 +270,7 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
   // in front of the current chunk's LAST group, so the last piece gets at least a third of a chunk to land
   constexpr int PPG = (Stream::kPieces + (GPC / 2 > 0 ? GPC / 2 : 1) - 1) / (GPC / 2 > 0 ? GPC / 2 : 1);
   auto pieces = [&](auto GQ) __attribute__((always_inline)) {
-    if constexpr (OBJ_SPREAD_DMA && kRingSlots == 2)
+    if constexpr (OBJ_SPREAD_DMA)
       static_for<PPG>([&](auto Q) __attribute__((always_inline)) { st.template piece_now<decltype(GQ)::value * PPG + decltype(Q)::value>(); });
   };
   ATiles<NT> abuf[2];
@@ -284,7 +288,7 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
     if constexpr (g + 1 < NG4) {
       load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
       if constexpr (((g + 1) * 4) % KG == 0) after_barrier(std::integral_constant<int, ((g + 1) * 4) / KG>{});
-    } else if constexpr (OBJ_SPREAD_DMA && kRingSlots == 2) {
+    } else if constexpr (OBJ_SPREAD_DMA) {
       // end of the layer: pieces the (shorter) last chunk had no group for
       static_for<Stream::kPieces>([&](auto I) __attribute__((always_inline)) {
         if constexpr (decltype(I)::value >= (g % GPC + 1) * PPG) st.template piece_now<decltype(I)::value>();
