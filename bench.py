@@ -404,7 +404,9 @@ def run(args, renderer=None, backend="nccl", argv=None):
                       "ray-samples/sec (MLP-evaluated sample points)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": scaling if (world > 1 or cfg_id in (3, 4)) else "weak",   # configs 3/4 are the sharded-frame modes at any N "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # configs 3 / 4 are the sharded-frame (strong-scaling) modes at any N
+            "scaling": scaling if (world > 1 or cfg_id in (3, 4)) else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": CONFIG_TEXT[cfg_id] % ((args.width, args.height, wl.S) + ((wl.I,) if cfg_id != 0 else ()))
                             + "; W1 random-init weights, %dx24 voxel table" % args.max_voxels,

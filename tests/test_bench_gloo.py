@@ -53,10 +53,28 @@ def _run(world, extra):
     return json.loads(q.get())
 
 
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config")
+
+
+def check_contract(line, n_gpus):
+    """the driver's JSON contract for bench.py's one line (a key that slips into a comment must not go unnoticed)"""
+    missing = [k for k in CONTRACT_KEYS if k not in line]
+    assert not missing, missing
+    assert line["unit"] == "ray-samples/s" and line["higher_is_better"] is True and line["n_gpus"] == n_gpus
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert line["scaling"] in ("weak", "strong") and isinstance(line["config"].get("workload"), str)
+    assert "model" not in line["config"]
+    assert line["value"] > 0 and abs(line["ms_per_step"] * line["value"] / 1e3 - line["config"]["evals_per_step_all_ranks"]) \
+        <= 1e-6 * line["config"]["evals_per_step_all_ranks"]
+
+
 @pytest.mark.parametrize("cfg", [3, 4])
 def test_strong_scaling_world2_equals_world1(cfg):
     one = _run(1, ["--config", str(cfg), "--dist"])
     two = _run(2, ["--config", str(cfg)])
+    check_contract(one, 1)
+    check_contract(two, 2)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and one["n_gpus"] == 1
     assert two["config"]["baseline_config_index"] == cfg
     mg = two["multi_gpu"]

@@ -55,7 +55,32 @@ def test_bench_editing_demo_over_rccl_world1():
 
 def test_bench_scene_only_line():
     r = _bench(["--config", "0"])
+    # the driver's contract keys + the two tier objects
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in r, k
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r["roofline"], k
     assert r["config"]["evals_per_ray"] == 64 and r["roofline"]["flop_per_eval"] == 1399808
+
+
+def test_bench_default_line_carries_cpu_baseline():
+    """the default (config 1, N = 1) line: cpu_baseline timed in the same run on a bounded sample, PSNR against it"""
+    small = [a for a in SMALL]
+    i = small.index("--cpu-rays")
+    small[i + 1] = "96"
+    e = dict(os.environ)
+    e.pop("OBJNERF_MFMA", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["config"]["baseline_config_index"] == 1 and r["n_gpus"] == 1
+    cb = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["unit"] == r["unit"] and 0 < cb["value"] < r["value"]
+    assert r["psnr_vs_cpu_oracle_db"] > 60.0
 
 
 def test_gradient_sync_over_rccl_world1():
