@@ -70,6 +70,47 @@ def sampler_on_reference(g, kw, randoms):
     return zf
 
 
+def multi_section():
+    """render_rays_multi (objnerf_render_rays_multi, one enqueue) against the reference's outputs of the four multi-object
+    golden cases: per key the max-norm error over all rays and over the settled rays (fine depths within 1e-4 of the
+    reference's), and how many rays are unsettled"""
+    from object_nerf_amd.multi_rendering import render_rays_multi
+    lines = ["## render_rays_multi (both modes)", ""]
+    m = cases.MULTI
+    specs = [("multi_scannet_dup", "voxel", lambda: cases.multi_inputs(), m["obj_ids"], dict(N_importance=64), True),
+             ("multi_coarse_only_white", "voxel", lambda: cases.multi_inputs(), m["obj_ids"], dict(N_importance=0, white_back=True), False),
+             ("multi_scannet_clip10", "voxel", lambda: cases.multi_inputs_clip(), m["obj_ids"], dict(N_importance=64), True)]
+    scenes = {}
+    for mode in ("f32", "bf16x3"):
+        os.environ["OBJNERF_MFMA"] = mode
+        for gname, sname, inputs, ids, kw, use_boxes in specs + [("multi_bench_edit_demo", "scannet_800k", None, cases.BENCH_MULTI["obj_ids"], dict(N_importance=64), True)]:
+            if sname not in scenes:
+                scenes[sname] = cases.scene_for(A, sname, device=DEV)
+            sc = scenes[sname]
+            g = cases.load_golden(gname)
+            if inputs is None:
+                sets = [g["_rays_%d" % k] for k in range(3)]
+                boxes = [cases.bench_multi_geometry()[2]]
+            else:
+                sets, boxes = inputs()
+            with torch.no_grad():
+                r = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.to(DEV) for s in sets], ids, N_samples=64,
+                                      perturb=0, noise_std=0, background_skip_bbox={4: boxes[0]} if use_boxes else None, **kw)
+            n = sets[0].shape[0]
+            settled = torch.ones(n, dtype=torch.bool)
+            if "z_vals_fine" in g:
+                dz = (r["z_vals_fine"].cpu().double() - g["z_vals_fine"].double()).abs().max(-1)[0] / g["z_vals_fine"].abs().max().item()
+                settled = dz <= 1e-4
+            lines += ["### %s, %s  (%d of %d rays unsettled)" % (gname, mode, int((~settled).sum()), n), "",
+                      "| key | err (all rays) | err (settled rays) |", "|---|---|---|"]
+            for k in sorted(x for x in g if not x.startswith("_") and x != "obj_ids_coarse"):
+                d = (r[k].cpu().double() - g[k].double()).abs()
+                d = d.reshape(n, -1).max(-1)[0] / g[k].double().abs().max().clamp_min(1e-30)
+                lines.append("| %s | %.1e | %.1e |" % (k, d.max().item(), d[settled].max().item() if settled.any() else 0.0))
+            lines.append("")
+    return lines
+
+
 def main(out_path):
     scenes = {}
     lines = ["# Parity of the HIP path vs the reference's outputs (round 2)", "",
@@ -141,6 +182,7 @@ def main(out_path):
                              % (k, err, floor, err / max(floor, 1e-30), es, es / max(floor, 1e-30), e2, f2, e2 / max(f2, 1e-30), t))
             lines.append("")
             summary.append((mode, case, p, worst, worst_l2, worst_s, int(moved.sum()), int(moved64.sum())))
+    lines += multi_section()
     lines += ["## Summary (sampling-dependent keys: worst error / floor ratio per case)", "",
               "| mode | case | PSNR dB | worst err/floor (max-norm) | worst err/floor (rel L2) | worst err_s/floor (settled rays) | "
               "rays moved (ours) | rays moved (fp64 oracle) |", "|---|---|---|---|---|---|---|---|"]
