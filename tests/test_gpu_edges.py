@@ -161,3 +161,42 @@ def test_invalidate_packed_after_data_writes():
         sc.models["coarse"].invalidate_packed()
         b = A.render_rays(sc.models, sc.embeddings, rays, **kw)["rgb_coarse"]
     assert (a - b).abs().max().item() > 1e-3
+
+
+def test_render_rays_multi_edge_batches():
+    """empty call, a single pixel, a call in which EVERY object ray missed its box (the culled MLP launch sees zero rays
+    and must write nothing), and one in which every ray hits (culling is the identity)"""
+    sc = scene("voxel")
+    sets, boxes = cases.multi_inputs()
+    kw = dict(N_samples=64, N_importance=64, perturb=0, noise_std=0)
+    ids = cases.MULTI["obj_ids"]
+    with torch.no_grad():
+        # empty
+        r = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s[:0].to(DEV) for s in sets], ids, **kw)
+        assert r["rgb_fine"].shape == (0, 3) and r["weights_fine"].shape == (0, 3 * 128) and r["obj_ids_coarse"].shape == (0, 192)
+        # one pixel == the same pixel of the 40-pixel call
+        full = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.to(DEV) for s in sets], ids, **kw)
+        one = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s[7:8].to(DEV) for s in sets], ids, **kw)
+        for k in full:
+            assert torch.equal(one[k], full[k][7:8]), k
+        # every object ray missed: the objects contribute nothing, the frame is the background's own render
+        missed = [sets[0]] + [s.clone() for s in sets[1:]]
+        for s in missed[1:]:
+            s[:, 6:8] = 0.0
+        rm = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.to(DEV) for s in missed], ids, **kw)
+        bg = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [sets[0].to(DEV)], [0], **kw)
+        assert torch.isfinite(rm["rgb_fine"]).all()
+        assert H.normwise(rm["rgb_fine"], bg["rgb_fine"]) < 1e-6 and H.normwise(rm["depth_fine"], bg["depth_fine"]) < 1e-6
+        assert H.normwise(rm["opacity_coarse"], bg["opacity_coarse"]) < 1e-6
+        # every ray hits
+        allhit = [sets[0]] + [s.clone() for s in sets[1:]]
+        for s in allhit[1:]:
+            dead = s[:, 7] == 0
+            s[dead, 6], s[dead, 7] = 0.7, 1.9
+        ra = render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.to(DEV) for s in allhit], ids, **kw)
+        ref = O.render_rays_multi(H.state(sc.models["coarse"]), H.state(sc.models["fine"]), H.oracle_grid(sc.embeddings["xyz"]),
+                                  sc.code_library.embedding_instance.weight.detach().cpu(), allhit, ids, N_samples=64,
+                                  N_importance=64)
+        for k in ("rgb_coarse", "opacity_coarse", "depth_coarse", "weights_coarse"):
+            assert H.normwise(ra[k], ref[k]) < 1e-4, k
+        assert H.normwise(ra["rgb_fine"], ref["rgb_fine"]) < 2e-2
