@@ -39,20 +39,39 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// Cross-lane steps as DPP modifiers on VALU instructions (no LDS crossbar traffic: a __shfl is a ds_bpermute_b32, and the
+// compositing kernels did 76 of them per 64-sample chunk).  dpp_ctrl: quad_perm 0x00-0xff, row_shr:n 0x110+n,
+// row_ror:n 0x120+n, wave_shr:1 0x138, row_bcast:15 0x142, row_bcast:31 0x143 (gfx9 encodings); lanes without a source
+// (or masked rows / banks) keep `old`.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// sum over the 64 lanes, returned in every lane: butterfly inside each row of 16 (quad swaps, row rotations), then the
+// row totals travel row_bcast:15 -> rows 1, 3 and row_bcast:31 -> rows 2, 3; lane 63 holds the total
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += dpp<0xB1>(0.f, v);            // quad_perm [1,0,3,2]
+  v += dpp<0x4E>(0.f, v);            // quad_perm [2,3,0,1]
+  v += dpp<0x124>(0.f, v);           // row_ror:4
+  v += dpp<0x128>(0.f, v);           // row_ror:8   -> every lane of a row holds the row's sum
+  v += dpp<0x142, 0xa>(0.f, v);      // row_bcast:15 into rows 1 and 3
+  v += dpp<0x143, 0xc>(0.f, v);      // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// inclusive product scan over the 64 lanes: Kogge-Stone inside each row of 16 (row_shr 1, 2, 4, 8; lanes without a source
+// multiply by 1), then the row totals as above
+__device__ __forceinline__ float wave_scan_mul(float v, int /*lane*/) {
+  v *= dpp<0x111>(1.f, v);
+  v *= dpp<0x112>(1.f, v);
+  v *= dpp<0x114>(1.f, v);
+  v *= dpp<0x118>(1.f, v);
+  v *= dpp<0x142, 0xa>(1.f, v);
+  v *= dpp<0x143, 0xc>(1.f, v);
   return v;
 }
-// inclusive product scan over the 64 lanes
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float t = __shfl_up(v, o);
-    if (lane >= o) v *= t;
-  }
-  return v;
-}
+// v of the lane below (lane 0 gets `fill`), and v of lane 63 in every lane
+__device__ __forceinline__ float wave_shr1(float v, float fill) { return dpp<0x138>(fill, v); }
+__device__ __forceinline__ float wave_last(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
 // ------------------------------------------------------------------------------------------
 // K1: coarse depths (models/rendering.py:260-277)
@@ -188,19 +207,61 @@ __device__ __forceinline__ CompositeOut composite_ray(const float* __restrict__ 
     }
     const float t = in ? (1.f - alpha) + 1e-10f : 1.f;     // alphas_shifted, rendering.py:159-161
     const float incl = wave_scan_mul(t, lane);
-    float excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 1.f;
+    const float excl = wave_shr1(incl, 1.f);
     const float T = carry * excl;
     const float w = alpha * T;                              // rendering.py:162
     if (in) {
       if (wout) wout[i] = w;
       so += w; sr += w * c0; sg += w * c1; sb += w * c2; sd += w * zi;
     }
-    carry = carry * __shfl(incl, 63);
+    carry = carry * wave_last(incl);
   }
   CompositeOut o;
   o.opacity = wave_sum(so); o.r = wave_sum(sr); o.g = wave_sum(sg); o.b = wave_sum(sb); o.depth = wave_sum(sd);
   return o;
+}
+
+// Scene and instance set of one ray in ONE sweep (no occlusion mask, i.e. the instance alphas do not depend on the scene
+// depth: eval mode, rendering.py:192): both sets' loads are in flight together, one memory round trip per chunk instead
+// of two dependent ones.  Per set the arithmetic and its order are exactly composite_ray's.
+__device__ __forceinline__ void composite_ray_pair(const float* __restrict__ z, const float* __restrict__ sigma0,
+                                                   const float* __restrict__ rgb0, const float* __restrict__ noise0,
+                                                   float last_delta0, float* __restrict__ wout0,
+                                                   const float* __restrict__ sigma1, const float* __restrict__ rgb1,
+                                                   const float* __restrict__ noise1, float* __restrict__ wout1,
+                                                   float noise_std, int S, int lane, CompositeOut& o0, CompositeOut& o1) {
+  float carry0 = 1.f, carry1 = 1.f;
+  float a0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, a1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // opacity, r, g, b, depth
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    const bool in = i < S;
+    float zi = 0.f, al0 = 0.f, al1 = 0.f, c0[3] = {0.f, 0.f, 0.f}, c1[3] = {0.f, 0.f, 0.f};
+    if (in) {
+      zi = z[i];
+      const bool last = i + 1 >= S;
+      const float dz = last ? 0.f : z[i + 1] - zi;
+      float s0 = sigma0[i], s1 = sigma1[i];
+      if (noise0) s0 = s0 + noise0[i] * noise_std;
+      if (noise1) s1 = s1 + noise1[i] * noise_std;
+      c0[0] = rgb0[i * 3]; c0[1] = rgb0[i * 3 + 1]; c0[2] = rgb0[i * 3 + 2];
+      c1[0] = rgb1[i * 3]; c1[1] = rgb1[i * 3 + 1]; c1[2] = rgb1[i * 3 + 2];
+      al0 = 1.f - expf(-(last ? last_delta0 : dz) * fmaxf(s0, 0.f));
+      al1 = 1.f - expf(-(last ? 0.f : dz) * fmaxf(s1, 0.f));          // the instance set's last delta is 0 (rendering.py:213)
+    }
+    const float t0 = in ? (1.f - al0) + 1e-10f : 1.f, t1 = in ? (1.f - al1) + 1e-10f : 1.f;
+    const float incl0 = wave_scan_mul(t0, lane), incl1 = wave_scan_mul(t1, lane);
+    const float w0 = al0 * (carry0 * wave_shr1(incl0, 1.f)), w1 = al1 * (carry1 * wave_shr1(incl1, 1.f));
+    if (in) {
+      if (wout0) wout0[i] = w0;
+      if (wout1) wout1[i] = w1;
+      a0[0] += w0; a0[1] += w0 * c0[0]; a0[2] += w0 * c0[1]; a0[3] += w0 * c0[2]; a0[4] += w0 * zi;
+      a1[0] += w1; a1[1] += w1 * c1[0]; a1[2] += w1 * c1[1]; a1[3] += w1 * c1[2]; a1[4] += w1 * zi;
+    }
+    carry0 = carry0 * wave_last(incl0);
+    carry1 = carry1 * wave_last(incl1);
+  }
+  o0.opacity = wave_sum(a0[0]); o0.r = wave_sum(a0[1]); o0.g = wave_sum(a0[2]); o0.b = wave_sum(a0[3]); o0.depth = wave_sum(a0[4]);
+  o1.opacity = wave_sum(a1[0]); o1.r = wave_sum(a1[1]); o1.g = wave_sum(a1[2]); o1.b = wave_sum(a1[3]); o1.depth = wave_sum(a1[4]);
 }
 
 __global__ void __launch_bounds__(256) composite_kernel(const objnerf_composite_args a) {
@@ -213,6 +274,26 @@ __global__ void __launch_bounds__(256) composite_kernel(const objnerf_composite_
     const bool inst = a.inst_sigma != nullptr;
     // scene: last delta 1e10 unless use_zero_as_last_delta (rendering.py:143-153)
     float* wscene = (inst && a.rays_in_bbox) ? nullptr : a.weights + ray * S;
+    if (inst && !a.occlusion) {          // kernel-uniform: both sets in one sweep
+      CompositeOut s, q;
+      composite_ray_pair(z, a.sigma + ray * S, a.rgb + ray * S * 3, a.noise ? a.noise + ray * S : nullptr,
+                         a.use_zero_as_last_delta ? 0.f : 1e10f, wscene, a.inst_sigma + ray * S, a.inst_rgb + ray * S * 3,
+                         a.noise_inst ? a.noise_inst + ray * S : nullptr, a.rays_in_bbox ? a.weights + ray * S : nullptr,
+                         a.noise_std, S, lane, s, q);
+      if (lane == 0) {
+        a.opacity[ray] = s.opacity;
+        a.depth[ray] = s.depth;
+        a.rgb_map[ray * 3 + 0] = a.white_back ? s.r + 1.f - s.opacity : s.r;
+        a.rgb_map[ray * 3 + 1] = a.white_back ? s.g + 1.f - s.opacity : s.g;
+        a.rgb_map[ray * 3 + 2] = a.white_back ? s.b + 1.f - s.opacity : s.b;
+        a.opacity_inst[ray] = q.opacity;
+        a.depth_inst[ray] = q.depth;
+        a.rgb_inst[ray * 3 + 0] = q.r + 1.f - q.opacity;
+        a.rgb_inst[ray * 3 + 1] = q.g + 1.f - q.opacity;
+        a.rgb_inst[ray * 3 + 2] = q.b + 1.f - q.opacity;
+      }
+      continue;
+    }
     const CompositeOut s = composite_ray(z, a.sigma + ray * S, a.rgb + ray * S * 3,
                                          a.noise ? a.noise + ray * S : nullptr, a.noise_std,
                                          a.use_zero_as_last_delta ? 0.f : 1e10f, S, lane, false, 0.f, wscene);
