@@ -33,12 +33,6 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   const int lo = __shfl((int)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_f64(v, o);
-  return v;
-}
-
 // Cross-lane steps as DPP modifiers on VALU instructions (no LDS crossbar traffic: a __shfl is a ds_bpermute_b32, and the
 // compositing kernels did 76 of them per 64-sample chunk).  dpp_ctrl: quad_perm 0x00-0xff, row_shr:n 0x110+n,
 // row_ror:n 0x120+n, wave_shr:1 0x138, row_bcast:15 0x142, row_bcast:31 0x143 (gfx9 encodings); lanes without a source
@@ -67,6 +61,38 @@ __device__ __forceinline__ float wave_scan_mul(float v, int /*lane*/) {
   v *= dpp<0x118>(1.f, v);
   v *= dpp<0x142, 0xa>(1.f, v);
   v *= dpp<0x143, 0xc>(1.f, v);
+  return v;
+}
+// float64 versions (two 32-bit DPP moves per step)
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const long long bo = __double_as_longlong(old), bv = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp((int)(bo & 0xffffffffll), (int)(bv & 0xffffffffll), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(bo >> 32), (int)(bv >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_last_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(0.0, v);
+  v += dpp_f64<0x4E>(0.0, v);
+  v += dpp_f64<0x124>(0.0, v);
+  v += dpp_f64<0x128>(0.0, v);
+  v += dpp_f64<0x142, 0xa>(0.0, v);
+  v += dpp_f64<0x143, 0xc>(0.0, v);
+  return wave_last_f64(v);
+}
+// inclusive sum scan over the 64 lanes
+__device__ __forceinline__ double wave_scan_add_f64(double v) {
+  v += dpp_f64<0x111>(0.0, v);
+  v += dpp_f64<0x112>(0.0, v);
+  v += dpp_f64<0x114>(0.0, v);
+  v += dpp_f64<0x118>(0.0, v);
+  v += dpp_f64<0x142, 0xa>(0.0, v);
+  v += dpp_f64<0x143, 0xc>(0.0, v);
   return v;
 }
 // v of the lane below (lane 0 gets `fill`), and v of lane 63 in every lane
@@ -345,7 +371,7 @@ __device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf
   const float tot = (float)wave_sum_f64(part);
   // cdf = cat([0, cumsum(pdf)]) (rendering.py:32-33).  ATen's CPU cumsum keeps its running sum in the accumulate type of
   // fp32, which is float64, and rounds every prefix to fp32 on store.  The same here: a wave-parallel inclusive scan in
-  // float64 (6 shuffle steps per 64 elements + a float64 carry), each prefix rounded to fp32.  A float64 prefix of <= 1023
+  // float64 (6 DPP steps per 64 elements + a float64 carry), each prefix rounded to fp32.  A float64 prefix of <= 1023
   // fp32 terms is exact to ~1e-16 relative in any association order, so the fp32-rounded prefixes equal the sequential
   // ones except when a float64 sum lies within that distance of an fp32 rounding boundary (probability ~1e-9 per
   // element).  Why it matters: u = 1 (the last deterministic sample) lands in the last bin or one bin earlier depending
@@ -356,14 +382,9 @@ __device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf
   for (int base = 0; base < nw; base += 64) {
     const int idx = base + lane;
     double v = idx < nw ? (double)__fdiv_rn(wts[idx] + eps, tot) : 0.0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const double t = shfl_up_f64(v, o);
-      v += lane >= o ? t : 0.0;
-    }
-    v += carry;
+    v = wave_scan_add_f64(v) + carry;
     if (idx < nw) cdf_lds[idx + 1] = (float)v;
-    carry = shfl_f64(v, 63);
+    carry = wave_last_f64(v);
   }
   __builtin_amdgcn_wave_barrier();
   for (int j = lane; j < I; j += 64) {
