@@ -126,6 +126,22 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, const float
   z_vals[idx] = z;
 }
 
+// unperturbed depths, four per thread (16-byte stores); same expression per element
+__global__ void sample_coarse4_kernel(const float* __restrict__ rays, const float* __restrict__ z_steps, int use_disp,
+                                      long n_rays, int S, float* __restrict__ z_vals) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = S >> 2;
+  if (idx >= n_rays * q) return;
+  const long ray = idx / q;
+  const int s = 4 * (int)(idx - ray * q);
+  const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
+  const f32x4 t = *(const f32x4*)(z_steps + s);
+  f32x4 z;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) z[j] = coarse_z(near, far, t[j], use_disp);
+  *(f32x4*)(z_vals + ray * S + s) = z;
+}
+
 // ------------------------------------------------------------------------------------------
 // Embedding.forward (embedding_helper.py:57-74)
 // ------------------------------------------------------------------------------------------
@@ -810,6 +826,11 @@ int objnerf_sample_coarse(const float* rays, const float* z_steps, const float* 
   if (!rays || !z_steps || !z_vals || S < 1 || n_rays < 0) return set_error(-1, "sample_coarse: bad arguments");
   if (perturb > 0.f && !perturb_rand) return set_error(-1, "sample_coarse: perturb > 0 needs perturb_rand");
   if (n_rays == 0) return 0;
+  if (!(perturb > 0.f) && (S & 3) == 0 && (((uintptr_t)z_steps | (uintptr_t)z_vals) & 15) == 0) {
+    hipLaunchKernelGGL(sample_coarse4_kernel, dim3(blocks_for(n_rays * (S >> 2), 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays, z_steps, use_disp, (long)n_rays, S, z_vals);
+    return check_launch("sample_coarse");
+  }
   hipLaunchKernelGGL(sample_coarse_kernel, dim3(blocks_for(n_rays * S, 256)), dim3(256), 0, (hipStream_t)stream,
                      rays, z_steps, perturb_rand, perturb, use_disp, (long)n_rays, S, z_vals);
   return check_launch("sample_coarse");
