@@ -35,6 +35,14 @@ struct GemmArgs {
   float* rowsum;         // optional, row-contiguous A' only: rowsum[m] += sum_k A'[m][k] (a Linear layer's bias gradient
                          // when A' = dY^T), accumulated with atomics by the workgroups of the first column of tiles
   int bx0, nbx;          // column tiles [bx0, bx0 + nbx) of the problem are computed by this launch (set by gemm_launch)
+  // Segmented contraction (split_k == 1 only): C = sum over segments s of A'_s [M x K_s] * B'_s [K_s x N], each segment
+  // with its own operand pointers / leading dimensions and the same contiguity flags -- one launch and one epilogue
+  // instead of nseg accumulating launches (the gradient w.r.t. an input that feeds several layers: train.hip).
+  // nseg == 0: the single segment (A, lda, B, ldb, K) above.
+  int nseg;
+  const float* segA[4]; long seglda[4];
+  const float* segB[4]; long segldb[4];
+  long segK[4];
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
@@ -176,10 +184,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   const long m0 = (long)by * GBM, n0 = (long)(g.bx0 + bx) * GBN;
   // TAIL: live 32-column sub-tiles of this (last, ragged) column tile
   const int ncol = TAIL ? (int)((g.N - n0 + 31) / 32) : 4;
-  // split-K slice of this workgroup
-  const long kchunk = ((g.K + g.split_k - 1) / g.split_k + GBK - 1) / GBK * GBK;
-  const long kbeg = (long)bz * kchunk;
-  const long kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
 
   // full tile: 2 x 2 waves, each 2 x 2 MFMA tiles (acc[2 i + j]); TAIL: 4 x 1 waves, acc[j] = column sub-tile j
   f32x16 acc[TAIL ? 3 : 4];
@@ -190,11 +194,21 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
 
   float rsum = 0.f;
   const bool want_rowsum = !A_KC && g.rowsum != nullptr && g.bx0 + bx == 0;     // uniform
+  const int nseg = g.nseg > 0 ? g.nseg : 1;
+  for (int sg = 0; sg < nseg; ++sg) {
+  const float* segA = g.nseg > 0 ? g.segA[sg] : g.A;
+  const float* segB = g.nseg > 0 ? g.segB[sg] : g.B;
+  const long seglda = g.nseg > 0 ? g.seglda[sg] : g.lda, segldb = g.nseg > 0 ? g.segldb[sg] : g.ldb;
+  const long segK = g.nseg > 0 ? g.segK[sg] : g.K;
+  // split-K slice of this workgroup (a segmented contraction is never split)
+  const long kchunk = ((segK + g.split_k - 1) / g.split_k + GBK - 1) / GBK * GBK;
+  const long kbeg = (long)bz * kchunk;
+  const long kend = kbeg + kchunk < segK ? kbeg + kchunk : segK;
   if (kbeg < kend) {          // uniform per workgroup
     GemmOperand<A_KC> opa;
     GemmOperand<B_KC> opb;    // B'[k][n]: "row" of the staged tile = n
-    opa.init(g.A, g.lda, m0, g.M, kbeg, tid);
-    opb.init(g.B, g.ldb, n0, g.N, kbeg, tid);
+    opa.init(segA, seglda, m0, g.M, kbeg, tid);
+    opb.init(segB, segldb, n0, g.N, kbeg, tid);
     opa.fetch(kbeg, kend, tid);
     opb.fetch(kbeg, kend, tid);
     const int half = lane >> 5, rl = lane & 31;
@@ -291,6 +305,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         buf ^= 1;
       }
     }
+  }
+  if (nseg > 1) __syncthreads();     // the next segment's first tile overwrites the LDS buffers
   }
   if (want_rowsum && m0 + (tid & 127) < g.M) atomicAdd(g.rowsum + m0 + (tid & 127), rsum);
   // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)

@@ -70,6 +70,23 @@ static void lin_dgrad(Ctx& c, const float* dY, long lddy, const float* W, long l
   GemmArgs g{dY, lddy, 1, W, ldw, 0, dX, lddx, P, in, out, accumulate, act ? EPI_LEAKY_BWD : EPI_NONE, act, 1, nullptr};
   c.rc = gemm_launch(g, c.s);
 }
+// dX (P x in) = sum_s dY_s (P x out_s) * W_s (out_s x in): the gradient w.r.t. an input that feeds several layers, as ONE
+// product over the concatenated contraction range (gemm.h "segmented contraction") instead of one accumulating launch
+// per consumer: no read-modify-write passes over dX and a 2-4x longer k loop per output tile
+struct DgradSeg { const float* dY; long lddy; const float* W; long ldw; int out; };
+static void lin_dgrad_multi(Ctx& c, const DgradSeg* segs, int nseg, long P, int in, float* dX, long lddx) {
+  if (c.rc || nseg <= 0) return;
+  GemmArgs g{segs[0].dY, segs[0].lddy, 1, segs[0].W, segs[0].ldw, 0, dX, lddx, P, in, segs[0].out, 0, EPI_NONE, nullptr, 1, nullptr};
+  if (nseg > 1) {
+    g.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) {
+      g.segA[i] = segs[i].dY; g.seglda[i] = segs[i].lddy;
+      g.segB[i] = segs[i].W; g.segldb[i] = segs[i].ldw;
+      g.segK[i] = segs[i].out;
+    }
+  }
+  c.rc = gemm_launch(g, c.s);
+}
 // dW (out x in, ld ldw) += dY^T (out x P) * X (P x in); split over the points
 // db (optional): the layer's bias gradient, db[o] += sum_p dY[p, o], taken from the dY^T tiles this GEMM stages anyway
 static void lin_wgrad(Ctx& c, const float* dY, long lddy, const float* X, long ldx, long P, int out, int in, float* dW,
@@ -275,10 +292,8 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     if (l == 5) {          // cat([input_xyz, h])
       lin_wgrad(c, d.A(5), 256, X, cx, P, 256, cx, gW(P_S5), cx + 256, db);
       lin_wgrad(c, d.A(5), 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
-      if (ce) lin_dgrad(c, d.A(5), 256, Wt(P_S5), cx + 256, P, 256, ce, d_emb_xyz, cx, 0);
     } else if (l == 1) {
       lin_wgrad(c, d.A(1), 256, X, cx, P, 256, cx, gW(P_S1), cx, db);
-      if (ce) lin_dgrad(c, d.A(1), 256, Wt(P_S1), cx, P, 256, ce, d_emb_xyz, cx, 1);   // layer 5 wrote it first
     } else {
       lin_wgrad(c, d.A(l), 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256, db);
     }
@@ -290,16 +305,11 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     lin_wgrad(c, d.odirh(), 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
     lin_wgrad(c, d.ofinal(), 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128, gB(P_OF));
     lin_wgrad(c, d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128, gB(P_OSIG));
-    bool ov_written = false;
     // one layer fed by cat([emb_xyz, obj_voxel, obj_code]): three column blocks of its weight
     auto obj_in_bwd = [&](const float* dY, int wid, int ldw, float* db) {
       lin_wgrad(c, dY, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
       if (vox) lin_wgrad(c, dY, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
       lin_wgrad(c, dY, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
-      if (ce) lin_dgrad(c, dY, 128, Wt(wid), ldw, P, 128, ce, d_emb_xyz, cx, 1);      // the scene branch wrote it first
-      if (vox) lin_dgrad(c, dY, 128, Wt(wid) + cx, ldw, P, 128, kObjVoxPE, d_obj_voxel, kObjVoxPE, ov_written ? 1 : 0);
-      lin_dgrad(c, dY, 128, Wt(wid) + cx + ov, ldw, P, 128, kCodeC, d_obj_code, kCodeC, ov_written ? 1 : 0);
-      ov_written = true;
     };
     for (int l = 4; l >= 1; --l) {
       float* db = gB(P_O1 + l - 1);
@@ -311,6 +321,19 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
       } else {
         lin_wgrad(c, d.B(l), 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128, db);
       }
+    }
+  }
+  // ---- gradients w.r.t. the embeddings: every consumer layer's dY W block in one segmented product per input ----
+  {
+    const int ov = vox ? kObjVoxPE : 0;
+    const DgradSeg emb[4] = {{d.A(5), 256, Wt(P_S5), cx + 256, 256}, {d.A(1), 256, Wt(P_S1), cx, 256},
+                             {d.B(3), 128, Wt(P_O3), co + 128, 128}, {d.B(1), 128, Wt(P_O1), co, 128}};
+    if (ce) lin_dgrad_multi(c, emb, obj ? 4 : 2, P, ce, d_emb_xyz, cx);       // only the voxel-feature columns (see above)
+    if (obj) {
+      const DgradSeg ovs[2] = {{d.B(3), 128, Wt(P_O3) + cx, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx, co, 128}};
+      if (vox) lin_dgrad_multi(c, ovs, 2, P, kObjVoxPE, d_obj_voxel, kObjVoxPE);
+      const DgradSeg cds[2] = {{d.B(3), 128, Wt(P_O3) + cx + ov, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx + ov, co, 128}};
+      lin_dgrad_multi(c, cds, 2, P, kCodeC, d_obj_code, kCodeC);
     }
   }
   return c.rc;
