@@ -162,8 +162,16 @@ struct GemmOperand {
   }
 };
 
+#ifndef OBJ_GEMM_WAVES
+#define OBJ_GEMM_WAVES 0     // > 0: ask the register allocator for this many waves per SIMD (tuning switch)
+#endif
+#if OBJ_GEMM_WAVES
+#define OBJ_GEMM_OCC __attribute__((amdgpu_waves_per_eu(OBJ_GEMM_WAVES, OBJ_GEMM_WAVES)))
+#else
+#define OBJ_GEMM_OCC
+#endif
 template <bool A_KC, bool B_KC, bool TAIL = false>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
+__global__ void __launch_bounds__(256) OBJ_GEMM_OCC gemm_kernel(const GemmArgs g) {
   constexpr int NBUF = OBJ_GEMM_DOUBLE_BUFFER ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * 2 * GTILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
