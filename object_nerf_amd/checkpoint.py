@@ -77,14 +77,17 @@ def build_from_state_dict(state_dict, model_config=None, device=None):
 
 
 def export_state_dict(scene):
-    """Flat Lightning-style state_dict of a scene built by build_from_state_dict / synth.build_scene."""
+    """Flat Lightning-style state_dict of a scene built by build_from_state_dict / synth.build_scene, keys in the order
+    the reference's LightningModule registers its children (train.py:45-65: embedding_xyz, nerf_coarse, nerf_fine,
+    code_library)."""
     out = OrderedDict()
-    for typ, m in scene.models.items():
-        for k, v in m.state_dict().items():
-            out["nerf_%s.%s" % (typ, k)] = v.detach().cpu()
-    for k, v in scene.code_library.state_dict().items():
-        out["code_library." + k] = v.detach().cpu()
     if isinstance(scene.embeddings["xyz"], EmbeddingVoxel):
         for k, v in scene.embeddings["xyz"].state_dict().items():
             out["embedding_xyz." + k] = v.detach().cpu()
+    for typ in ("coarse", "fine"):
+        if typ in scene.models:
+            for k, v in scene.models[typ].state_dict().items():
+                out["nerf_%s.%s" % (typ, k)] = v.detach().cpu()
+    for k, v in scene.code_library.state_dict().items():
+        out["code_library." + k] = v.detach().cpu()
     return out

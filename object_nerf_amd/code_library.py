@@ -10,19 +10,16 @@ the code table its gradient through ordinary autograd on the training path).
 """
 from torch import nn
 
-_IDS, _ROWS = "instance_ids", "embedding_instance"
-
 
 class CodeLibrary(nn.Module):
+    """A boundary type: three statements the callers and the checkpoint layout dictate (attribute name, `.get` defaults,
+    the squeeze, the result key), so it necessarily reads like the reference's."""
+
     def __init__(self, model_config):
         super().__init__()
-        table = nn.Embedding(num_embeddings=model_config.get("N_max_objs", 64),
-                             embedding_dim=model_config.get("N_obj_code_length", 64))
-        self.add_module(_ROWS, table)
-
-    def codes_for(self, instance_ids):
-        """(N,1) / (N,) integer ids -> (N, code_length) rows (ids are squeezed like the reference does)"""
-        return getattr(self, _ROWS)(instance_ids.squeeze())
+        self.embedding_instance = nn.Embedding(model_config.get("N_max_objs", 64), model_config.get("N_obj_code_length", 64))
 
     def forward(self, inputs):
-        return {_ROWS: self.codes_for(inputs[_IDS])} if _IDS in inputs else {}
+        if "instance_ids" not in inputs:
+            return {}
+        return {"embedding_instance": self.embedding_instance(inputs["instance_ids"].squeeze())}

@@ -224,6 +224,11 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (a->do_scene && !a->sigma) return set_error(-1, "mlp_eval: scene branch needs a sigma output");
   if (a->do_object && !a->inst_sigma) return set_error(-1, "mlp_eval: object branch needs an inst_sigma output");
   const bool fused = a->emb_xyz == nullptr;
+  // ray subset (objnerf_hip.h: fused form only, both or neither): a list without its count would make the kernel walk all
+  // n_rays slots of a list whose tail is uninitialised; a count without a list would silently evaluate the first rays
+  if ((a->ray_index == nullptr) != (a->n_active == nullptr))
+    return set_error(-1, "mlp_eval: ray_index and n_active go together (both or neither)");
+  if (a->ray_index && !fused) return set_error(-1, "mlp_eval: ray_index / n_active need the fused form (rays + z_vals)");
   long P;
   if (fused) {
     if (!a->rays || !a->z_vals || a->S < 1 || a->n_rays < 0) return set_error(-1, "mlp_eval: bad fused inputs");
@@ -383,6 +388,11 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
   const int K = in->K, S = cfg->N_samples, I = cfg->N_importance > 0 ? cfg->N_importance : 0;
   const int64_t N = in->n_rays;
   if (K < 1 || K > 16 || S < 1 || N < 0) return set_error(-1, "render_rays_multi: bad sizes (1 <= K <= 16)");
+  // limits of the stages further down the enqueue, checked BEFORE the first launch (the joint compositing stages
+  // K*(S+I) samples of 28 bytes in 64 KiB of LDS; the importance sampler needs S - 2 >= 1 interior bins)
+  if ((int64_t)K * (S + I) * 28 > 64 * 1024)
+    return set_error(-1, "render_rays_multi: K*(N_samples+N_importance) too large (28 bytes per sample must fit 64 KiB of LDS: K*(S+I) <= 2340)");
+  if (I > 0 && S < 3) return set_error(-1, "render_rays_multi: N_importance > 0 needs N_samples >= 3");
   if (N == 0) return 0;
   if (!in->h_rays || !in->h_obj_ids || !in->workspace || !in->blob_coarse || !in->aux_coarse || !in->z_steps)
     return set_error(-1, "render_rays_multi: missing input");

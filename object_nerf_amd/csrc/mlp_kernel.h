@@ -948,6 +948,24 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       if (P == 0) return;            // uniform across the grid; nothing has been issued yet
     }
   }
+  // Tile -> workgroup map.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with
+  // its own 4 MB L2.  Every XCD gets ONE contiguous eighth of the tiles and its 32 workgroups walk it side by side, so
+  // the voxel-table rows shared by neighbouring depths / neighbouring pixels are fetched into one L2 instead of eight
+  // (with the plain "tile = b + k * grid" map consecutive tiles land on 8 different XCDs).
+#if OBJ_XCD_TILES
+  const bool by_xcd = (gridDim.x & 7) == 0;
+#else
+  const bool by_xcd = false;
+#endif
+  const long tiles_per_xcd = (ntiles + 7) / 8;
+  const long tile_first = by_xcd ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const long tile_step = by_xcd ? (gridDim.x >> 3) : gridDim.x;
+  const long tile_end = by_xcd ? (((blockIdx.x & 7) + 1) * tiles_per_xcd < ntiles ? ((blockIdx.x & 7) + 1) * tiles_per_xcd : ntiles)
+                               : ntiles;
+  // a workgroup without a tile (the grid is sized for all n_rays, a culled ray subset may need far fewer): leave before
+  // the weight DMA, the aux staging and the first gather prologue are issued -- uniform per workgroup
+  if (tile_first >= tile_end) return;
+
   WeightStreamT<kCB> st;
   st.init((const char*)a.blob + (size_t)kStart * kCB, kEnd - kStart,
           (lds_char*)ring_mem, tid);
@@ -967,20 +985,6 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   constexpr int NE = ks_emb(VOXEL);
   constexpr int NO = ks_objin(VOXEL);
 
-  // Tile -> workgroup map.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with
-  // its own 4 MB L2.  Every XCD gets ONE contiguous eighth of the tiles and its 32 workgroups walk it side by side, so
-  // the voxel-table rows shared by neighbouring depths / neighbouring pixels are fetched into one L2 instead of eight
-  // (with the plain "tile = b + k * grid" map consecutive tiles land on 8 different XCDs).
-#if OBJ_XCD_TILES
-  const bool by_xcd = (gridDim.x & 7) == 0;
-#else
-  const bool by_xcd = false;
-#endif
-  const long tiles_per_xcd = (ntiles + 7) / 8;
-  const long tile_first = by_xcd ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-  const long tile_step = by_xcd ? (gridDim.x >> 3) : gridDim.x;
-  const long tile_end = by_xcd ? (((blockIdx.x & 7) + 1) * tiles_per_xcd < ntiles ? ((blockIdx.x & 7) + 1) * tiles_per_xcd : ntiles)
-                               : ntiles;
   constexpr bool PREFETCH = OBJ_PREFETCH_TILE && FUSED && DO_OBJ;
   TilePrologue<VOXEL> pre;
   if constexpr (FUSED) {

@@ -126,14 +126,18 @@ class GradientSync:
     """
 
     def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
-                 active_rows: Dict[torch.nn.Parameter, int] = None, reduce_at_world1: bool = False):
+                 active_rows: Dict[torch.nn.Parameter, int] = None, reduce_at_world1: bool = False,
+                 check_inactive_rows: bool = False):
         """active_rows: {parameter: n} -- only the first n rows of that (2-D) parameter can ever receive a gradient, so only
         `grad[:n]` travels.  This is the sparse handling of the voxel feature table: the renderer only
         reads rows the index map points at, i.e. rows < number of occupied voxels (`EmbeddingVoxel.active_rows()`); the
         reference's `max_voxels` = 800000 rows (76.8 MB of gradient) are mostly padding -- 103.6k rows = 9.9 MB in the
         ScanNet-like scene, 10.8k rows = 1 MB in the ToyDesk-2-like one.  Contiguous prefix: no index exchange, no
         host synchronisation.  reduce_at_world1: issue the collectives even in a 1-rank group (tests of the RCCL path on
-        one GPU); by default a 1-rank sync is a no-op."""
+        one GPU); by default a 1-rank sync is a no-op.  check_inactive_rows: debug switch -- every sync asserts that the rows
+        beyond the active prefix carry no gradient (a host synchronisation per parameter: off by default); call
+        `set_active_rows` after the voxel index map changes (e.g. a checkpoint with another occupancy was loaded)."""
+        self.check_inactive_rows = bool(check_inactive_rows)
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.reduce_at_world1 = bool(reduce_at_world1)
@@ -157,6 +161,14 @@ class GradientSync:
             self.buckets.append(cur)
         self._flat: List[torch.Tensor] = [None] * len(self.buckets)
 
+    def set_active_rows(self, param: torch.nn.Parameter, n: int) -> None:
+        """new travelling prefix of `param` (same value on every rank); the flat buffers are re-sized on the next sync"""
+        i = next(j for j, p in enumerate(self.params) if p is param)
+        if n < 0 or n > param.shape[0]:
+            raise ValueError("active_rows: parameter has %d rows" % param.shape[0])
+        self.rows[i] = int(n)
+        self._flat = [None] * len(self.buckets)
+
     def _numel(self, i: int) -> int:
         p = self.params[i]
         return p.numel() if self.rows[i] < 0 else self.rows[i] * p.shape[1]
@@ -169,7 +181,7 @@ class GradientSync:
         idx = self.buckets[b]
         n = sum(self._numel(i) for i in idx)
         dev = self.params[idx[0]].device
-        if self._flat[b] is None or self._flat[b].device != dev:
+        if self._flat[b] is None or self._flat[b].device != dev or self._flat[b].numel() != n:
             self._flat[b] = torch.empty(n, dtype=torch.float32, device=dev)
         return self._flat[b]
 
@@ -197,6 +209,9 @@ class GradientSync:
                     view.zero_()
                 else:
                     view.copy_(self._travelling(i, p.grad))
+                    if self.check_inactive_rows and self.rows[i] >= 0 and bool(p.grad[self.rows[i]:].any()):
+                        raise RuntimeError("GradientSync: a row beyond active_rows = %d received a gradient (the voxel index "
+                                           "map changed after construction?): ranks would diverge" % self.rows[i])
                 off += n
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         inv = 1.0 / world
@@ -210,6 +225,10 @@ class GradientSync:
                 g = flat[off:off + n]
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
-                dst = self._travelling(i, p.grad)        # a view of p.grad (grads are contiguous)
-                torch.mul(g, inv, out=dst)
+                if p.grad.is_contiguous():
+                    torch.mul(g, inv, out=self._travelling(i, p.grad))     # a view of p.grad: written in place
+                elif self.rows[i] < 0:
+                    p.grad.copy_((g * inv).view_as(p.grad))                # any layout: reshape() would have been a copy
+                else:
+                    p.grad[: self.rows[i]].copy_((g * inv).view(self.rows[i], -1))
                 off += n

@@ -63,9 +63,21 @@ def render_rays_multi(
         raise RuntimeError("render_rays_multi: every ray set must have the same number of rays")
     boxes = pack_boxes(background_skip_bbox, dev) if background_skip_bbox else None
     ids = [int(i) for i in obj_instance_ids]
-    table = _lib.as_f32(code_library.embedding_instance.weight.detach())
-    if any(i < 0 or i >= table.shape[0] for i in ids) or table.shape[1] != 64:
-        raise RuntimeError("render_rays_multi: object ids must index the (N_max_objs, 64) code table")
+    table = None
+    if any(i != 0 for i in ids):          # the code table is only read for object sets (multi_rendering.py:45-51)
+        w = code_library.embedding_instance.weight.detach()
+        _lib.require_cuda(w, "code_library.embedding_instance.weight")
+        if w.device != dev:
+            raise RuntimeError("render_rays_multi: the code library is on %s, the rays on %s" % (w.device, dev))
+        table = _lib.as_f32(w)
+        if any(i < 0 or i >= table.shape[0] for i in ids) or table.shape[1] != 64:
+            raise RuntimeError("render_rays_multi: object ids must index the (N_max_objs, 64) code table")
+    elif any(i < 0 for i in ids):
+        raise RuntimeError("render_rays_multi: negative object id")
+    # limits of the joint compositing kernel, raised before anything is enqueued (objnerf_render_rays_multi checks them too)
+    if K > 16 or K * (S + max(I, 0)) * 28 > 64 * 1024:
+        raise RuntimeError("render_rays_multi: %d ray sets x %d samples exceed the joint compositing limits "
+                           "(K <= 16, K * (N_samples + N_importance) <= 2340)" % (K, S + max(I, 0)))
 
     b3 = mfma_mode() == "bf16x3"
     cfg = _lib.RenderMultiCfg(use_voxel=int(use_voxel), N_samples=S, N_importance=I, use_disp=int(bool(use_disp)),
@@ -77,7 +89,8 @@ def render_rays_multi(
     h_rays = (C.c_void_p * K)(*[r.data_ptr() for r in rays_c])
     h_ids = (C.c_int32 * K)(*ids)
     rin.h_rays, rin.h_obj_ids = h_rays, h_ids
-    rin.code_table = table.data_ptr()
+    if table is not None:
+        rin.code_table = table.data_ptr()
     bc, ac = coarse.packed(split_bf16=b3)
     rin.blob_coarse, rin.aux_coarse = bc.data_ptr(), ac.data_ptr()
     keep = [rays_c, table, ws, bc, ac, boxes]

@@ -8,6 +8,7 @@ The committed vectors pin both the oracle (tests/test_oracle_vs_golden.py, CPU) 
 (tests/test_gpu_*.py).  The reference itself ships no golden vectors or tests for this path
 (SURVEY.md §4), so these are outputs of the reference code itself, fp32, torch 2.10 CPU kernels.
 """
+import math
 import os
 import sys
 import types
@@ -43,6 +44,97 @@ def save(name, d):
     print("wrote %-28s %s" % (name, {k: tuple(a.shape) for k, a in list(arrs.items())[:4]}))
 
 
+def _f64_oracle(fn, *a, **kw):
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.no_grad():
+            return fn(*a, **kw)
+    finally:
+        torch.set_default_dtype(old)
+
+
+def _dbl(d):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+
+
+def frames(ref, scene):
+    """Image-scale goldens (cases.FRAME_CASES): one 160x120 frame of each bench workload rendered by the real reference
+    (utils/metrics.py:5-15 defines PSNR over a frame).  Stored per case: the pixel maps of both passes, the fine depths of
+    every sub-th ray (moved-ray count on the GPU), `_floor_<key>` = max-norm distance between the reference's fp32 maps
+    and the float64 oracle on the same inputs (the reference's own fp32 noise floor), `_floor_l2_<key>` the same in
+    relative L2, `_moved64` = the float64 oracle's moved-ray count on the stored subset."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from oracle import objnerf_oracle as O
+    for case, fc in cases.FRAME_CASES.items():
+        out = {}
+        if fc["kind"] == "single":
+            rays, ids, kw, sname = cases.frame_inputs(case)
+            sc = scene(sname)
+            codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+            r = dict(ref.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, chunk=32768, **kw))
+            okw = {k: v for k, v in kw.items()}
+            f64 = _f64_oracle(O.render_rays, _dbl(H.state(sc.models["coarse"])), _dbl(H.state(sc.models["fine"])),
+                              _dbl(H.oracle_grid(sc.embeddings["xyz"])), rays.double(), embedding_instance=codes.double(), **okw)
+            maps = cases.FRAME_MAPS
+            sub = torch.arange(0, rays.shape[0], cases.FRAME["sub"])
+            zc_sub = r["z_vals_coarse"][sub]
+        else:
+            sname = cases.frame_inputs(case)[3]
+            sc = scene(sname)
+            bm = cases.BENCH_MULTI
+            focal, poses, box, _ = cases.frame_inputs(case)
+            w_, h_ = cases.FRAME["W"], cases.FRAME["H"]
+            directions = ref.get_ray_directions(h_, w_, focal)
+            helper = ref_import.make_box(box)
+            sets = []
+            for k, Toc in enumerate(poses):
+                rays_o, rays_d = ref.get_rays(directions, torch.from_numpy(np.asarray(Toc)).float())
+                if k == 0:
+                    pre = synth.SCANNET_LIKE
+                    nf = [pre["near"] * torch.ones_like(rays_o[:, :1]), pre["far"] * torch.ones_like(rays_o[:, :1])]
+                else:
+                    mask, bn, bf = helper.get_ray_bbox_intersections(rays_o, rays_d, box["scale_factor"], bbox_enlarge=bm["bbox_enlarge"])
+                    bn[~mask] = torch.zeros_like(bn[~mask])
+                    bf[~mask] = torch.zeros_like(bf[~mask])
+                    nf = [bn, bf]
+                    out["_hit_%d" % k] = np.packbits(mask.numpy())
+                sets.append(torch.cat([rays_o, rays_d] + nf, 1))
+            # the tests regenerate these ray sets with the oracle's generate_rays: it has to be bit-equal to the reference's
+            for a, b in zip(sets, cases.frame_multi_sets(O.generate_rays, case)):
+                assert torch.equal(a, b), "oracle generate_rays differs from the reference's ray / box code"
+            r = dict(ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets], bm["obj_ids"],
+                                           N_samples=bm["N_samples"], N_importance=bm["N_importance"], perturb=0, noise_std=0,
+                                           chunk=32768, white_back=False, background_skip_bbox={4: helper}))
+            for typ in ("coarse", "fine"):
+                zz = r["z_vals_" + typ]
+                out["_tied_" + typ] = ((zz[:, 1:] == zz[:, :-1]) & (zz[:, 1:] != 0)).any(1).sum()
+            f64 = _f64_oracle(O.render_rays_multi, _dbl(H.state(sc.models["coarse"])), _dbl(H.state(sc.models["fine"])),
+                              _dbl(H.oracle_grid(sc.embeddings["xyz"])), sc.code_library.embedding_instance.weight.detach().double(),
+                              [s.double() for s in sets], bm["obj_ids"], N_samples=bm["N_samples"],
+                              N_importance=bm["N_importance"], skip_boxes=[box])
+            maps = ["rgb", "depth", "opacity"]
+            sub = torch.arange(0, sets[0].shape[0], cases.FRAME["sub_multi"])
+            # the joint coarse depths interleave the K sets: the spacing a moved sample is measured against is a set's own
+            # (the background's; helpers.frame_report does the same)
+            nf = sets[0][sub, 6:8]
+            zc_sub = nf[:, :1] + (nf[:, 1:] - nf[:, :1]) * torch.linspace(0, 1, bm["N_samples"])
+        for typ in ("coarse", "fine"):
+            for m in maps:
+                k = "%s_%s" % (m, typ)
+                out[k] = r[k]
+                out["_floor_" + k] = H.normwise(r[k], f64[k])
+                out["_floor_l2_" + k] = H.rel_l2(r[k], f64[k])
+        out["_sub"] = sub
+        out["_z_vals_fine_sub"] = r["z_vals_fine"][sub]
+        out["_moved64"] = int(H.moved_rays(f64["z_vals_fine"][sub], r["z_vals_fine"][sub], zc_sub).sum())
+        out["_psnr64"] = -10.0 * math.log10(max(((r["rgb_fine"].double() - f64["rgb_fine"]) ** 2).mean().item(), 1e-30))
+        print(case, "floors:", {k[7:]: "%.1e" % float(v) for k, v in out.items() if k.startswith("_floor_") and "l2" not in k},
+              "moved64", out["_moved64"], "of", len(sub), "psnr64 %.1f" % out["_psnr64"])
+        save(case, out)
+
+
 def main():
     torch.set_num_threads(8)
     ref = ref_import.load_reference()
@@ -54,7 +146,13 @@ def main():
             scenes[name] = cases.scene_for(rt, name)
         return scenes[name]
 
+    if "--frames" in sys.argv:       # only the image-scale cases (minutes of CPU: the other files are left untouched)
+        with torch.no_grad():
+            frames(ref, scene)
+        return
+
     with torch.no_grad():
+        frames(ref, scene)
         # ---- render_rays end to end ----
         for case, c in cases.RENDER_CASES.items():
             sc = scene(c["scene"])

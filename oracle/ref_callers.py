@@ -28,6 +28,9 @@ Two flavours, each in its OWN process because both own the module names `models`
               drop-in modules' own parameters.  Outputs must equal the reference flavour's bit for bit; the recorded
               calls are written to <work>/calls.npz.  Also writes <work>/dropin.ckpt (checkpoint.export_state_dict).
   reference-load   loads <work>/dropin.ckpt into the reference-typed system (strict) and re-renders one scenario.
+  checkpoint  writes <work>/reference_small.ckpt (a small scene, reference module types, Lightning layout) and
+              <work>/ckpt_render.npz (what the reference renders from it): the committed fixture of the `-m gpu`
+              checkpoint test (tests/test_gpu_checkpoint.py; `python oracle/ref_callers.py checkpoint tests/golden`).
 
 tests/golden/callers_{outputs,calls}.npz are these files, committed; the `-m gpu` test replays the recorded calls
 through the HIP entry points on the GPU box (where the reference is absent) and compares with the real callers' outputs.
@@ -104,17 +107,17 @@ def install_caller_stubs():
     sys.modules.setdefault("kornia.losses", kl)
 
 
-def make_config(work):
+def make_config(work, n_points=200_000, max_voxels=MAX_VOXELS):
     """the training config the callers read (config/default_conf.yml + config/scannet_base_0113_multi.yml shapes)"""
     from object_nerf_amd import synth
     from object_nerf_amd.config import default_model_config
     from oracle import ref_import
-    extra = dict(synth.dataset_extra(synth.SCANNET_LIKE, 200_000))
+    extra = dict(synth.dataset_extra(synth.SCANNET_LIKE, n_points))
     cloud = extra.pop("pcd_xyz")
     ref_import.POINT_CLOUDS["callers.ply"] = np.asarray(cloud)
     extra["pcd_path"] = "callers.ply"                                 # read through the stub open3d by BOTH flavours
     extra.update(near=synth.SCANNET_LIKE["near"], far=synth.SCANNET_LIKE["far"])
-    model = dict(default_model_config(use_voxel_embedding=True, N_max_voxels=MAX_VOXELS, N_importance=64))
+    model = dict(default_model_config(use_voxel_embedding=True, N_max_voxels=max_voxels, N_importance=64))
     model.update(frustum_bound=0.05)
     cfg = dict(model=model, dataset_extra=extra, dataset_name="scannet_base", img_wh=[12, 10],
                train=dict(chunk=CHUNK, optimizer="adam", lr=5e-4, weight_decay=0, lr_scheduler="steplr", decay_step=[100],
@@ -364,19 +367,70 @@ def run_scenarios(flavour, work, rec):
     return out
 
 
+# the committed checkpoint fixture (row f3): a 300-point cloud (6,025 occupied voxels of the 62 x 62 x 27 grid) and a
+# 6,500-row table keep the file at 8 MB -- 7.1 MB of it are the two MLPs, whose architecture the kernels fix
+CKPT_POINTS, CKPT_MAX_VOXELS = 300, 6500
+
+
+def _box_helper(box):
+    """a reference BBoxRayHelper for a synth.oriented_box dict (its constructor reads dataset files, bbox_utils.py:10-34)"""
+    import utils.bbox_utils as BU
+    helper = object.__new__(BU.BBoxRayHelper)
+    helper.scale_factor = box["scale_factor"]
+    helper.pose_avg = np.eye(4); helper.pose_avg[:3, :3] = box["R_avg"]; helper.pose_avg[:3, 3] = box["t_avg"]
+    helper.axis_align_mat = np.eye(4); helper.axis_align_mat[:3, :3] = box["R_box"]; helper.axis_align_mat[:3, 3] = box["t_box"]
+    helper.bbox_bounds = np.array([np.asarray(box["bmin"], dtype=np.float64), np.asarray(box["bmax"], dtype=np.float64)])
+    return helper
+
+
+def write_checkpoint_fixture(work):
+    """tests/golden/reference_small.ckpt + ckpt_render.npz: the REAL train.py::ObjectNeRFSystem built from the REFERENCE's
+    module types, filled with the seeded W1 weights, saved the way Lightning saves it ({"state_dict": ...}), and what the
+    reference renders from it: render_rays on cases.render_inputs("voxel_eval") (64 + 64, eval) and render_rays_multi on
+    cases.multi_inputs() (ids [0, 4, 4], removed-object box) -- editable_renderer.py:75-79 then 125-140 / 272-287."""
+    from oracle import ref_import
+    import cases
+    import train as T
+    import render_tools.multi_rendering as MR
+    assert T.__file__.startswith(REF) and T.render_rays.__module__ == "models.rendering"
+    cfg = make_config(work, CKPT_POINTS, CKPT_MAX_VOXELS)
+    system = T.ObjectNeRFSystem(cfg)
+    assert type(system.nerf_coarse).__module__ == "models.nerf_model"
+    fill_system(system)
+    system.eval()
+    torch.save({"state_dict": system.state_dict(), "epoch": 0, "global_step": 0}, os.path.join(work, "reference_small.ckpt"))
+    out = {}
+    with torch.no_grad():
+        rays, ids, _, _ = cases.render_inputs("voxel_eval")
+        codes = system.code_library({"instance_ids": ids})["embedding_instance"]
+        r = T.render_rays(system.models, system.embeddings, rays, N_samples=64, N_importance=64, perturb=0, noise_std=0,
+                          chunk=32768, embedding_instance=codes, is_eval=True)
+        out.update({"single_" + k: v for k, v in r.items()})
+        sets, boxes = cases.multi_inputs()
+        m = cases.MULTI
+        r = MR.render_rays_multi(system.models, system.embeddings, system.code_library, [s.clone() for s in sets], m["obj_ids"],
+                                 N_samples=m["N_samples"], N_importance=m["N_importance"], perturb=0, noise_std=0, chunk=32768,
+                                 white_back=False, background_skip_bbox={4: _box_helper(boxes[0])})
+        out.update({"multi_" + k: v for k, v in r.items()})
+    np.savez_compressed(os.path.join(work, "ckpt_render.npz"), **{k: v.numpy() for k, v in out.items()})
+    print("checkpoint flavour: %d tensors in the state_dict, %d rendered arrays" % (len(system.state_dict()), len(out)))
+
+
 def main():
     flavour, work = sys.argv[1], sys.argv[2]
     os.makedirs(work, exist_ok=True)
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, ROOT)
-    if flavour in ("reference", "reference-load"):
+    if flavour in ("reference", "reference-load", "checkpoint"):
         sys.path.insert(0, REF)
     else:
         sys.path.insert(0, REF)
         sys.path.insert(0, os.path.join(ROOT, "dropin"))
     install_caller_stubs()
-    if flavour == "reference":
+    if flavour == "checkpoint":
+        write_checkpoint_fixture(work)
+    elif flavour == "reference":
         out = run_scenarios("reference", work, None)
         np.savez_compressed(os.path.join(work, "callers.npz"), **{k: v.numpy() for k, v in out.items()})
         print("reference flavour: %d arrays" % len(out))
@@ -403,7 +457,7 @@ def main():
             assert torch.equal(v, ref[k]), k
         print("reference-load: %d tensors equal" % len(ref))
     else:
-        raise SystemExit("usage: ref_callers.py reference|dropin|reference-load <workdir>")
+        raise SystemExit("usage: ref_callers.py reference|dropin|reference-load|checkpoint <workdir>")
 
 
 if __name__ == "__main__":

@@ -209,3 +209,42 @@ def load_golden(name):
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     z = np.load(path)
     return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+# ---- image-scale parity: a whole 160x120 frame of each bench workload rendered by the REAL reference ----------------
+# (VERDICT r2 missing #3 / SURVEY §8d "PSNR definition": utils/metrics.py:5-15 is a mean over a frame; the 48-ray cases
+# above cannot carry that).  Same scenes, presets, weights and code assignment as bench.py --config 1 / 2 / 4, the camera
+# of the preset at 160x120 (same pose and field of view: every fourth pixel direction of the 640x480 frame, roughly).
+# Stored: the pixel maps only (+ the fine depths of every FRAME["sub"]-th ray for the moved-ray count, the float64
+# oracle's distances from the reference per key = the fp32 noise floor, and its moved-ray count), see make_golden.frames().
+FRAME = dict(W=160, H=120, sub=8, sub_multi=24)
+FRAME_CASES = {
+    "frame_toydesk2": dict(kind="single", render_case="bench_toydesk2"),            # BASELINE configs[1]
+    "frame_scannet_multi": dict(kind="single", render_case="bench_scannet_multi"),  # BASELINE configs[2] / [3]
+    "frame_edit_demo": dict(kind="multi"),                                          # BASELINE configs[4]
+}
+FRAME_MAPS = ["rgb", "depth", "opacity", "rgb_instance", "depth_instance", "opacity_instance"]
+
+
+def frame_inputs(case):
+    """single: (rays (n,8), ids (n), render_rays kwargs, scene name); multi: (focal, poses, box, scene name)"""
+    fc = FRAME_CASES[case]
+    w, h = FRAME["W"], FRAME["H"]
+    if fc["kind"] == "single":
+        c = RENDER_CASES[fc["render_case"]]
+        rays = synth.preset_rays(SCENES[c["scene"]][2], w, h)
+        n = rays.shape[0]
+        ids = synth.per_ray_ids(n) if c["ids"] == "five" else torch.full((n,), int(c["ids"]), dtype=torch.long)
+        kw = dict(c["kw"], perturb=0, noise_std=0)
+        return rays, ids, kw, c["scene"]
+    focal, poses, box = synth.edit_demo_geometry(synth.SCANNET_LIKE, w)
+    return focal, poses, box, "scannet_800k"
+
+
+def frame_multi_sets(gen, case="frame_edit_demo"):
+    """The three ray sets of the 160x120 editing-demo frame through a `generate_rays(H, W, focal, c2w, near, far, box=,
+    bbox_enlarge=)`-shaped function (the oracle's, bit-equal to the reference's ray / box code; or the device kernel)."""
+    focal, poses, box, _ = frame_inputs(case)
+    pre, bm = synth.SCANNET_LIKE, BENCH_MULTI
+    return [gen(FRAME["H"], FRAME["W"], focal, torch.from_numpy(np.asarray(T)).float(), pre["near"], pre["far"],
+                box=None if k == 0 else box, bbox_enlarge=bm["bbox_enlarge"]) for k, T in enumerate(poses)]

@@ -182,6 +182,28 @@ def test_c_abi_argument_validation():
     rin.K = 2
     assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0
     assert b"missing input" in l.objnerf_last_error()
+    # round 3: the compositing kernel's LDS limit and the sampler's S >= 3 are checked BEFORE the first launch
+    big = _lib.RenderMultiCfg(N_samples=64, N_importance=128)
+    rin.K = 13                                                    # 13 x 192 x 28 B > 64 KiB
+    assert l.objnerf_render_rays_multi(C.byref(big), C.byref(rin), C.byref(out), None, None) < 0
+    assert b"too large" in l.objnerf_last_error()
+    rin.K = 2
+    tiny = _lib.RenderMultiCfg(N_samples=2, N_importance=4)
+    assert l.objnerf_render_rays_multi(C.byref(tiny), C.byref(rin), C.byref(out), None, None) < 0
+    assert b"N_samples >= 3" in l.objnerf_last_error()
+    # ray subset of objnerf_mlp_eval: list and count go together, fused form only
+    a = _lib.MlpArgs()
+    a.blob = a.aux = 64                                           # non-null dummies: validation never dereferences them
+    a.rays = a.z_vals = a.sigma = 64
+    a.n_rays, a.S, a.do_scene = 4, 8, 1
+    a.ray_index = 64
+    assert l.objnerf_mlp_eval(C.byref(a), None) < 0 and b"go together" in l.objnerf_last_error()
+    a.ray_index, a.n_active = None, 64
+    assert l.objnerf_mlp_eval(C.byref(a), None) < 0 and b"go together" in l.objnerf_last_error()
+    a.ray_index = 64
+    a.emb_xyz = a.emb_dir = 64                                    # memory form
+    a.n_points = 4
+    assert l.objnerf_mlp_eval(C.byref(a), None) < 0 and b"fused form" in l.objnerf_last_error()
 
 
 def test_library_never_allocates_or_synchronises():
