@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 5
+#define OBJNERF_ABI_VERSION 6
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -256,6 +256,28 @@ int objnerf_composite_multi(const objnerf_composite_multi_args* args, void* stre
  * for rays that miss the box or start inside it.  rays: (H*W, 8) row-major pixel order. */
 int objnerf_generate_rays(int H, int W, float focal, const float* h_c2w, float near, float far,
                           const double* h_box, double bbox_enlarge, float* rays, void* stream);
+/* The same for a subset of the image rows (one rank's share of a sharded frame): n_rows rows, local row lr = image row
+ * row0 + (lr / row_block) * row_block * block_stride + lr % row_block.  A contiguous band is row_block = n_rows,
+ * block_stride = 1; the block-cyclic share of rank r of w ranks is row0 = r * row_block, block_stride = w.
+ * rays: (n_rows * W, 8). */
+int objnerf_generate_rays_rows(int H, int W, float focal, const float* h_c2w, float near, float far,
+                               const double* h_box, double bbox_enlarge, int row0, int n_rows, int row_block,
+                               int block_stride, float* rays, void* stream);
+/* The stage-by-stage form of the above, as the reference's unchanged caller issues it
+ * (render_tools/editable_renderer.py:191-198, 215, 257, 163-170) -- same device arithmetic as objnerf_generate_rays:
+ *   objnerf_ray_directions    datasets/ray_utils.py:5-25   get_ray_directions -> directions (H*W, 3)
+ *   objnerf_get_rays          datasets/ray_utils.py:28-51  get_rays: directions (n,3), c2w = DEVICE pointer to the (3,4)
+ *                             matrix, rows row_stride floats apart (4 for a contiguous (3,4) or the top of a (4,4))
+ *                             -> rays_o (n,3), rays_d (n,3)
+ *   objnerf_ray_box_near_far  utils/bbox_utils.py:132-156 BBoxRayHelper.get_ray_bbox_intersections (+ the slab test
+ *                             datasets/geo_utils.py:111-162 it calls on the host): rays_o/rays_d (n,3), h_box = HOST
+ *                             OBJNERF_BOX_DOUBLES doubles (bounds NOT enlarged), bbox_enlarge grows both bounds when > 0
+ *                             -> hit (n) uint8, near (n), far (n) already divided by the box's scale_factor, 0/0 on a miss */
+int objnerf_ray_directions(int H, int W, float focal, float* directions, void* stream);
+int objnerf_get_rays(const float* directions, int64_t n, const float* c2w, int row_stride, float* rays_o, float* rays_d,
+                     void* stream);
+int objnerf_ray_box_near_far(const float* rays_o, const float* rays_d, int64_t n, const double* h_box, double bbox_enlarge,
+                             uint8_t* hit, float* near, float* far, void* stream);
 
 /* ---- whole render_rays (models/rendering.py:233-337) in one enqueue ---- */
 typedef struct {

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 5     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 6     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -179,6 +179,11 @@ SIGNATURES = {
     "objnerf_points_in_boxes": (C.c_int, [_VP, C.c_int64, _VP, C.c_int, _VP, _VP]),
     "objnerf_composite_multi": (C.c_int, [C.POINTER(CompositeMultiArgs), _VP]),
     "objnerf_generate_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, C.c_float, C.c_float, _VP, C.c_double, _VP, _VP]),
+    "objnerf_generate_rays_rows": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, C.c_float, C.c_float, _VP, C.c_double,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "objnerf_ray_directions": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, _VP]),
+    "objnerf_get_rays": (C.c_int, [_VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP]),
+    "objnerf_ray_box_near_far": (C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_double, _VP, _VP, _VP, _VP]),
     "objnerf_render_workspace_bytes": (C.c_int64, [C.POINTER(RenderCfg), C.c_int64]),
     "objnerf_render_rays": (C.c_int, [C.POINTER(RenderCfg), C.POINTER(RenderIn), C.POINTER(RenderOut), C.POINTER(RenderOut), _VP]),
     "objnerf_render_multi_workspace_bytes": (C.c_int64, [C.POINTER(RenderMultiCfg), C.c_int32, C.c_int64]),

@@ -71,3 +71,25 @@ def check_in_any_boxes(boxes, xyz, scale_factor=None, bbox_enlarge=0.0):
     _lib.check(_lib.lib().objnerf_points_in_boxes(_lib.ptr(pts), pts.shape[0], _lib.ptr(packed), packed.shape[0],
                                                   _lib.ptr(out), _lib.stream_ptr()), "points_in_boxes")
     return out.bool().view(*shp)
+
+
+@_lib.on_device_of(lambda box, rays_o, *a, **k: rays_o)
+def ray_bbox_intersections(box, rays_o, rays_d, scale_factor=None, bbox_enlarge=0):
+    """Drop-in for `BBoxRayHelper.get_ray_bbox_intersections` (utils/bbox_utils.py:132-156): (hit (n) bool, near (n,1),
+    far (n,1)) of rays against one oriented box, near/far already divided by scale_factor, 0/0 on a miss.  The reference
+    copies the rays to the host, runs a numba loop (datasets/geo_utils.py:111-162) and copies three arrays back, per object
+    per frame; here it is one kernel on the rays where they are (float64 slab test, the reference's miss rules)."""
+    _lib.require_cuda(rays_o, "rays_o")
+    _lib.require_cuda(rays_d, "rays_d")
+    o, d = _lib.as_f32(rays_o).reshape(-1, 3), _lib.as_f32(rays_d).reshape(-1, 3)
+    if o.shape != d.shape:
+        raise RuntimeError("ray_bbox_intersections: rays_o %s and rays_d %s differ" % (tuple(o.shape), tuple(d.shape)))
+    import ctypes as C
+    row = _box_row(box, scale_factor, 0.0)              # both bounds grow by bbox_enlarge in the kernel (bbox_utils.py:141-145)
+    box_h = (C.c_double * _lib.BOX_DOUBLES)(*row.tolist())
+    n = o.shape[0]
+    hit = torch.empty(n, dtype=torch.uint8, device=o.device)
+    near, far = torch.empty(n, 1, dtype=torch.float32, device=o.device), torch.empty(n, 1, dtype=torch.float32, device=o.device)
+    _lib.check(_lib.lib().objnerf_ray_box_near_far(_lib.ptr(o), _lib.ptr(d), n, box_h, float(bbox_enlarge), _lib.ptr(hit),
+                                                   _lib.ptr(near), _lib.ptr(far), _lib.stream_ptr()), "ray_box_near_far")
+    return hit.bool(), near, far

@@ -631,7 +631,61 @@ __global__ void points_in_boxes_kernel(const float* __restrict__ xyz, long n, co
   inside[idx] = in_any_box(xyz[idx * 3], xyz[idx * 3 + 1], xyz[idx * 3 + 2], boxes, n_boxes) ? 1 : 0;
 }
 
-// Ray generation for one ray set of the editor (datasets/ray_utils.py:5-51, editable_renderer.py:153-181).
+// Ray generation for the editor (datasets/ray_utils.py:5-51, editable_renderer.py:153-181), as three device functions so
+// that the one-kernel form (objnerf_generate_rays) and the stage-by-stage form the reference's caller is written
+// against (get_ray_directions / get_rays / BBoxRayHelper.get_ray_bbox_intersections) are the same arithmetic.
+// directions = [(i - W/2)/focal, -(j - H/2)/focal, -1]   (ray_utils.py:21-23; no +0.5)
+__device__ __forceinline__ void pixel_direction(int x, int y, int W, int H, float focal, float dir[3]) {
+  dir[0] = __fdiv_rn((float)x - (float)W / 2.f, focal);
+  dir[1] = -__fdiv_rn((float)y - (float)H / 2.f, focal);
+  dir[2] = -1.f;
+}
+// rays_d = directions @ c2w[:, :3].T, normalised (ray_utils.py:43-44); c2w row r at c2w + r * stride
+__device__ __forceinline__ void rotate_normalise(const float dir[3], const float* c2w, int stride, float d[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = dir[0] * c2w[r * stride + 0] + dir[1] * c2w[r * stride + 1] + dir[2] * c2w[r * stride + 2];
+  const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = __fdiv_rn(d[r], nrm);
+}
+// float64 transform to box coordinates (bbox_utils.py:100-117), slab test (geo_utils.py:126-162) with the reference's
+// rules: the direction is rotated by the box rotation only, zero components become 1e-14, an origin inside the box
+// (tmin < 0) is a miss; near/far = entry/exit / scale_factor in fp32, 0/0 on a miss
+__device__ __forceinline__ bool ray_box(const float o[3], const float d[3], const double* B, double enlarge, float& near, float& far) {
+  const double sx = (double)o[0] * B[0], sy = (double)o[1] * B[0], sz = (double)o[2] * B[0];
+  const double ax = B[1] * sx + B[2] * sy + B[3] * sz + B[10];
+  const double ay = B[4] * sx + B[5] * sy + B[6] * sz + B[11];
+  const double az = B[7] * sx + B[8] * sy + B[9] * sz + B[12];
+  double ob[3], db[3];
+  ob[0] = B[13] * ax + B[14] * ay + B[15] * az + B[22];
+  ob[1] = B[16] * ax + B[17] * ay + B[18] * az + B[23];
+  ob[2] = B[19] * ax + B[20] * ay + B[21] * az + B[24];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)      // direction: box rotation only (bbox_utils.py:115)
+    db[r] = B[13 + 3 * r] * (double)d[0] + B[14 + 3 * r] * (double)d[1] + B[15 + 3 * r] * (double)d[2];
+  const double e = enlarge > 0 ? enlarge : 0.0;
+  double tmin = 0, tmax = 0;
+  bool hit = true;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double dd = db[r] == 0.0 ? 1.0e-14 : db[r];
+    const double inv = 1.0 / dd;
+    const double lo = B[25 + r] - e, hi = B[28 + r] + e;
+    const double t0 = ((inv < 0 ? hi : lo) - ob[r]) * inv;
+    const double t1 = ((inv < 0 ? lo : hi) - ob[r]) * inv;
+    if (r == 0) { tmin = t0; tmax = t1; }
+    else {
+      if (tmin > t1 || t0 > tmax) hit = false;
+      if (t0 > tmin) tmin = t0;
+      if (t1 < tmax) tmax = t1;
+    }
+  }
+  if (tmin < 0 || tmax < 0) hit = false;       // origin inside the box counts as a miss
+  near = hit ? __fdiv_rn((float)tmin, (float)B[0]) : 0.f;
+  far = hit ? __fdiv_rn((float)tmax, (float)B[0]) : 0.f;
+  return hit;
+}
+
 struct GenRaysArgs {
   int H, W;
   float focal;
@@ -640,61 +694,55 @@ struct GenRaysArgs {
   int has_box;
   double box[OBJNERF_BOX_DOUBLES];
   double enlarge;
+  // which image rows this call writes: local row lr -> image row row0 + (lr / row_block) * row_block * block_stride +
+  // lr % row_block (contiguous band: row_block = n_rows, block_stride = 1; block-cyclic share of rank r of w:
+  // row0 = r * row_block, block_stride = w)
+  int row0, n_rows, row_block, block_stride;
 };
 __global__ void generate_rays_kernel(const GenRaysArgs a, float* __restrict__ rays) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)a.H * a.W) return;
-  const int y = (int)(idx / a.W), x = (int)(idx - (long)y * a.W);
-  // directions = [(i - W/2)/focal, -(j - H/2)/focal, -1]   (ray_utils.py:21-23; no +0.5)
-  const float dx = __fdiv_rn((float)x - (float)a.W / 2.f, a.focal);
-  const float dy = -__fdiv_rn((float)y - (float)a.H / 2.f, a.focal);
-  const float dz = -1.f;
-  // rays_d = directions @ c2w[:, :3].T, normalised (ray_utils.py:43-44)
-  float d[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) d[r] = dx * a.c2w[r * 4 + 0] + dy * a.c2w[r * 4 + 1] + dz * a.c2w[r * 4 + 2];
-  const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) d[r] = __fdiv_rn(d[r], nrm);
+  if (idx >= (long)a.n_rows * a.W) return;
+  const int lr = (int)(idx / a.W), x = (int)(idx - (long)lr * a.W);
+  const int y = a.row0 + (lr / a.row_block) * a.row_block * a.block_stride + lr % a.row_block;
+  float dir[3], d[3];
+  pixel_direction(x, y, a.W, a.H, a.focal, dir);
+  rotate_normalise(dir, a.c2w, 4, d);
   const float o[3] = {a.c2w[3], a.c2w[7], a.c2w[11]};
   float near = a.near, far = a.far;
-  if (a.has_box) {
-    // float64 transform to box coordinates (bbox_utils.py:100-117), slab test (geo_utils.py:126-162)
-    const double* B = a.box;
-    const double sx = (double)o[0] * B[0], sy = (double)o[1] * B[0], sz = (double)o[2] * B[0];
-    const double ax = B[1] * sx + B[2] * sy + B[3] * sz + B[10];
-    const double ay = B[4] * sx + B[5] * sy + B[6] * sz + B[11];
-    const double az = B[7] * sx + B[8] * sy + B[9] * sz + B[12];
-    double ob[3], db[3];
-    ob[0] = B[13] * ax + B[14] * ay + B[15] * az + B[22];
-    ob[1] = B[16] * ax + B[17] * ay + B[18] * az + B[23];
-    ob[2] = B[19] * ax + B[20] * ay + B[21] * az + B[24];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)      // direction: box rotation only (bbox_utils.py:115)
-      db[r] = B[13 + 3 * r] * (double)d[0] + B[14 + 3 * r] * (double)d[1] + B[15 + 3 * r] * (double)d[2];
-    const double e = a.enlarge > 0 ? a.enlarge : 0.0;
-    double tmin = 0, tmax = 0;
-    bool hit = true;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const double dd = db[r] == 0.0 ? 1.0e-14 : db[r];
-      const double inv = 1.0 / dd;
-      const double lo = B[25 + r] - e, hi = B[28 + r] + e;
-      const double t0 = ((inv < 0 ? hi : lo) - ob[r]) * inv;
-      const double t1 = ((inv < 0 ? lo : hi) - ob[r]) * inv;
-      if (r == 0) { tmin = t0; tmax = t1; }
-      else {
-        if (tmin > t1 || t0 > tmax) hit = false;
-        if (t0 > tmin) tmin = t0;
-        if (t1 < tmax) tmax = t1;
-      }
-    }
-    if (tmin < 0 || tmax < 0) hit = false;       // origin inside the box counts as a miss
-    near = hit ? __fdiv_rn((float)tmin, (float)B[0]) : 0.f;
-    far = hit ? __fdiv_rn((float)tmax, (float)B[0]) : 0.f;
-  }
+  if (a.has_box) ray_box(o, d, a.box, a.enlarge, near, far);
   float* r = rays + idx * 8;
   r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = d[0]; r[4] = d[1]; r[5] = d[2]; r[6] = near; r[7] = far;
+}
+
+// the stage-by-stage form (dropin/datasets/ray_utils.py, dropin/utils/bbox_utils.py)
+__global__ void ray_directions_kernel(int H, int W, float focal, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)H * W) return;
+  const int y = (int)(idx / W), x = (int)(idx - (long)y * W);
+  float dir[3];
+  pixel_direction(x, y, W, H, focal, dir);
+  out[idx * 3] = dir[0]; out[idx * 3 + 1] = dir[1]; out[idx * 3 + 2] = dir[2];
+}
+__global__ void get_rays_kernel(const float* __restrict__ directions, long n, const float* __restrict__ c2w, int stride,
+                                float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float dir[3] = {directions[idx * 3], directions[idx * 3 + 1], directions[idx * 3 + 2]};
+  float d[3];
+  rotate_normalise(dir, c2w, stride, d);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { rays_d[idx * 3 + r] = d[r]; rays_o[idx * 3 + r] = c2w[r * stride + 3]; }
+}
+struct BoxArg { double box[OBJNERF_BOX_DOUBLES]; double enlarge; };
+__global__ void ray_box_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, long n, const BoxArg b,
+                               uint8_t* __restrict__ hit, float* __restrict__ near, float* __restrict__ far) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float o[3] = {rays_o[idx * 3], rays_o[idx * 3 + 1], rays_o[idx * 3 + 2]};
+  const float d[3] = {rays_d[idx * 3], rays_d[idx * 3 + 1], rays_d[idx * 3 + 2]};
+  float nr, fr;
+  const bool h = ray_box(o, d, b.box, b.enlarge, nr, fr);
+  hit[idx] = h ? 1 : 0; near[idx] = nr; far[idx] = fr;
 }
 
 // volume_rendering_multi (multi_rendering.py:96-157): joint stable sort by z of K*S samples,
@@ -948,17 +996,60 @@ int objnerf_points_in_boxes(const float* xyz, int64_t n, const double* boxes, in
   return check_launch("points_in_boxes");
 }
 
-int objnerf_generate_rays(int H, int W, float focal, const float* h_c2w, float near, float far, const double* h_box,
-                          double bbox_enlarge, float* rays, void* stream) {
-  if (H < 1 || W < 1 || !(focal > 0.f) || !h_c2w || !rays) return set_error(-1, "generate_rays: bad arguments");
+int objnerf_generate_rays_rows(int H, int W, float focal, const float* h_c2w, float near, float far, const double* h_box,
+                               double bbox_enlarge, int row0, int n_rows, int row_block, int block_stride, float* rays,
+                               void* stream) {
+  if (H < 1 || W < 1 || !(focal > 0.f) || !h_c2w) return set_error(-1, "generate_rays: bad arguments");
+  if (n_rows < 0 || row0 < 0 || row_block < 1 || block_stride < 1) return set_error(-1, "generate_rays: bad row range");
+  if (n_rows == 0) return 0;
+  if (!rays) return set_error(-1, "generate_rays: null output");
+  const int last = n_rows - 1;
+  if (row0 + (last / row_block) * (long)row_block * block_stride + last % row_block >= H)
+    return set_error(-1, "generate_rays: row range leaves the image");
   GenRaysArgs a;
   a.H = H; a.W = W; a.focal = focal; a.near = near; a.far = far;
   for (int i = 0; i < 12; ++i) a.c2w[i] = h_c2w[i];
   a.has_box = h_box != nullptr;
   for (int i = 0; i < OBJNERF_BOX_DOUBLES; ++i) a.box[i] = h_box ? h_box[i] : 0.0;
   a.enlarge = bbox_enlarge;
-  hipLaunchKernelGGL(generate_rays_kernel, dim3(blocks_for((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, a, rays);
+  a.row0 = row0; a.n_rows = n_rows; a.row_block = row_block; a.block_stride = block_stride;
+  hipLaunchKernelGGL(generate_rays_kernel, dim3(blocks_for((long)n_rows * W, 256)), dim3(256), 0, (hipStream_t)stream, a, rays);
   return check_launch("generate_rays");
+}
+
+int objnerf_generate_rays(int H, int W, float focal, const float* h_c2w, float near, float far, const double* h_box,
+                          double bbox_enlarge, float* rays, void* stream) {
+  if (H < 1) return set_error(-1, "generate_rays: bad arguments");
+  return objnerf_generate_rays_rows(H, W, focal, h_c2w, near, far, h_box, bbox_enlarge, 0, H, H, 1, rays, stream);
+}
+
+int objnerf_ray_directions(int H, int W, float focal, float* directions, void* stream) {
+  if (H < 1 || W < 1 || !(focal > 0.f) || !directions) return set_error(-1, "ray_directions: bad arguments");
+  hipLaunchKernelGGL(ray_directions_kernel, dim3(blocks_for((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, H, W, focal, directions);
+  return check_launch("ray_directions");
+}
+
+int objnerf_get_rays(const float* directions, int64_t n, const float* c2w, int row_stride, float* rays_o, float* rays_d,
+                     void* stream) {
+  if (n < 0 || row_stride < 4) return set_error(-1, "get_rays: bad arguments");
+  if (n == 0) return 0;
+  if (!directions || !c2w || !rays_o || !rays_d) return set_error(-1, "get_rays: null pointer");
+  hipLaunchKernelGGL(get_rays_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, directions, (long)n, c2w,
+                     row_stride, rays_o, rays_d);
+  return check_launch("get_rays");
+}
+
+int objnerf_ray_box_near_far(const float* rays_o, const float* rays_d, int64_t n, const double* h_box, double bbox_enlarge,
+                             uint8_t* hit, float* near, float* far, void* stream) {
+  if (n < 0 || !h_box) return set_error(-1, "ray_box_near_far: bad arguments");
+  if (n == 0) return 0;
+  if (!rays_o || !rays_d || !hit || !near || !far) return set_error(-1, "ray_box_near_far: null pointer");
+  BoxArg b;
+  for (int i = 0; i < OBJNERF_BOX_DOUBLES; ++i) b.box[i] = h_box[i];
+  b.enlarge = bbox_enlarge;
+  hipLaunchKernelGGL(ray_box_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, (long)n, b,
+                     hit, near, far);
+  return check_launch("ray_box_near_far");
 }
 
 int objnerf_composite_multi(const objnerf_composite_multi_args* a, void* stream) {

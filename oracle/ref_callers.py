@@ -223,6 +223,31 @@ class Recorder:
                                        skip_boxes=box_dicts, chunk=kw["chunk"])
 
 
+    # ---- row f2: the device ray generation the shims `dropin/datasets/ray_utils.py`, `dropin/utils/bbox_utils.py` route to ----
+    def get_rays(self, directions, c2w):
+        from oracle import objnerf_oracle as O
+        inspect.signature(self.product["get_rays"]).bind(directions, c2w)
+        rays_o, rays_d = O.get_rays(directions, c2w)
+        self.calls.append((self.scenario, "get_rays", {}, dict(directions=directions.detach().clone(), c2w=c2w.detach().clone(),
+                                                                 out_rays_o=rays_o.clone(), out_rays_d=rays_d.clone())))
+        return rays_o, rays_d
+
+    def ray_bbox_intersections(self, box, rays_o, rays_d, scale_factor=None, bbox_enlarge=0):
+        from object_nerf_amd import bbox
+        from oracle import objnerf_oracle as O
+        import helpers as H
+        inspect.signature(self.product["ray_bbox_intersections"]).bind(box, rays_o, rays_d, scale_factor, bbox_enlarge)
+        bd = H.box_dict_from_helper(box)
+        if scale_factor is not None:
+            bd["scale_factor"] = float(scale_factor)
+        hit, near, far = O.ray_box_near_far(rays_o, rays_d, bd, bbox_enlarge)
+        row = torch.from_numpy(bbox._box_row(box, scale_factor, 0.0))     # what the product hands to the kernel
+        self.calls.append((self.scenario, "ray_bbox_intersections", dict(bbox_enlarge=float(bbox_enlarge)),
+                           dict(rays_o=rays_o.detach().clone(), rays_d=rays_d.detach().clone(), box=row,
+                                out_hit=hit.clone(), out_near=near.clone(), out_far=far.clone())))
+        return hit, near, far
+
+
 def save_calls(path, calls):
     arrs, meta = {}, []
     for i, (scn, fn, scal, tens) in enumerate(calls):
@@ -248,6 +273,26 @@ def run_scenarios(flavour, work, rec):
     if rec is not None:
         T.render_rays = lambda **kw: rec.render_rays(**kw)
         ER.render_rays_multi = lambda **kw: rec.render_rays_multi(**kw)
+        # row f2: the editor's ray generation binds to the device shims (editable_renderer.py:18,21 unchanged) ...
+        import datasets.ray_utils as DRU
+        import utils.bbox_utils as DBU
+        import datasets.geo_utils as GEO
+        from object_nerf_amd import bbox as hip_bbox, ray_utils as hip_rays
+        assert DRU.__file__.startswith(os.path.join(ROOT, "dropin")) and DBU.__file__.startswith(os.path.join(ROOT, "dropin"))
+        assert ER.get_rays is DRU.get_rays and ER.BBoxRayHelper is DBU.BBoxRayHelper
+        assert issubclass(DBU.BBoxRayHelper, sys.modules["utils._reference_bbox_utils"].BBoxRayHelper)
+        # ... "tensor is on the GPU" is always true for the stand-in device (as Tensor.cuda() is the identity here) ...
+        DRU._on_device = DBU._on_device = lambda t: True
+        # ... the product functions the shims call are the recording stand-in ...
+        rec.product = dict(get_rays=hip_rays.get_rays, ray_bbox_intersections=hip_bbox.ray_bbox_intersections)
+        hip_rays.get_rays = rec.get_rays
+        hip_bbox.ray_bbox_intersections = rec.ray_bbox_intersections
+
+        # ... and the host slab test must never run: datasets/geo_utils.py:111-162 raises from here on
+        def _host_slab_test(*a, **k):
+            raise AssertionError("datasets/geo_utils.py::bbox_intersection[_batch] was called on the drop-in path")
+        GEO.bbox_intersection_batch = GEO.bbox_intersection = _host_slab_test
+        sys.modules["utils._reference_bbox_utils"].bbox_intersection_batch = _host_slab_test
     cfg = make_config(work)
     out = OrderedDict()
 
@@ -428,6 +473,12 @@ def main():
         sys.path.insert(0, REF)
         sys.path.insert(0, os.path.join(ROOT, "dropin"))
     install_caller_stubs()
+    if flavour == "dropin":
+        # the REAL dropin/datasets/__init__.py runs (package-path extension + the reference's own datasets/__init__.py
+        # with its cv2 / torchvision imports stubbed above) instead of the stub package of the reference flavours
+        del sys.modules["datasets"]
+        import datasets
+        assert datasets.__file__.startswith(os.path.join(ROOT, "dropin")) and "scannet_base" in datasets.dataset_dict
     if flavour == "checkpoint":
         write_checkpoint_fixture(work)
     elif flavour == "reference":

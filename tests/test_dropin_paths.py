@@ -26,6 +26,43 @@ if os.path.isdir(ref):
     import models.losses                       # still the reference's file
     assert models.losses.__file__.startswith(ref)
     assert importlib.util.find_spec('render_tools.editable_renderer').origin.startswith(ref)
+    # ---- row f2: datasets.ray_utils / utils.bbox_utils shims (the reference's un-installed imports stubbed) ----
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    from oracle import ref_callers
+    ref_callers.install_caller_stubs()
+    del sys.modules['datasets']                  # the stub package of the harness: import the real shim package instead
+    import numpy as np, torch
+    import datasets, utils
+    import datasets.ray_utils as RU, datasets.geo_utils as GEO, utils.bbox_utils as BU, utils.util
+    drop = os.path.join(root, 'dropin')
+    assert datasets.__file__.startswith(drop) and utils.__file__.startswith(drop)
+    assert RU.__file__.startswith(drop) and BU.__file__.startswith(drop)
+    assert GEO.__file__.startswith(ref) and utils.util.__file__.startswith(ref)          # everything else: the reference's
+    assert 'scannet_base' in datasets.dataset_dict and callable(utils.get_parameters) and callable(utils.get_optimizer)
+    REFBU = sys.modules['utils._reference_bbox_utils']
+    assert REFBU.__file__.startswith(ref) and issubclass(BU.BBoxRayHelper, REFBU.BBoxRayHelper)
+    import render_tools.editable_renderer as ER
+    assert ER.get_rays is RU.get_rays and ER.BBoxRayHelper is BU.BBoxRayHelper
+    # CPU tensors (the dataset's DataLoader workers, generic_dataset.py:144,397) take the reference's own code
+    d = RU.get_ray_directions(6, 8, 7.0)
+    c2w = torch.tensor([[0.8, -0.6, 0.0, 0.1], [0.6, 0.8, 0.0, 0.2], [0.0, 0.0, 1.0, 0.3]])
+    REFRU = sys.modules['datasets._reference_ray_utils']
+    for a, b in zip(RU.get_rays(d, c2w), REFRU.get_rays(REFRU.get_ray_directions(6, 8, 7.0), c2w)):
+        assert torch.equal(a, b)
+    from object_nerf_amd import synth
+    h = ref_callers._box_helper(synth.oriented_box([2.9, 3.1, 0.5], [1.0, 0.8, 1.0], 20.0, [2.0, 2.0, 0.0], 2.0))
+    assert type(h) is BU.BBoxRayHelper
+    o, dd = RU.get_rays(d, c2w)
+    mask, near, far = h.get_ray_bbox_intersections(o, dd, 2.0, bbox_enlarge=0.06)       # CPU rays: the reference's numba path
+    assert mask.shape == (48,) and near.shape == (48, 1)
+    # GPU tensors would go to the HIP library: with no GPU here the product raises instead of computing on the CPU
+    RU._on_device = BU._on_device = lambda t: True
+    for fn in (lambda: RU.get_rays(d, c2w), lambda: h.get_ray_bbox_intersections(o, dd, 2.0), lambda: h.check_xyz_in_bounds(o)):
+        try:
+            fn()
+            raise SystemExit('a CPU tensor was computed on the device path')
+        except RuntimeError as e:
+            assert 'GPU' in str(e), e
 print('ok')
 """
 

@@ -166,3 +166,86 @@ def test_editable_renderer_chunk_loops(scene, gold, scenario, prefix, n_sets):
                                             background_skip_bbox=boxes if boxes else None, **kw))
     out = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}          # editable_renderer.py:289-292 / 143-150
     grade(out, gold, prefix)
+
+
+@pytest.mark.single_mode
+def test_editor_ray_generation_on_the_device(gold):
+    """Row f2 through the reference's unchanged caller: in the build container EditableRenderer.render_edit /
+    render_origin ran over dropin/datasets/ray_utils.py and dropin/utils/bbox_utils.py (the host slab test of
+    datasets/geo_utils.py blocked), and the calls those shims made to the product -- `get_rays` per ray set,
+    `ray_bbox_intersections` per object -- were recorded next to what the reference's own code returns for them.  Here
+    the recorded calls run on the GPU: origins equal, directions and near / far within 2e-6, hit masks identical; and the
+    ray sets the editor then assembled from them (editable_renderer.py:153-181) reproduce the recorded render inputs."""
+    from object_nerf_amd import bbox, ray_utils
+    calls = load_calls()
+    n_gr = n_rb = 0
+    sets = {"render_edit": [], "render_origin": []}          # per scenario: [rays_o, rays_d, box result or None] per ray set
+    for c in calls:
+        t = c["tens"]
+        if c["fn"] == "get_rays":
+            o, d = ray_utils.get_rays(t["directions"].to(DEV), t["c2w"].to(DEV))
+            assert o.shape == t["out_rays_o"].shape and torch.equal(o.cpu(), t["out_rays_o"])
+            assert H.normwise(d, t["out_rays_d"]) < 2e-6
+            sets[c["scenario"]].append([o, d, None])
+            n_gr += 1
+        elif c["fn"] == "ray_bbox_intersections":
+            hit, near, far = bbox.ray_bbox_intersections(box_from_row(t["box"]), t["rays_o"].to(DEV), t["rays_d"].to(DEV),
+                                                         None, c["scalars"]["bbox_enlarge"])
+            assert hit.dtype == torch.bool and torch.equal(hit.cpu(), t["out_hit"])
+            assert near.shape == t["out_near"].shape and H.normwise(near, t["out_near"]) < 2e-6 and H.normwise(far, t["out_far"]) < 2e-6
+            assert 0 < int(hit.sum()) < hit.numel()
+            cur = sets[c["scenario"]][-1]
+            assert torch.equal(t["rays_o"], cur[0].cpu())      # the call was made with the rays of the preceding get_rays
+            cur[2] = (hit, near, far)
+            n_rb += 1
+    assert n_gr == 4 and n_rb == 2              # three ray sets of the edit + one of render_origin; two object sets
+    # editable_renderer.py:153-181 on the device results -> the (N, 8) ray sets of the recorded render_rays_multi calls
+    multi = [c for c in calls if c["scenario"] == "render_edit" and c["fn"] == "render_rays_multi"]
+    assert [r[2] is None for r in sets["render_edit"]] == [True, False, False] and len(sets["render_origin"]) == 1
+    for k, (o, d, box_res) in enumerate(sets["render_edit"]):
+        want = torch.cat([c["tens"]["rays_%d" % k] for c in multi], 0)
+        if box_res is None:
+            got = torch.cat([o, d, want[:, 6:8].to(DEV)], 1)
+        else:
+            hit, near, far = box_res
+            near, far = near.clone(), far.clone()
+            near[~hit] = 0
+            far[~hit] = 0
+            got = torch.cat([o, d, near, far], 1)
+        assert torch.equal((got[:, 7] > 0).cpu(), want[:, 7] > 0) and H.normwise(got, want) < 2e-6
+
+
+@pytest.mark.single_mode
+def test_stagewise_ray_generation_equals_the_fused_kernel():
+    """640x480: get_ray_directions + get_rays + ray_bbox_intersections (the stages the reference's caller issues) are
+    bit-equal to the one-kernel objnerf_generate_rays (same device functions), and the row-subset form writes exactly the
+    rows of the full frame -- contiguous band and block-cyclic share."""
+    from object_nerf_amd import bbox, ray_utils, synth
+    focal, poses, box = cases.bench_multi_geometry()
+    w, h = cases.BENCH_MULTI["frame"]
+    pre = synth.SCANNET_LIKE
+    e = cases.BENCH_MULTI["bbox_enlarge"]
+    dirs = ray_utils.get_ray_directions(h, w, focal)
+    assert dirs.shape == (h, w, 3)
+    for k, Toc in enumerate(poses):
+        full = ray_utils.generate_rays(h, w, focal, Toc, pre["near"], pre["far"], box=None if k == 0 else box, bbox_enlarge=e)
+        o, d = ray_utils.get_rays(dirs, torch.from_numpy(Toc).float().to(DEV))
+        if k == 0:
+            staged = torch.cat([o, d, torch.full_like(o[:, :1], pre["near"]), torch.full_like(o[:, :1], pre["far"])], 1)
+        else:
+            hit, near, far = bbox.ray_bbox_intersections(box, o, d, None, e)
+            assert torch.equal(hit, far[:, 0] > 0)
+            staged = torch.cat([o, d, near, far], 1)
+        assert torch.equal(staged, full)
+        img = full.view(h, w, 8)
+        for world in (3, 8):
+            for rank in range(world):
+                lo, n, rb, bs = ray_utils.row_share(h, rank, world)
+                band = ray_utils.generate_rays(h, w, focal, Toc, pre["near"], pre["far"], box=None if k == 0 else box,
+                                               bbox_enlarge=e, rows=(lo, n, rb, bs))
+                assert torch.equal(band, img[lo:lo + n].reshape(-1, 8))
+                share = ray_utils.row_share(h, rank, world, row_block=8)
+                cyc = ray_utils.generate_rays(h, w, focal, Toc, pre["near"], pre["far"], box=None if k == 0 else box,
+                                              bbox_enlarge=e, rows=share)
+                rows = torch.cat([torch.arange(b * 8, min(b * 8 + 8, h)) for b in range(rank, (h + 7) // 8, world)])
+                assert torch.equal(cyc, img[rows.to(DEV)].reshape(-1, 8))
