@@ -70,11 +70,20 @@ def parse(argv=None):
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--max-voxels", type=int, default=800_000, help="rows of the voxel feature table (config default 800000)")
-    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=4096,
+                    help="rays in the CPU baseline sample (BASELINE.md §3: a 4096-ray slab, one warm-up + 3 timed repetitions, "
+                         "median; 0 = skip)")
     ap.add_argument("--split-bf16-steps", type=int, default=2,
                     help="extra, separately reported frames in the opt-in split-bf16 arithmetic mode (0 = skip)")
     ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
                     help="collect roofline.traffic with two rocprofv3 --pmc passes of this workload (auto: N = 1 and rocprofv3 on PATH)")
+    ap.add_argument("--shard", choices=["auto", "contiguous", "cyclic"], default="auto",
+                    help="strong scaling: how a frame's image rows are dealt to the ranks (auto: contiguous bands for "
+                         "configs[3], whose rays all cost the same; 4-row blocks round-robin for configs[4], whose culled "
+                         "object ray sets make the cost per pixel non-uniform)")
+    ap.add_argument("--row-block", type=int, default=4, help="image rows per block of the cyclic split")
+    ap.add_argument("--as-rank", type=int, nargs=2, metavar=("RANK", "WORLD"), default=None,
+                    help="single process: render only the share that rank RANK of WORLD would render (tools/band_replay.py)")
     ap.add_argument("--dist", action="store_true", help="initialise the RCCL process group even at N = 1")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -150,8 +159,8 @@ class HipRenderer:
         with torch.no_grad():
             return self._multi(sc.models, sc.embeddings, sc.code_library, rays_list, obj_instance_ids, **kw)
 
-    def generate_rays(self, H, W, focal, c2w, near=0.0, far=0.0, box=None, bbox_enlarge=0.0):
-        return self._gen(H, W, focal, c2w, near, far, box=box, bbox_enlarge=bbox_enlarge, device=self.device)
+    def generate_rays(self, H, W, focal, c2w, near=0.0, far=0.0, box=None, bbox_enlarge=0.0, rows=None):
+        return self._gen(H, W, focal, c2w, near, far, box=box, bbox_enlarge=bbox_enlarge, device=self.device, rows=rows)
 
     def sync(self):
         torch.cuda.synchronize()
@@ -176,25 +185,36 @@ class Workload:
     """One BASELINE config bound to a renderer, a rank and a scaling mode.  step() renders this rank's share of one step
     and all-gathers the pixels; everything it reads is resident on the device beforehand."""
 
-    def __init__(self, cfg_id, args, R, rank, world, scaling, dist):
+    def __init__(self, cfg_id, args, R, rank, world, scaling, dist, as_rank=False, scene=None):
         import object_nerf_amd as A
         from object_nerf_amd import synth
-        from object_nerf_amd.distributed import shard_bounds
         self.cfg_id, self.R, self.rank, self.world, self.scaling, self.dist = cfg_id, R, rank, world, scaling, dist
+        self.as_rank = (rank, world) if as_rank else None      # single-process replay of one rank's share (--as-rank)
         self.W, self.H = args.width, args.height
         dev = R.device
         self.S = 64
         self.I = {0: 0, 1: 64, 2: 128, 3: 128, 4: 64}[cfg_id]
         self.preset = synth.TOYDESK2 if cfg_id in (0, 1) else synth.SCANNET_LIKE
-        self.sc = synth.build_scene(A, use_voxel=True, preset=self.preset, max_voxels=args.max_voxels, device=dev,
-                                    n_importance=max(self.I, 1))
+        self.sc = scene if scene is not None else synth.build_scene(A, use_voxel=True, preset=self.preset,
+                                                                    max_voxels=args.max_voxels, device=dev, n_importance=max(self.I, 1))
         self.typ = "fine" if self.I > 0 else "coarse"
         self.gather_keys = tuple("%s_%s" % (k, self.typ) for k in ("rgb", "depth", "opacity"))
         n = self.W * self.H
         self.n_pixels = n                                   # per frame
-        # strong: one frame, this rank's band; weak: this rank's own frame (camera rotated per rank)
-        self.frames_per_step = 1 if (scaling == "strong" or world == 1) else world
-        self.lo, self.hi = shard_bounds(n, rank, world) if scaling == "strong" else (0, n)
+        # strong: one frame, this rank's share; weak: this rank's own frame (camera rotated per rank)
+        self.frames_per_step = 1 if (scaling == "strong" or world == 1 or as_rank) else world
+        # strong scaling deals whole image rows: contiguous bands (configs[3]) or row blocks round-robin (configs[4])
+        from object_nerf_amd.distributed import RayShards
+        from object_nerf_amd.ray_utils import row_share
+        mode = args.shard if args.shard != "auto" else ("cyclic" if cfg_id == 4 else "contiguous")
+        self.row_block = args.row_block if (mode == "cyclic" and scaling == "strong") else None
+        if scaling == "strong":
+            self.shards = RayShards.rows(self.H, self.W, world, self.row_block)
+            self.rows = row_share(self.H, rank, world, self.row_block)
+            self.n_local = self.shards.counts[rank]
+        else:
+            self.shards, self.rows, self.n_local = None, None, n
+        self.shard_mode = mode if scaling == "strong" else "whole frame per rank"
         yaw = 0.0 if scaling == "strong" else 20.0 * rank
         self.marks = []                                     # (t_start, t_rendered, t_gathered) per step
         if cfg_id == 4:
@@ -208,7 +228,7 @@ class Workload:
             self.rank_rays = [float(h) for h in hit.tolist()]
             self.evals_rank = sum(self.rank_rays) * (self.S + self.S + self.I)
             self.flop_rank = (self.rank_rays[0] * FLOP_SCENE + sum(self.rank_rays[1:]) * FLOP_OBJECT) * (self.S + self.S + self.I)
-            self.nominal_evals_rank = 3.0 * (self.hi - self.lo) * (self.S + self.S + self.I)
+            self.nominal_evals_rank = 3.0 * self.n_local * (self.S + self.S + self.I)
             self.flop_per_eval = None
             self.kernel = "objnerf::mlp_kernel<voxel,fused> scene-only (background set) and object-only (object sets) variants"
         else:
@@ -220,7 +240,7 @@ class Workload:
                 else:
                     ids = torch.full((n,), 1, dtype=torch.long)                   # val_instance_id (toy_desk_2.yml:39)
                 codes = self.sc.code_library({"instance_ids": ids.to(dev)})["embedding_instance"]
-            # strong scaling keeps the whole frame on every rank (88 MB) and lets render_rays_sharded cut the band;
+            # strong scaling keeps the whole frame on every rank (88 MB) and lets render_rays_sharded cut this rank's share;
             # weak scaling renders the rank's own whole frame
             self.rays = rays.to(dev).contiguous()
             self.codes = codes.contiguous()
@@ -230,18 +250,20 @@ class Workload:
             if cfg_id in (2, 3):
                 self.kw["rays_in_bbox"] = True
             self.flop_per_eval = FLOP_BOTH if fi else FLOP_SCENE
-            self.evals_rank = float(self.hi - self.lo) * (self.S + (self.S + self.I if self.I > 0 else 0))
+            self.evals_rank = float(self.n_local) * (self.S + (self.S + self.I if self.I > 0 else 0))
             self.nominal_evals_rank = self.evals_rank
             self.flop_rank = self.evals_rank * self.flop_per_eval
             self.kernel = "objnerf::mlp_kernel<voxel,fused,%s>" % ("scene,object" if fi else "scene")
         self.evals_per_ray = self.S + (self.S + self.I if self.I > 0 else 0)
         self.last = None
 
-    def _ray_sets(self, band=True):
-        sets = [self.R.generate_rays(self.H, self.W, self.focal, self.poses[0], self.preset["near"], self.preset["far"])]
+    def _ray_sets(self):
+        """this rank's rows of the K ray sets, written on the device by objnerf_generate_rays_rows (strong scaling: only
+        the rank's own share of the image rows -- nobody generates the whole frame and slices it)"""
+        sets = [self.R.generate_rays(self.H, self.W, self.focal, self.poses[0], self.preset["near"], self.preset["far"], rows=self.rows)]
         for p in self.poses[1:]:
-            sets.append(self.R.generate_rays(self.H, self.W, self.focal, p, box=self.box, bbox_enlarge=0.06))
-        return [s[self.lo:self.hi] for s in sets] if band else sets      # contiguous pixel band of every set
+            sets.append(self.R.generate_rays(self.H, self.W, self.focal, p, box=self.box, bbox_enlarge=0.06, rows=self.rows))
+        return sets
 
     def _mark(self):
         if self.R.device.type == "cuda":
@@ -264,11 +286,12 @@ class Workload:
             if self.kind == "multi":
                 out = render_rays_multi_sharded(
                     lambda rays_list, **kw: self.R.render_rays_multi(self.sc, rays_list, self.obj_ids, **kw),
-                    self._ray_sets(band=False), gather_keys=self.gather_keys, on_rendered=rendered, **self.kw)
+                    self._ray_sets(), gather_keys=self.gather_keys, on_rendered=rendered, shards=self.shards,
+                    rays_are_local=True, as_rank=self.as_rank, **self.kw)
             else:
                 out = render_rays_sharded(lambda rays, **kw: self.R.render_rays(self.sc, rays, **kw), self.rays,
                                           {"embedding_instance": self.codes}, gather_keys=self.gather_keys,
-                                          on_rendered=rendered, **self.kw)
+                                          on_rendered=rendered, shards=self.shards, as_rank=self.as_rank, **self.kw)
         else:
             if self.kind == "multi":
                 res = self.R.render_rays_multi(self.sc, self._ray_sets(), self.obj_ids, **self.kw)
@@ -302,6 +325,8 @@ def run(args, renderer=None, backend="nccl", argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.as_rank is not None and (world != 1 or not 0 <= args.as_rank[0] < args.as_rank[1]):
+        raise SystemExit("bench.py --as-rank RANK WORLD is a single-process replay (0 <= RANK < WORLD, --gpus 1)")
     if renderer is None:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -322,7 +347,13 @@ def run(args, renderer=None, backend="nccl", argv=None):
 
     cfg_id = args.config if args.config is not None else (1 if world == 1 else 3)
     scaling = args.scaling or ("strong" if (cfg_id in (3, 4) or world == 1) else "weak")
-    wl = Workload(cfg_id, args, R, rank, world, scaling, dist)
+    # what the JSON line says: configs 3 / 4 are the sharded-frame (strong-scaling) modes at any N; a plain N = 1 run of
+    # the other configs is the one-frame-per-rank series, i.e. "weak"
+    scaling_label = scaling if (world > 1 or cfg_id in (3, 4)) else "weak"
+    if args.as_rank is not None:
+        wl = Workload(cfg_id, args, R, args.as_rank[0], args.as_rank[1], "strong", None, as_rank=True)
+    else:
+        wl = Workload(cfg_id, args, R, rank, world, scaling, dist)
     lib = None
     if on_gpu:
         from object_nerf_amd import _lib
@@ -334,7 +365,8 @@ def run(args, renderer=None, backend="nccl", argv=None):
             dist.barrier()
         R.sync()
 
-    log("config %d (%s scaling), %d pixels/frame, rays [%d, %d) on rank 0, world %d" % (cfg_id, scaling, wl.n_pixels, wl.lo, wl.hi, world))
+    log("config %d (scaling: %s), %d pixels/frame, %d rays on rank %d (%s), world %d" % (
+        cfg_id, scaling_label, wl.n_pixels, wl.n_local, wl.rank, wl.shard_mode, wl.world))
     for _ in range(args.warmup):
         wl.step()
     fence()
@@ -387,7 +419,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
         fence()
         tg = time.perf_counter()
         for _ in range(10):
-            gather_pixel_maps(local, n_total)
+            gather_pixel_maps(local, n_total, wl.shards)
         R.sync()
         gather_alone_ms = allreduce((time.perf_counter() - tg) / 10 * 1e3, "MAX")
 
@@ -404,14 +436,13 @@ def run(args, renderer=None, backend="nccl", argv=None):
                       "ray-samples/sec (MLP-evaluated sample points)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            # configs 3 / 4 are the sharded-frame (strong-scaling) modes at any N
-            "scaling": scaling if (world > 1 or cfg_id in (3, 4)) else "weak",
+            "scaling": scaling_label,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": CONFIG_TEXT[cfg_id] % ((args.width, args.height, wl.S) + ((wl.I,) if cfg_id != 0 else ()))
                             + "; W1 random-init weights, %dx24 voxel table" % args.max_voxels,
                 "baseline_config_index": cfg_id, "pixels_per_frame": wl.n_pixels, "frames_per_step": wl.frames_per_step,
-                "rays_per_step_rank0": wl.hi - wl.lo, "evals_per_ray": wl.evals_per_ray,
+                "rays_per_step_rank0": wl.n_local, "evals_per_ray": wl.evals_per_ray, "sharding": wl.shard_mode,
                 "evals_per_step_all_ranks": evals_job, "rays_per_s": wl.frames_per_step * wl.n_pixels * args.steps / elapsed,
                 "collective": ("one all_gather_into_tensor of [%s] per step over %s" % (", ".join(wl.gather_keys), backend_name(backend)))
                               if dist is not None else "none"},
@@ -436,7 +467,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
             res["multi_gpu"] = {"world_size": world, "backend": backend_name(backend), "scaling": scaling,
                                 "per_rank_render_ms": per_rank_render, "per_rank_gather_ms_incl_wait": per_rank_gather,
                                 "per_rank_ms_per_step": per_rank_step, "gather_alone_ms": gather_alone_ms,
-                                "gather_bytes_per_rank": 5 * 4 * (wl.hi - wl.lo),
+                                "gather_bytes_per_rank": 5 * 4 * (wl.shards.per if wl.shards is not None else wl.n_local),
                                 "note": "gather_ms_incl_wait = the all-gather as seen by the rank's stream: the collective plus the "
                                         "wait for the slowest rank's render; gather_alone_ms = the same collective after a barrier"}
         if extra is not None:
@@ -444,7 +475,9 @@ def run(args, renderer=None, backend="nccl", argv=None):
     if rank == 0 and lib is not None:
         want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and cfg_id == 1)
         res["roofline"].update(pmc_traffic(args, cfg_id, live=want_pmc and dist is None))
-    if rank == 0 and world == 1 and args.cpu_rays > 0:
+    if rank == 0 and args.as_rank is not None:
+        res["config"]["as_rank"] = list(args.as_rank)       # this line is ONE rank's share of a WORLD-rank frame, rendered alone
+    if rank == 0 and world == 1 and args.cpu_rays > 0 and args.as_rank is None:
         res["cpu_baseline"], psnr = cpu_baseline(wl, args.cpu_rays)
         res["psnr_vs_cpu_oracle_db"], res["psnr_delta_vs_reference_db"] = psnr
     if rank == 0:
@@ -575,10 +608,11 @@ def cpu_baseline(wl, n_sample):
         avail = os.cpu_count() or 1
     key = wl.gather_keys[0]
     dev = wl.R.device
-    n_local = wl.hi - wl.lo
-    idx = torch.linspace(0, n_local - 1, min(n_sample, n_local)).long()
+    n_local = wl.n_local
+    idx = torch.linspace(0, n_local - 1, min(n_sample, n_local)).long()       # positions in this rank's render order
     g_cpu = wl.last[key][idx.to(dev)].cpu()
-    off = wl.lo if wl.scaling == "strong" else 0          # wl.rays / wl.codes hold the whole frame
+    # wl.rays / wl.codes hold the whole frame: this rank's j-th ray is frame pixel local_index[j]
+    frame_idx = wl.shards.local_index(wl.rank)[idx] if (wl.scaling == "strong" and wl.shards is not None) else idx
     if wl.kind == "multi":
         sets = [s[idx.to(dev)].cpu() for s in wl._ray_sets()]
 
@@ -586,7 +620,7 @@ def cpu_baseline(wl, n_sample):
             return Ro.render_rays_multi(wl.sc, [s[:m] for s in sets], wl.obj_ids, **wl.kw)
         evals_of = lambda m: sum(float((s[:m, 7] > 0).sum()) for s in sets) * wl.evals_per_ray   # noqa: E731
     else:
-        r_cpu, c_cpu = wl.rays[(idx + off).to(dev)].cpu(), wl.codes[(idx + off).to(dev)].cpu()
+        r_cpu, c_cpu = wl.rays[frame_idx.to(dev)].cpu(), wl.codes[frame_idx.to(dev)].cpu()
 
         def run(m):
             return Ro.render_rays(wl.sc, r_cpu[:m], embedding_instance=c_cpu[:m], **wl.kw)
@@ -605,7 +639,10 @@ def cpu_baseline(wl, n_sample):
             best = (nt, dt)
     ncpu, per_ray = best[0], best[1] / 128
     torch.set_num_threads(ncpu)
-    m = int(max(128, min(idx.numel(), 8.0 / max(per_ray, 1e-6))))      # ~8 s per repetition
+    # the whole slab (4096 rays by default), one warm-up + 3 timed repetitions, median; bounded at ~15 s per
+    # repetition so that a slow host cannot stretch the default run beyond minutes (the bound is reported when it bites)
+    m = int(max(128, min(idx.numel(), 15.0 / max(per_ray, 1e-6))))
+    run(m)
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
@@ -622,9 +659,12 @@ def cpu_baseline(wl, n_sample):
     # images here, so both renders are scored against one synthetic target T = reference render + N(0, 0.05) noise
     tgt = (ref + 0.05 * torch.randn(ref.shape, generator=torch.Generator().manual_seed(7))).clamp(0, 1)
     delta = abs(psnr_of(g_cpu, tgt) - psnr_of(ref, tgt))
-    return {"value": evals_of(m) / med, "unit": "ray-samples/s", "cores": ncpu, "cores_available": avail, "kind": "port",
-            "sample": "%d rays evenly spread over the frame, same weights/grid/codes/flags, median of 3 (%.2f s each)"
-                      % (m, med)}, (psnr, delta)
+    base = {"value": evals_of(m) / med, "unit": "ray-samples/s", "cores": ncpu, "cores_available": avail, "kind": "port",
+            "sample": "%d-ray slab (BASELINE.md §3 asks for 4096%s), rays evenly spread over the frame, same "
+                      "weights/grid/codes/flags, thread count = best of a 128-ray probe over {8,16,32,64,128}, one warm-up + "
+                      "median of 3 repetitions (%.2f s each)"
+                      % (m, "" if m >= min(4096, idx.numel()) else "; cut to keep a repetition under ~15 s on this host", med)}
+    return base, (psnr, delta)
 
 
 def main(argv=None):

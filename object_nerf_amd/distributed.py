@@ -40,10 +40,91 @@ def shard_rays(rays: torch.Tensor, extras: Dict[str, torch.Tensor] = None, rank:
     return rays[lo:hi], ex
 
 
-def gather_pixels(local: torch.Tensor, n_total: int = None) -> torch.Tensor:
-    """All-gathers per-ray pixel rows.  `local` is (n_local, C) (or (n_local,)); every rank must
-    hold the same n_local except possibly trailing short/empty shards, which are padded to
-    ceil(n_total/world) for the collective and trimmed afterwards.  Returns (n_total, C)."""
+class RayShards:
+    """How the n rays (pixels) of one frame are dealt to `world` ranks.
+
+    block=None  contiguous bands of ceil(n/world) rays (`shard_bounds`): right when every ray costs the same
+                (`render_rays`: BASELINE configs[3]).
+    block=b     blocks of b consecutive rays dealt round-robin (block-cyclic): the cost-balanced split for
+                `render_rays_multi` (BASELINE configs[4]) -- rays that miss their object's box are culled before the MLP
+                kernel and the hits are spatially clustered (the moved object covers a fifth of the frame), so contiguous
+                bands carry very different amounts of work and the single all-gather waits for the heaviest; with blocks
+                of a few image rows every rank gets the same share of every region.  Rays stay whole (all K ray sets of a
+                pixel on one rank), results come back in frame order through one index_select after the ONE all-gather.
+    """
+
+    def __init__(self, n: int, world: int, block: int = None, band: int = None):
+        """band: rays per contiguous band when block is None (default ceil(n/world); `rows` passes whole image rows)"""
+        self.n, self.world, self.block = int(n), int(world), (None if block is None else int(block))
+        if self.block is not None and self.block < 1:
+            raise ValueError("RayShards: block must be >= 1")
+        if self.block is None:
+            self.band = int(band) if band is not None else (self.n + self.world - 1) // self.world
+            self.counts = [self._band(r)[1] - self._band(r)[0] for r in range(self.world)]
+        else:
+            nblk = (self.n + self.block - 1) // self.block
+            self.counts = [sum(min(self.block, self.n - b * self.block) for b in range(r, nblk, self.world)) for r in range(self.world)]
+        self.per = max(self.counts) if self.counts else 0          # rows per rank in the (padded) collective
+        self._idx = {}
+
+    @staticmethod
+    def rows(H: int, W: int, world: int, row_block: int = None) -> "RayShards":
+        """shards of an H x W frame in whole image rows (what `ray_utils.row_share` / objnerf_generate_rays_rows produce)"""
+        if row_block is None:
+            return RayShards(H * W, world, band=((H + world - 1) // world) * W)
+        return RayShards(H * W, world, block=row_block * W)
+
+    def _band(self, rank):
+        lo = min(rank * self.band, self.n)
+        return lo, min(lo + self.band, self.n)
+
+    def local_index(self, rank: int, device=None) -> torch.Tensor:
+        """frame positions of rank's rays, in the order the rank renders them (cached per device)"""
+        key = ("local", rank, str(device))
+        if key not in self._idx:
+            if self.block is None:
+                lo, hi = self._band(rank)
+                idx = torch.arange(lo, hi)
+            else:
+                nblk = (self.n + self.block - 1) // self.block
+                idx = torch.cat([torch.arange(b * self.block, min((b + 1) * self.block, self.n)) for b in range(rank, nblk, self.world)]
+                                or [torch.zeros(0, dtype=torch.long)])
+            self._idx[key] = idx.to(device) if device is not None else idx
+        return self._idx[key]
+
+    def take(self, t: torch.Tensor, rank: int) -> torch.Tensor:
+        """this rank's rows of a per-ray tensor (n, ...)"""
+        if self.block is None:
+            lo, hi = self._band(rank)
+            return t[lo:hi]
+        return t.index_select(0, self.local_index(rank, t.device))
+
+    def restore(self, gathered: torch.Tensor) -> torch.Tensor:
+        """(world * per, C) all-gather result (rank r's rows at [r*per, r*per + counts[r])) -> (n, C) in frame order"""
+        if self.block is None and self.band == self.per:
+            return gathered[: self.n]                        # bands are already in frame order: only the tail is padding
+        key = ("inverse", str(gathered.device))
+        if key not in self._idx:
+            inv = torch.empty(self.n, dtype=torch.long)
+            for r in range(self.world):
+                inv[self.local_index(r)] = r * self.per + torch.arange(self.counts[r])
+            self._idx[key] = inv.to(gathered.device)
+        return gathered.index_select(0, self._idx[key])
+
+
+def default_block(n: int, world: int) -> int:
+    """block-cyclic granularity when the caller gives none: ~64 blocks per rank, a multiple of 64 rays, and -- when possible --
+    a block count divisible by the world size so that every rank gets the same number of rays"""
+    b = max(64, (n // (world * 64)) // 64 * 64)
+    for cand in range(b, max(63, b // 2), -64):
+        if n % cand == 0 and (n // cand) % world == 0:
+            return cand
+    return b
+
+
+def gather_pixels(local: torch.Tensor, n_total: int = None, shards: RayShards = None) -> torch.Tensor:
+    """All-gathers per-ray pixel rows.  `local` is (n_local, C) (or (n_local,)); short / empty shards are padded to the
+    longest one for the collective and the padding dropped afterwards.  Returns (n_total, C) in frame order."""
     if not dist.is_initialized():
         return local
     world = dist.get_world_size()
@@ -51,29 +132,49 @@ def gather_pixels(local: torch.Tensor, n_total: int = None) -> torch.Tensor:
     cols = 1
     for d in local.shape[1:]:
         cols *= int(d)
-    x = local.reshape(local.shape[0], cols).contiguous()     # explicit width: reshape(0, -1) is ambiguous
-    per = x.shape[0] if n_total is None else (n_total + world - 1) // world
-    if x.shape[0] < per:
-        x = torch.cat([x, x.new_zeros(per - x.shape[0], x.shape[1])], 0)
-    out = x.new_empty(world * per, x.shape[1])
-    dist.all_gather_into_tensor(out, x)
-    if n_total is not None:
-        out = out[:n_total]
+    x = local.reshape(local.shape[0], cols)                  # explicit width: reshape(0, -1) is ambiguous
+    if shards is None and n_total is not None:
+        shards = RayShards(n_total, world)
+    per = x.shape[0] if shards is None else shards.per
+    if x.shape[0] == per and x.is_contiguous():
+        send = x
+    else:
+        send = x.new_zeros(per, cols)
+        send[: x.shape[0]].copy_(x)
+    out = x.new_empty(world * per, cols)
+    dist.all_gather_into_tensor(out, send)
+    if shards is not None:
+        out = shards.restore(out)
     return out.reshape(-1) if squeeze else out
 
 
-def gather_pixel_maps(local: Dict[str, torch.Tensor], n_total: int = None) -> Dict[str, torch.Tensor]:
+def gather_pixel_maps(local: Dict[str, torch.Tensor], n_total: int = None, shards: RayShards = None) -> Dict[str, torch.Tensor]:
     """All-gathers several per-ray maps ((n_local,) or (n_local, C) each) in ONE collective: the maps are packed side by
-    side into one (n_local, sum C) message -- rgb + depth + opacity = 20 B/ray -- because on xGMI a ring all-gather is
-    latency-bound at this size (<1 MB per rank) and three launches cost three latencies.  Returns {key: (n_total, ...)}."""
+    side into one (per, sum C) message -- rgb + depth + opacity = 20 B/ray -- because on xGMI a ring all-gather is
+    latency-bound at this size (<1 MB per rank) and three launches cost three latencies.  The message buffer is
+    allocated at its padded size and the maps are copied straight into its columns (no cat, no pad pass).
+    Returns {key: (n_total, ...)} in frame order."""
     keys = list(local)
     if not dist.is_initialized() or not keys:
         return dict(local)
+    world = dist.get_world_size()
     cols = [int(torch.Size(local[k].shape[1:]).numel()) for k in keys]          # 1 for (n_local,) maps
-    n_local = local[keys[0]].shape[0]
-    packed = torch.cat([local[k].reshape(n_local, c) for k, c in zip(keys, cols)], 1) if len(keys) > 1 else \
-        local[keys[0]].reshape(n_local, cols[0])
-    full = gather_pixels(packed, n_total)
+    first = local[keys[0]]
+    n_local = first.shape[0]
+    if shards is None and n_total is not None:
+        shards = RayShards(n_total, world)
+    per = n_local if shards is None else shards.per
+    packed = first.new_empty(per, sum(cols))
+    off = 0
+    for k, c in zip(keys, cols):
+        packed[:n_local, off:off + c].copy_(local[k].reshape(n_local, c))
+        off += c
+    if n_local < per:
+        packed[n_local:].zero_()
+    full = first.new_empty(world * per, packed.shape[1])
+    dist.all_gather_into_tensor(full, packed)
+    if shards is not None:
+        full = shards.restore(full)
     out, off = {}, 0
     for k, c in zip(keys, cols):
         piece = full[:, off:off + c]
@@ -82,34 +183,61 @@ def gather_pixel_maps(local: Dict[str, torch.Tensor], n_total: int = None) -> Di
     return out
 
 
+def _rank_world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+
 def render_rays_sharded(render_fn, rays: torch.Tensor, per_ray: Dict[str, torch.Tensor] = None,
-                        gather_keys: Iterable[str] = ("rgb_fine", "depth_fine", "opacity_fine"), on_rendered=None, **kwargs):
-    """Renders this rank's band of `rays` with `render_fn(rays=..., **per_ray_slices, **kwargs)`
-    and returns {key: full-frame tensor} for `gather_keys` (identical on every rank); one collective per call.
-    on_rendered(local_results): optional hook between the render and the collective (bench.py records an event there)."""
+                        gather_keys: Iterable[str] = ("rgb_fine", "depth_fine", "opacity_fine"), on_rendered=None,
+                        shards: RayShards = None, as_rank: Tuple[int, int] = None, **kwargs):
+    """Renders this rank's share of `rays` with `render_fn(rays=..., **per_ray_slices, **kwargs)` and returns
+    {key: full-frame tensor} for `gather_keys` (identical on every rank); one collective per call.  Default split:
+    contiguous bands (every ray of `render_rays` costs the same).
+    on_rendered(local_results): optional hook between the render and the collective (bench.py records an event there).
+    as_rank = (rank, world): render that rank's share without a process group (tools/band_replay.py replays the ranks of
+    an N-GPU run one after the other on one GPU); the local maps are returned, nothing is gathered."""
     n = rays.shape[0]
-    r_local, ex = shard_rays(rays, per_ray)
-    res = render_fn(rays=r_local, **ex, **kwargs)
+    rank, world = as_rank if as_rank is not None else _rank_world()
+    sh = shards if shards is not None else RayShards(n, world)
+    ex = {}
+    for k, v in (per_ray or {}).items():
+        ex[k] = sh.take(v, rank) if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v
+    res = render_fn(rays=sh.take(rays, rank), **ex, **kwargs)
     if on_rendered is not None:
         on_rendered(res)
-    return gather_pixel_maps({k: res[k] for k in gather_keys if k in res}, n)
+    local = {k: res[k] for k in gather_keys if k in res}
+    return local if as_rank is not None else gather_pixel_maps(local, n, sh)
 
 
 def render_rays_multi_sharded(render_fn, rays_list, gather_keys: Iterable[str] = ("rgb_fine", "depth_fine", "opacity_fine"),
-                              on_rendered=None, **kwargs):
+                              on_rendered=None, shards: RayShards = None, rays_are_local: bool = False,
+                              as_rank: Tuple[int, int] = None, **kwargs):
     """The same for `render_rays_multi` (BASELINE configs[4], the editing demo on N GPUs): every ray set of the list
-    describes the same pixels through a different object transform, so all sets are cut at the same row bounds and
-    each rank composites its band of pixels over all sets; one pixel all-gather per frame, as above."""
-    n = rays_list[0].shape[0]
-    if any(r.shape[0] != n for r in rays_list):
-        raise RuntimeError("render_rays_multi_sharded: every ray set must have the same number of rays")
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    lo, hi = shard_bounds(n, rank, world)
-    res = render_fn(rays_list=[r[lo:hi] for r in rays_list], **kwargs)
+    describes the same pixels through a different object transform, so all sets are dealt with the same `RayShards` and
+    each rank composites its pixels over all sets; one pixel all-gather per frame.  Default split: block-cyclic
+    (`default_block`), because the culled object ray sets make the cost per pixel non-uniform (see RayShards).
+    rays_are_local: `rays_list` already holds only this rank's rays in `shards.local_index(rank)` order (each rank
+    generated its own rows, `ray_utils.generate_rays(rows=ray_utils.row_share(...))`); `shards` is then required.
+    as_rank: as in render_rays_sharded."""
+    rank, world = as_rank if as_rank is not None else _rank_world()
+    if rays_are_local:
+        if shards is None:
+            raise RuntimeError("render_rays_multi_sharded: rays_are_local needs the RayShards the rays were generated for")
+        n, sh = shards.n, shards
+        if any(r.shape[0] != sh.counts[rank] for r in rays_list):
+            raise RuntimeError("render_rays_multi_sharded: a local ray set does not have this rank's %d rays" % sh.counts[rank])
+        local = list(rays_list)
+    else:
+        n = rays_list[0].shape[0]
+        if any(r.shape[0] != n for r in rays_list):
+            raise RuntimeError("render_rays_multi_sharded: every ray set must have the same number of rays")
+        sh = shards if shards is not None else RayShards(n, world, default_block(n, world) if world > 1 else None)
+        local = [sh.take(r, rank) for r in rays_list]
+    res = render_fn(rays_list=local, **kwargs)
     if on_rendered is not None:
         on_rendered(res)
-    return gather_pixel_maps({k: res[k] for k in gather_keys if k in res}, n)
+    maps = {k: res[k] for k in gather_keys if k in res}
+    return maps if as_rank is not None else gather_pixel_maps(maps, n, sh)
 
 
 class GradientSync:

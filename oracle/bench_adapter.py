@@ -43,19 +43,37 @@ class OracleRenderer:
         pc, pf, grid, _ = self._scene(sc)
         kw = dict(kw)
         kw["embedding_instance"] = kw["embedding_instance"].cpu()
+        if rays.shape[0] == 0:
+            # an idle rank of a sharded frame: the reference (and so its restatement) cannot take an empty batch
+            # (torch.cat of no chunks, rendering.py:132); the product returns empty maps -- do the same here
+            one = torch.tensor([[0.5, 0.5, 0.6, 0.0, 0.0, -1.0, 0.15, 3.0]])
+            kw["embedding_instance"] = torch.zeros(1, kw["embedding_instance"].shape[1])
+            with torch.no_grad():
+                return {k: v[:0] for k, v in O.render_rays(pc, pf, grid, one, **kw).items()}
         with torch.no_grad():
             return O.render_rays(pc, pf, grid, rays.cpu(), **kw)
 
     def render_rays_multi(self, sc, rays_list, obj_instance_ids, background_skip_bbox=None, **kw):
         pc, pf, grid, table = self._scene(sc)
         boxes = list(background_skip_bbox.values()) if background_skip_bbox else None
+        if rays_list[0].shape[0] == 0:                 # idle rank, as above
+            one = torch.tensor([[0.5, 0.5, 0.6, 0.0, 0.0, -1.0, 0.15, 3.0]])
+            with torch.no_grad():
+                r = O.render_rays_multi(pc, pf, grid, table, [one for _ in rays_list], list(obj_instance_ids), skip_boxes=boxes, **kw)
+            return {k: v[:0] for k, v in r.items()}
         with torch.no_grad():
             return O.render_rays_multi(pc, pf, grid, table, [r.cpu() for r in rays_list], list(obj_instance_ids),
                                        skip_boxes=boxes, **kw)
 
-    def generate_rays(self, H, W, focal, c2w, near=0.0, far=0.0, box=None, bbox_enlarge=0.0):
+    def generate_rays(self, H, W, focal, c2w, near=0.0, far=0.0, box=None, bbox_enlarge=0.0, rows=None):
         c = torch.as_tensor(c2w, dtype=torch.float32)[:3, :4]
-        return O.generate_rays(H, W, focal, c, near, far, box, bbox_enlarge)
+        full = O.generate_rays(H, W, focal, c, near, far, box, bbox_enlarge)
+        if rows is None:
+            return full
+        row0, n_rows, blk, stride = rows              # the row map of objnerf_generate_rays_rows (include/objnerf_hip.h)
+        lr = torch.arange(n_rows)
+        y = row0 + (lr // blk) * blk * stride + lr % blk
+        return full.view(H, W, 8)[y].reshape(-1, 8)
 
     def sync(self):
         pass

@@ -80,12 +80,38 @@ def test_strong_scaling_world2_equals_world1(cfg):
     mg = two["multi_gpu"]
     assert mg["world_size"] == 2 and len(mg["per_rank_render_ms"]) == 2 and len(mg["per_rank_gather_ms_incl_wait"]) == 2
     assert mg["gather_alone_ms"] is not None and all(v > 0 for v in mg["per_rank_render_ms"])
-    # one frame per step whatever the world size; rank 0 renders the first band
-    assert two["config"]["frames_per_step"] == 1 and two["config"]["rays_per_step_rank0"] == (12 * 9 + 1) // 2
+    # one frame per step whatever the world size; rank 0 renders whole image rows: the first band of ceil(9/2) rows
+    # (configs[3], contiguous) or the 4-row blocks 0 and 2 = rows 0-3 and 8 (configs[4], block-cyclic)
+    assert two["config"]["frames_per_step"] == 1 and two["config"]["rays_per_step_rank0"] == 5 * 12
+    assert two["config"]["sharding"] == ("contiguous" if cfg == 3 else "cyclic")
     assert two["config"]["evals_per_step_all_ranks"] == one["config"]["evals_per_step_all_ranks"]
     key = [k for k in two["config"] if k.startswith("mean_rgb")][0]
     assert abs(two["config"][key] - one["config"][key]) <= 1e-12 * abs(one["config"][key])   # identical pixels (float64 mean)
     assert "one all_gather_into_tensor" in two["config"]["collective"]
+
+
+@pytest.mark.parametrize("cfg,extra,rank0_rows", [(4, [], 4), (3, [], 2), (4, ["--shard", "contiguous"], 2), (3, ["--shard", "cyclic", "--row-block", "1"], 2)])
+def test_strong_scaling_world8_equals_world1(cfg, extra, rank0_rows):
+    """the node size the driver scales to, on a 12 x 9 frame: 9 rows over 8 ranks leaves ragged and EMPTY shards in either
+    split (contiguous: bands of 2 rows, ranks 5-7 idle; 4-row blocks: ranks 3-7 idle); each rank generates only its own rows
+    of the K ray sets (objnerf_generate_rays_rows' row map); the frame equals the single-process one"""
+    one = _run(1, ["--config", str(cfg), "--dist"])
+    eight = _run(8, ["--config", str(cfg)] + extra)
+    check_contract(eight, 8)
+    assert eight["scaling"] == "strong" and eight["multi_gpu"]["world_size"] == 8
+    assert eight["config"]["rays_per_step_rank0"] == rank0_rows * 12
+    assert eight["config"]["evals_per_step_all_ranks"] == one["config"]["evals_per_step_all_ranks"]
+    key = [k for k in eight["config"] if k.startswith("mean_rgb")][0]
+    assert abs(eight["config"][key] - one["config"][key]) <= 1e-12 * abs(one["config"][key])
+
+
+def test_as_rank_replay_renders_one_ranks_share():
+    """--as-rank R W (tools/band_replay.py): a single process renders exactly the share rank R of W would, no process group"""
+    shares = [_run(1, ["--config", "4", "--as-rank", str(r), "3"]) for r in range(3)]
+    whole = _run(1, ["--config", "4", "--dist"])
+    assert [s["config"]["rays_per_step_rank0"] for s in shares] == [4 * 12, 4 * 12, 1 * 12]       # 4-row blocks 0, 1, 2 of 9 rows
+    assert all("multi_gpu" not in s and s["config"]["as_rank"] == [r, 3] for r, s in enumerate(shares))
+    assert abs(sum(s["config"]["evals_per_step_all_ranks"] for s in shares) - whole["config"]["evals_per_step_all_ranks"]) < 1e-6
 
 
 def test_weak_scaling_world2_renders_two_frames():

@@ -9,8 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from object_nerf_amd.distributed import (GradientSync, gather_pixels, render_rays_multi_sharded, render_rays_sharded,
-                                         shard_rays)
+from object_nerf_amd.distributed import (GradientSync, RayShards, default_block, gather_pixel_maps, gather_pixels,
+                                         render_rays_multi_sharded, render_rays_sharded, shard_rays)
 
 
 def _free_port():
@@ -52,24 +52,80 @@ def _worker(rank, world, port, n, q):
         want = fake_multi(sets, [0, 4, 2])
         got = render_rays_multi_sharded(fake_multi, sets, obj_instance_ids=[0, 4, 2], gather_keys=("rgb_fine", "depth_fine"))
         ok = ok and torch.equal(got["rgb_fine"], want["rgb_fine"]) and torch.equal(got["depth_fine"], want["depth_fine"])
+        # every split of the same frame gives the same pixels: contiguous bands, block-cyclic with a ragged last block,
+        # blocks larger than the frame (most ranks empty), and rays handed over already dealt (rays_are_local)
+        for sh in (RayShards(n, world), RayShards(n, world, 3), RayShards(n, world, 1), RayShards(n, world, n + 5),
+                   RayShards(n, world, default_block(n, world))):
+            ok = ok and sum(sh.counts) == n and sh.per == max(sh.counts)
+            got = render_rays_multi_sharded(fake_multi, sets, obj_instance_ids=[0, 4, 2], gather_keys=("rgb_fine", "depth_fine"),
+                                            shards=sh)
+            ok = ok and torch.equal(got["rgb_fine"], want["rgb_fine"]) and torch.equal(got["depth_fine"], want["depth_fine"])
+            mine = [sh.take(r, rank) for r in sets]
+            got = render_rays_multi_sharded(fake_multi, mine, obj_instance_ids=[0, 4, 2], gather_keys=("rgb_fine",),
+                                            shards=sh, rays_are_local=True)
+            ok = ok and torch.equal(got["rgb_fine"], want["rgb_fine"])
+            out = render_rays_sharded(_fake_render, rays, {"embedding_instance": codes}, scale=3.0,
+                                      gather_keys=("rgb_fine", "depth_fine"), shards=sh)
+            ok = ok and torch.equal(out["rgb_fine"], full["rgb_fine"]) and torch.equal(out["depth_fine"], full["depth_fine"])
+            # packed maps of mixed rank (a (n,) and a (n, 3) map in one message)
+            loc = {"a": sh.take(rays[:, 5], rank), "b": sh.take(rays[:, :3], rank)}
+            gm = gather_pixel_maps(loc, n, sh)
+            ok = ok and torch.equal(gm["a"], rays[:, 5]) and torch.equal(gm["b"], rays[:, :3])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [10, 7, 1])
-def test_sharded_render_world2(n):
+def _run_sharded(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("n", [10, 7, 1])
+def test_sharded_render_world2(n):
+    _run_sharded(2, n)
+
+
+@pytest.mark.parametrize("n", [37, 5])
+def test_sharded_render_world8_ragged_and_empty_shards(n):
+    """8 ranks (the node size the driver scales to): n = 37 -> ragged bands (5,5,5,5,5,5,5,2); n = 5 -> three ranks with
+    nothing to render at all.  Every split reproduces the single-process frame bit for bit."""
+    _run_sharded(8, n)
+
+
+def test_ray_shards_layouts():
+    """the dealing itself, no process group: counts, the block-cyclic order, whole-row shards as objnerf_generate_rays_rows
+    writes them (ray_utils.row_share), restore() = inverse permutation of the padded all-gather buffer"""
+    from object_nerf_amd.ray_utils import row_share
+    for n, world, block in [(307200, 8, None), (307200, 8, 2560), (307201, 3, 1000), (10, 8, None), (10, 8, 3), (0, 4, 5),
+                            (5, 8, None), (307200, 8, default_block(307200, 8))]:
+        sh = RayShards(n, world, block)
+        x = torch.arange(n, dtype=torch.float32)[:, None]
+        g = torch.full((world * sh.per, 1), -1.0)
+        for r in range(world):
+            loc = sh.take(x, r)
+            assert loc.shape[0] == sh.counts[r] and torch.equal(loc[:, 0].long(), sh.local_index(r))
+            g[r * sh.per:r * sh.per + sh.counts[r]] = loc
+        assert sum(sh.counts) == n and torch.equal(sh.restore(g), x)
+    assert RayShards(307200, 8, default_block(307200, 8)).counts == [38400] * 8        # equal shares when the sizes allow
+    H, W = 480, 640
+    for world, rb in [(8, 4), (8, None), (3, 8), (7, None), (8, 64)]:
+        sh = RayShards.rows(H, W, world, rb)
+        for r in range(world):
+            row0, n_rows, blk, stride = row_share(H, r, world, rb)
+            lr = torch.arange(n_rows)
+            y = row0 + (lr // blk) * blk * stride + lr % blk                            # the kernel's row map
+            want = (y[:, None] * W + torch.arange(W)[None]).reshape(-1)
+            assert sh.counts[r] == n_rows * W and torch.equal(sh.local_index(r), want)
 
 
 def _grad_worker(rank, world, port, q):
@@ -107,6 +163,24 @@ def _grad_worker(rank, world, port, q):
         s2.sync()
         ok = ok and torch.allclose(table.grad[:300], sum(tg) / world, atol=1e-6)
         ok = ok and bool((table.grad[900] == float(rank + 1)).all()) and bool((table.grad[300:900] == 0).all())
+        # the debug switch names the silent divergence above; a changed occupancy is announced with set_active_rows
+        s3 = GradientSync([table], active_rows={table: 300}, check_inactive_rows=True)
+        try:
+            s3.sync()
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "active_rows" in str(e)
+        table.grad[900] = 0.0
+        table.grad[:400] = float(rank + 1)
+        s3.set_active_rows(table, 400)
+        s3.sync()
+        ok = ok and bool((table.grad[:400] == (1 + world) / 2.0).all()) and s3.message_bytes() == [4 * 400 * 24]
+        # a gradient that is not contiguous (a transposed view) is still averaged in place, whatever the layout
+        pt = torch.nn.Parameter(torch.zeros(6, 4))
+        pt.grad = torch.full((4, 6), float(rank + 1)).t()
+        ok = ok and not pt.grad.is_contiguous()
+        GradientSync([pt]).sync()
+        ok = ok and bool((pt.grad == (1 + world) / 2.0).all())
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
