@@ -473,7 +473,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
         if extra is not None:
             res["split_bf16_mode"] = extra
     if rank == 0 and lib is not None:
-        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and cfg_id == 1)
+        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and args.as_rank is None)     # every config at N = 1
         res["roofline"].update(pmc_traffic(args, cfg_id, live=want_pmc and dist is None))
     if rank == 0 and args.as_rank is not None:
         res["config"]["as_rank"] = list(args.as_rank)       # this line is ONE rank's share of a WORLD-rank frame, rendered alone
@@ -582,8 +582,8 @@ def pmc_traffic(args, cfg_id, live):
         except Exception as e:
             log("live PMC collection failed (%s: %s); using the committed profile" % (type(e).__name__, e))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-    if not files:
-        return {"traffic": None}
+    if not files or cfg_id != 1:          # the committed counters are of the config-1 frame: never quoted for another workload
+        return {"traffic": None, "traffic_source": "not collected in this run"}
     try:
         d = json.load(open(files[-1]))["derived"]
         return {"traffic": d["hbm_traffic_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC)",

@@ -97,12 +97,20 @@ class RayShards:
         if self.block is None:
             lo, hi = self._band(rank)
             return t[lo:hi]
+        if self._even():      # whole blocks, the same number for every rank: a strided view, one copy
+            return t.reshape(self.n // (self.block * self.world), self.world, self.block, *t.shape[1:])[:, rank].reshape(-1, *t.shape[1:])
         return t.index_select(0, self.local_index(rank, t.device))
+
+    def _even(self):
+        return self.block is not None and self.n > 0 and self.n % (self.block * self.world) == 0
 
     def restore(self, gathered: torch.Tensor) -> torch.Tensor:
         """(world * per, C) all-gather result (rank r's rows at [r*per, r*per + counts[r])) -> (n, C) in frame order"""
         if self.block is None and self.band == self.per:
             return gathered[: self.n]                        # bands are already in frame order: only the tail is padding
+        if self._even():      # rank-major blocks -> frame order: one strided copy instead of an index_select
+            g = gathered.reshape(self.world, self.per // self.block, self.block, *gathered.shape[1:])
+            return g.transpose(0, 1).reshape(self.n, *gathered.shape[1:])
         key = ("inverse", str(gathered.device))
         if key not in self._idx:
             inv = torch.empty(self.n, dtype=torch.long)

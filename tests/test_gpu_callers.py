@@ -153,7 +153,7 @@ def box_from_row(row):
 
 @pytest.mark.parametrize("scenario,prefix,n_sets", [("render_edit", "edit_", 3), ("render_origin", "origin_", 1)])
 def test_editable_renderer_chunk_loops(scene, gold, scenario, prefix, n_sets):
-    calls = [c for c in load_calls() if c["scenario"] == scenario]
+    calls = [c for c in load_calls() if c["scenario"] == scenario and c["fn"] == "render_rays_multi"]
     assert [c["tens"]["rays_0"].shape[0] for c in calls] == [50, 50, 20]        # config.chunk = 50 over 10 x 12 pixels
     chunks = []
     with torch.no_grad():
