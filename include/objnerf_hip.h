@@ -143,7 +143,22 @@ typedef struct {
    * render_tools/multi_rendering.py:40,83,92. */
   const int32_t* ray_index;
   const int32_t* n_active;
+  /* fused form only, optional: alpha compositing (models/rendering.py:139-229, eval mode: no occlusion mask, no noise)
+   * begun in the kernel's epilogue -- a wave holds 32 consecutive samples of one ray, so it forms alpha, the
+   * transmittance scan and the weighted sums of its 32-sample SEGMENT right where sigma / rgb were computed; they are
+   * then never written (sigma / rgb / inst_sigma / inst_rgb may be NULL).  Requires do_scene, S % 32 == 0, no ray_index.
+   *   comp_w    (n_rays, S) out: per-sample weights relative to the start of their segment -- of the scene set, or of
+   *             the instance set when comp_inst_weights (rays_in_bbox, rendering.py:228-229); NULL = off
+   *   comp_rec  (n_rays * S / 32, OBJNERF_SEG_REC_FLOATS) out: per segment [Q A R G B D - - | the same of the instance
+   *             set]: product of (1 - alpha + 1e-10), sums of the local weights x {1, r, g, b, z}
+   *   comp_last_delta  delta of the scene set's last sample: 1e10, or 0 with use_zero_as_last_delta (the instance set's is 0)
+   * objnerf_composite_finish turns comp_w / comp_rec into the reference's weights and maps. */
+  float* comp_w;
+  float* comp_rec;
+  float comp_last_delta;
+  int32_t comp_inst_weights;
 } objnerf_mlp_args;
+#define OBJNERF_SEG_REC_FLOATS 16
 int objnerf_mlp_eval(const objnerf_mlp_args* args, void* stream);
 
 /* scene + instance alpha compositing: models/rendering.py:139-229.
@@ -176,6 +191,16 @@ typedef struct {
   float* opacity_inst;       /* (N) */
 } objnerf_composite_args;
 int objnerf_composite(const objnerf_composite_args* args, void* stream);
+/* Second half of the fused form (objnerf_mlp_args.comp_*): per ray, the segments' incoming transmittances in ascending
+ * order, weights[n, s] *= T(segment of s) in place (weights = the comp_w the MLP kernel wrote), and the maps of
+ * rendering.py:164-229 (rgb_map white-backed when white_back; the instance maps, always white-backed, when has_instance;
+ * inst_weights: `weights` are the instance set's, objnerf_mlp_args.comp_inst_weights).
+ * Results are BIT-EQUAL to objnerf_composite on the same sigma / rgb (shared arithmetic, csrc/composite_seg.h).
+ * HBM traffic: 8 B per sample + 64 B per 32 samples, against 40 B per sample for objnerf_composite + 32 B per sample of
+ * sigma / rgb stores in the MLP kernel. */
+int objnerf_composite_finish(const float* seg_records, int64_t n_rays, int S, int has_instance, int inst_weights,
+                             int white_back, float* weights, float* opacity, float* rgb_map, float* depth, float* rgb_inst,
+                             float* depth_inst, float* opacity_inst, void* stream);
 
 /* sample_pdf + sort(cat) : models/rendering.py:11-61 and 302-313.
  * weights: (N,S) coarse weights (the kernel uses weights[:,1:-1] and z_mid of z_coarse);
@@ -294,6 +319,11 @@ typedef struct {
   float frustum_bound_th;
   int32_t rays_in_bbox;
   int32_t mfma_bf16x3;       /* blob_coarse / blob_fine are objnerf_pack_weights_b3() streams (see objnerf_mlp_args) */
+  /* 0 (default): a pass without occlusion mask and noise whose sample count is a multiple of 32 composites in the MLP
+   * kernel's epilogue (objnerf_mlp_args.comp_*: sigma / rgb never reach memory, workspace 2 B instead of 32 B per sample);
+   * 1: always the two-kernel form (MLP kernel -> sigma / rgb in the workspace -> objnerf_composite).  Results are
+   * bit-equal either way. */
+  int32_t separate_composite;
 } objnerf_render_cfg;
 
 typedef struct {

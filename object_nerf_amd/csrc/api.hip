@@ -221,9 +221,15 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (!a || !a->blob || !a->aux) return set_error(-1, "mlp_eval: null weights");
   if ((a->emb_xyz == nullptr ? a->n_rays * (int64_t)a->S : a->n_points) == 0) return 0;   // nothing to do
   if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
-  if (a->do_scene && !a->sigma) return set_error(-1, "mlp_eval: scene branch needs a sigma output");
-  if (a->do_object && !a->inst_sigma) return set_error(-1, "mlp_eval: object branch needs an inst_sigma output");
   const bool fused = a->emb_xyz == nullptr;
+  const bool comp = a->comp_w != nullptr;      // compositing in the epilogue: sigma / rgb need not be written
+  if (comp) {
+    if (!fused || !a->do_scene || !a->comp_rec || a->ray_index || a->sigma_only || a->S < 32 || (a->S & 31))
+      return set_error(-1, "mlp_eval: comp_w needs the fused form, the scene branch, comp_rec, S % 32 == 0 and no ray subset");
+  } else {
+    if (a->do_scene && !a->sigma) return set_error(-1, "mlp_eval: scene branch needs a sigma output");
+    if (a->do_object && !a->inst_sigma) return set_error(-1, "mlp_eval: object branch needs an inst_sigma output");
+  }
   // ray subset (objnerf_hip.h: fused form only, both or neither): a list without its count would make the kernel walk all
   // n_rays slots of a list whose tail is uninitialised; a count without a list would silently evaluate the first rays
   if ((a->ray_index == nullptr) != (a->n_active == nullptr))
@@ -284,11 +290,23 @@ int objnerf_timing_read(int64_t* launches, double* total_ms) {
 }
 
 // ---- whole render_rays (models/rendering.py:233-337) --------------------------------------------
-// workspace: sigma (N*Smax) | rgb (3*N*Smax) | inst_sigma (N*Smax) | inst_rgb (3*N*Smax)
+// A pass composites in the MLP kernel's epilogue (objnerf_mlp_args.comp_*) when nothing between sigma and alpha needs
+// another ray-wide quantity: no occlusion mask (eval mode or frustum_bound_th <= 0, rendering.py:192), no noise
+// (noise_std == 0), and 32-sample segments that tile the ray (S % 32 == 0).
+static bool pass_fuses(const objnerf_render_cfg* cfg, int S) {
+  const bool occlusion = !cfg->is_eval && cfg->frustum_bound_th > 0.f;
+  return !cfg->separate_composite && !occlusion && cfg->noise_std == 0.f && S >= 32 && (S & 31) == 0;
+}
+// workspace of one pass: fused -> segment records only (64 B per 32 samples); two-kernel form ->
+// sigma (N*S) | rgb (3*N*S) | inst_sigma (N*S) | inst_rgb (3*N*S)
+static int64_t pass_floats(const objnerf_render_cfg* cfg, int64_t n_rays, int S) {
+  return pass_fuses(cfg, S) ? n_rays * (S / 32) * OBJNERF_SEG_REC_FLOATS : n_rays * S * 8;
+}
 int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_rays) {
   if (!cfg || n_rays < 0) return -1;
-  const int64_t smax = cfg->N_samples + (cfg->N_importance > 0 ? cfg->N_importance : 0);
-  return (int64_t)sizeof(float) * n_rays * smax * 8 + 256;
+  const int64_t c = pass_floats(cfg, n_rays, cfg->N_samples);
+  const int64_t f = cfg->N_importance > 0 ? pass_floats(cfg, n_rays, cfg->N_samples + cfg->N_importance) : 0;
+  return (int64_t)sizeof(float) * (c > f ? c : f) + 256;
 }
 
 static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* out,
@@ -296,6 +314,7 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
                        void* stream) {
   const int64_t N = in->n_rays;
   float* ws = (float*)in->workspace;
+  const bool fuse = pass_fuses(cfg, S);
   float* sigma = ws;
   float* rgb = sigma + N * S;
   float* isig = rgb + 3 * N * S;
@@ -307,6 +326,16 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
   m.blob = blob; m.aux = aux; m.mfma_bf16x3 = cfg->mfma_bf16x3;
   m.rays = in->rays; m.z_vals = out->z_vals; m.n_rays = N; m.S = S;
   m.codes = in->codes; m.code_stride = in->code_stride; m.grid = in->grid;
+  const bool inst_weights = cfg->rays_in_bbox && cfg->forward_instance;          // rendering.py:228-229
+  if (fuse) {
+    m.comp_w = out->weights; m.comp_rec = ws;
+    m.comp_last_delta = cfg->use_zero_as_last_delta ? 0.f : 1e10f;               // rendering.py:143-153
+    m.comp_inst_weights = inst_weights;
+    int rc = objnerf_mlp_eval(&m, stream);
+    if (rc) return rc;
+    return objnerf_composite_finish(ws, N, S, cfg->forward_instance, inst_weights, cfg->white_back, out->weights, out->opacity,
+                                    out->rgb, out->depth, out->rgb_instance, out->depth_instance, out->opacity_instance, stream);
+  }
   m.sigma = sigma; m.rgb = rgb;
   m.inst_sigma = cfg->forward_instance ? isig : nullptr;
   m.inst_rgb = cfg->forward_instance ? irgb : nullptr;
@@ -322,7 +351,7 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
   c.occlusion = (!cfg->is_eval && cfg->frustum_bound_th > 0.f) ? 1 : 0;     // rendering.py:192
   c.frustum_bound_th = cfg->frustum_bound_th;
   c.pass_through_mask = in->pass_through_mask;
-  c.rays_in_bbox = cfg->rays_in_bbox && cfg->forward_instance;
+  c.rays_in_bbox = inst_weights;
   c.weights = out->weights; c.opacity = out->opacity; c.rgb_map = out->rgb; c.depth = out->depth;
   c.rgb_inst = out->rgb_instance; c.depth_inst = out->depth_instance; c.opacity_inst = out->opacity_instance;
   return objnerf_composite(&c, stream);

@@ -30,6 +30,7 @@
 #include <type_traits>
 #include "layout.h"
 #include "device_math.h"
+#include "composite_seg.h"
 #include "../../include/objnerf_hip.h"
 
 // ---- tuning switches (defaults = the shipped configuration; tools/tune_mlp.py A/Bs them) ----
@@ -736,6 +737,7 @@ template <class S, int NH, int NT> struct HidThenDir {
 template <bool VOXEL>
 struct TilePrologue {
   long p, ray;
+  int sidx;            // the point's sample index inside its ray
   bool valid;
   float rw[8];         // ray row [o, d, near, far]
   float zv;
@@ -753,7 +755,8 @@ struct TilePrologue {
     // ray subset (objnerf_mlp_args.ray_index): tiles walk the listed rays only; p stays the point's index in the
     // full (n_rays, S) arrays, so depths are read and results written in place
     ray = a.ray_index ? (long)a.ray_index[slot] : slot;
-    p = ray * a.S + (pc - slot * a.S);
+    sidx = (int)(pc - slot * a.S);
+    p = ray * a.S + sidx;
     const float* r = a.rays + ray * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) rw[i] = r[i];
@@ -997,9 +1000,13 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
     pre.run_all(a, tile_first, P, wave, lane, half);
 #endif
   }
+  // compositing in the epilogue (objnerf_mlp_args.comp_w, composite_seg.h): inference form of the fused kernel only
+  constexpr bool COMP = FUSED && !SAVE && !SIGMA_ONLY && DO_SCENE;
   for (long tile = tile_first; tile < tile_end; tile += tile_step) {
     long p;
     bool valid;
+    float comp_z = 0.f, comp_zn = 0.f, comp_sg = 0.f, comp_c[3] = {0.f, 0.f, 0.f};
+    bool comp_last = false;
     Src src;
     src.half = half;
     if constexpr (FUSED) {
@@ -1015,6 +1022,15 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       }
       p = pre.p;
       valid = pre.valid;
+      if constexpr (COMP) {
+        // compositing in the epilogue: this sample's depth and the next one's (the prologue registers are re-used for
+        // the NEXT tile during the object branch); one extra load per tile, consumed a whole pass later
+        if (a.comp_w) {
+          comp_z = pre.zv;
+          comp_last = pre.sidx + 1 >= a.S;
+          comp_zn = comp_last ? 0.f : a.z_vals[p + 1];
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) { src.dir[c] = pre.dir[c]; src.pos[c] = pre.pos[c]; }
 #pragma unroll
@@ -1084,10 +1100,11 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         col[c] = sigmoidf(head_dot<4>(hd, aux + kAuxSRgb + c * 4 * 32, half) + aux[kAuxSRgb + 3 * 4 * 32 + c]);
-      if (valid && half == 0) {
+      if (valid && half == 0 && a.sigma) {
         out_store(a.sigma + p, sg);
         if (a.rgb) { out_store(a.rgb + p * 3 + 0, col[0]); out_store(a.rgb + p * 3 + 1, col[1]); out_store(a.rgb + p * 3 + 2, col[2]); }
       }
+      if constexpr (COMP) { comp_sg = sg; comp_c[0] = col[0]; comp_c[1] = col[1]; comp_c[2] = col[2]; }
       }
     }
 
@@ -1131,10 +1148,39 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         col[c] = sigmoidf(head_dot<2>(hd, aux + kAuxORgb + c * 2 * 32, half) + aux[kAuxORgb + 3 * 2 * 32 + c]);
-      if (valid && half == 0) {
+      if (valid && half == 0 && a.inst_sigma) {
         out_store(a.inst_sigma + p, sg);
         if (a.inst_rgb) { out_store(a.inst_rgb + p * 3 + 0, col[0]); out_store(a.inst_rgb + p * 3 + 1, col[1]); out_store(a.inst_rgb + p * 3 + 2, col[2]); }
       }
+      if constexpr (COMP) {
+        // instance set of this wave's 32-sample segment (last delta 0, rendering.py:148,213); both lane halves hold the
+        // same 32 points, the lower half's totals are kept
+        if (a.comp_w && valid) {
+          const float delta = comp_last ? 0.f : comp_zn - comp_z;
+          SegTotals lo, hi;
+          const float lw = segment_composite(sample_alpha(delta, sg), true, col[0], col[1], col[2], comp_z, lane, lo, hi);
+          if (a.comp_inst_weights && half == 0) a.comp_w[p] = lw;
+          if (lane == 0) {
+            float* rec = a.comp_rec + (p >> 5) * kSegRecFloats + kSegRecInst;
+            *(f32x4*)rec = f32x4{lo.Q, lo.A, lo.R, lo.G};
+            rec[4] = lo.B; rec[5] = lo.D;
+          }
+        }
+      }
+      }
+    }
+    if constexpr (COMP) {
+      // scene set (last delta 1e10, or 0 with use_zero_as_last_delta: rendering.py:143-153)
+      if (a.comp_w && valid) {
+        const float delta = comp_last ? a.comp_last_delta : comp_zn - comp_z;
+        SegTotals lo, hi;
+        const float lw = segment_composite(sample_alpha(delta, comp_sg), true, comp_c[0], comp_c[1], comp_c[2], comp_z, lane, lo, hi);
+        if (!(DO_OBJ && a.comp_inst_weights) && half == 0) a.comp_w[p] = lw;
+        if (lane == 0) {
+          float* rec = a.comp_rec + (p >> 5) * kSegRecFloats;
+          *(f32x4*)rec = f32x4{lo.Q, lo.A, lo.R, lo.G};
+          rec[4] = lo.B; rec[5] = lo.D;
+        }
       }
     }
   }

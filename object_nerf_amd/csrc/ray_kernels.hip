@@ -10,6 +10,7 @@
 #include <math.h>
 #include "layout.h"
 #include "device_math.h"
+#include "composite_seg.h"
 #include "host_api.h"
 
 namespace objnerf {
@@ -33,14 +34,7 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   const int lo = __shfl((int)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-// Cross-lane steps as DPP modifiers on VALU instructions (no LDS crossbar traffic: a __shfl is a ds_bpermute_b32, and the
-// compositing kernels did 76 of them per 64-sample chunk).  dpp_ctrl: quad_perm 0x00-0xff, row_shr:n 0x110+n,
-// row_ror:n 0x120+n, wave_shr:1 0x138, row_bcast:15 0x142, row_bcast:31 0x143 (gfx9 encodings); lanes without a source
-// (or masked rows / banks) keep `old`.
-template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
-__device__ __forceinline__ float dpp(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
-}
+// (dpp<> and the 32-lane segment primitives of the compositing kernels: composite_seg.h)
 // sum over the 64 lanes, returned in every lane: butterfly inside each row of 16 (quad swaps, row rotations), then the
 // row totals travel row_bcast:15 -> rows 1, 3 and row_bcast:31 -> rows 2, 3; lane 63 holds the total
 __device__ __forceinline__ float wave_sum(float v) {
@@ -226,14 +220,14 @@ __global__ void __launch_bounds__(256) voxel_embed_kernel(const objnerf_voxel_gr
 // ------------------------------------------------------------------------------------------
 struct CompositeOut { float opacity, r, g, b, depth; };
 
-// composites one channel set over the ray; when `wout` != null writes per-sample weights.
+// composites one channel set over the ray (composite_seg.h: 32-sample segments, lanes 0-31 and 32-63 of a 64-sample
+// chunk are two consecutive segments); when `wout` != null writes per-sample weights.
 // occl_depth: when occl, alphas with (occl_depth + th) < z are zeroed (rendering.py:192-202).
 __device__ __forceinline__ CompositeOut composite_ray(const float* __restrict__ z, const float* __restrict__ sigma,
                                                       const float* __restrict__ rgb, const float* __restrict__ noise,
                                                       float noise_std, float last_delta, int S, int lane,
                                                       bool occl, float occl_limit, float* __restrict__ wout) {
-  float carry = 1.f;   // prod_{j<base} (1 - a_j + 1e-10)
-  float so = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
+  RayAcc acc;
   for (int base = 0; base < S; base += 64) {
     const int i = base + lane;
     const bool in = i < S;
@@ -243,23 +237,17 @@ __device__ __forceinline__ CompositeOut composite_ray(const float* __restrict__ 
       const float delta = i + 1 < S ? z[i + 1] - zi : last_delta;
       float sg_ = sigma[i];
       if (noise) sg_ = sg_ + noise[i] * noise_std;
-      alpha = 1.f - expf(-delta * fmaxf(sg_, 0.f));          // rendering.py:157
+      alpha = sample_alpha(delta, sg_);                       // rendering.py:157
       if (occl && occl_limit < zi) alpha = 0.f;
       c0 = rgb[i * 3]; c1 = rgb[i * 3 + 1]; c2 = rgb[i * 3 + 2];
     }
-    const float t = in ? (1.f - alpha) + 1e-10f : 1.f;     // alphas_shifted, rendering.py:159-161
-    const float incl = wave_scan_mul(t, lane);
-    const float excl = wave_shr1(incl, 1.f);
-    const float T = carry * excl;
-    const float w = alpha * T;                              // rendering.py:162
-    if (in) {
-      if (wout) wout[i] = w;
-      so += w; sr += w * c0; sg += w * c1; sb += w * c2; sd += w * zi;
-    }
-    carry = carry * wave_last(incl);
+    SegTotals lo, hi;
+    const float lw = segment_composite(alpha, in, c0, c1, c2, zi, lane, lo, hi);
+    const float Tlo = acc.step(lo), Thi = acc.step(hi);       // a segment beyond S has Q = 1 and zero sums: no effect
+    if (in && wout) wout[i] = (lane < 32 ? Tlo : Thi) * lw;   // rendering.py:162
   }
   CompositeOut o;
-  o.opacity = wave_sum(so); o.r = wave_sum(sr); o.g = wave_sum(sg); o.b = wave_sum(sb); o.depth = wave_sum(sd);
+  o.opacity = acc.opacity; o.r = acc.r; o.g = acc.g; o.b = acc.b; o.depth = acc.depth;
   return o;
 }
 
@@ -272,8 +260,7 @@ __device__ __forceinline__ void composite_ray_pair(const float* __restrict__ z, 
                                                    const float* __restrict__ sigma1, const float* __restrict__ rgb1,
                                                    const float* __restrict__ noise1, float* __restrict__ wout1,
                                                    float noise_std, int S, int lane, CompositeOut& o0, CompositeOut& o1) {
-  float carry0 = 1.f, carry1 = 1.f;
-  float a0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, a1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // opacity, r, g, b, depth
+  RayAcc acc0, acc1;
   for (int base = 0; base < S; base += 64) {
     const int i = base + lane;
     const bool in = i < S;
@@ -287,23 +274,70 @@ __device__ __forceinline__ void composite_ray_pair(const float* __restrict__ z, 
       if (noise1) s1 = s1 + noise1[i] * noise_std;
       c0[0] = rgb0[i * 3]; c0[1] = rgb0[i * 3 + 1]; c0[2] = rgb0[i * 3 + 2];
       c1[0] = rgb1[i * 3]; c1[1] = rgb1[i * 3 + 1]; c1[2] = rgb1[i * 3 + 2];
-      al0 = 1.f - expf(-(last ? last_delta0 : dz) * fmaxf(s0, 0.f));
-      al1 = 1.f - expf(-(last ? 0.f : dz) * fmaxf(s1, 0.f));          // the instance set's last delta is 0 (rendering.py:213)
+      al0 = sample_alpha(last ? last_delta0 : dz, s0);
+      al1 = sample_alpha(last ? 0.f : dz, s1);                // the instance set's last delta is 0 (rendering.py:213)
     }
-    const float t0 = in ? (1.f - al0) + 1e-10f : 1.f, t1 = in ? (1.f - al1) + 1e-10f : 1.f;
-    const float incl0 = wave_scan_mul(t0, lane), incl1 = wave_scan_mul(t1, lane);
-    const float w0 = al0 * (carry0 * wave_shr1(incl0, 1.f)), w1 = al1 * (carry1 * wave_shr1(incl1, 1.f));
+    SegTotals lo0, hi0, lo1, hi1;
+    const float lw0 = segment_composite(al0, in, c0[0], c0[1], c0[2], zi, lane, lo0, hi0);
+    const float lw1 = segment_composite(al1, in, c1[0], c1[1], c1[2], zi, lane, lo1, hi1);
+    const float Tlo0 = acc0.step(lo0), Thi0 = acc0.step(hi0), Tlo1 = acc1.step(lo1), Thi1 = acc1.step(hi1);
     if (in) {
-      if (wout0) wout0[i] = w0;
-      if (wout1) wout1[i] = w1;
-      a0[0] += w0; a0[1] += w0 * c0[0]; a0[2] += w0 * c0[1]; a0[3] += w0 * c0[2]; a0[4] += w0 * zi;
-      a1[0] += w1; a1[1] += w1 * c1[0]; a1[2] += w1 * c1[1]; a1[3] += w1 * c1[2]; a1[4] += w1 * zi;
+      if (wout0) wout0[i] = (lane < 32 ? Tlo0 : Thi0) * lw0;
+      if (wout1) wout1[i] = (lane < 32 ? Tlo1 : Thi1) * lw1;
     }
-    carry0 = carry0 * wave_last(incl0);
-    carry1 = carry1 * wave_last(incl1);
   }
-  o0.opacity = wave_sum(a0[0]); o0.r = wave_sum(a0[1]); o0.g = wave_sum(a0[2]); o0.b = wave_sum(a0[3]); o0.depth = wave_sum(a0[4]);
-  o1.opacity = wave_sum(a1[0]); o1.r = wave_sum(a1[1]); o1.g = wave_sum(a1[2]); o1.b = wave_sum(a1[3]); o1.depth = wave_sum(a1[4]);
+  o0.opacity = acc0.opacity; o0.r = acc0.r; o0.g = acc0.g; o0.b = acc0.b; o0.depth = acc0.depth;
+  o1.opacity = acc1.opacity; o1.r = acc1.r; o1.g = acc1.g; o1.b = acc1.b; o1.depth = acc1.depth;
+}
+
+// Second half of the fused form: the MLP kernel's epilogue left per-sample local weights and per-segment records
+// (objnerf_mlp_args.comp_*); one wave per ray walks the segments in ascending order -- exactly RayAcc::step as in
+// composite_ray -- rescales the segment's weights in place and writes the maps.
+__global__ void __launch_bounds__(256) composite_finish_kernel(const float* __restrict__ rec, long n_rays, int S, int has_inst,
+                                                               int white_back, float* __restrict__ weights,
+                                                               float* __restrict__ opacity, float* __restrict__ rgb_map,
+                                                               float* __restrict__ depth, float* __restrict__ rgb_inst,
+                                                               float* __restrict__ depth_inst, float* __restrict__ opacity_inst,
+                                                               int inst_weights) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int nseg = S >> 5;
+  for (long ray = wave; ray < n_rays; ray += nwaves) {
+    RayAcc s, q;
+    float* w = weights + ray * S;
+    // lane l rescales sample l of segments l >> 5, l >> 5 + 2, ...: two segments per sweep of the wave
+    for (int j = 0; j < nseg; j += 2) {
+      const float* r0 = rec + (ray * nseg + j) * kSegRecFloats;
+      const bool two = j + 1 < nseg;
+      const float* r1 = two ? r0 + kSegRecFloats : r0;
+      const SegTotals a0{r0[0], r0[1], r0[2], r0[3], r0[4], r0[5]};
+      const SegTotals a1{two ? r1[0] : 1.f, two ? r1[1] : 0.f, two ? r1[2] : 0.f, two ? r1[3] : 0.f, two ? r1[4] : 0.f, two ? r1[5] : 0.f};
+      float Tlo = s.step(a0), Thi = s.step(a1);
+      if (has_inst) {
+        const SegTotals b0{r0[8], r0[9], r0[10], r0[11], r0[12], r0[13]};
+        const SegTotals b1{two ? r1[8] : 1.f, two ? r1[9] : 0.f, two ? r1[10] : 0.f, two ? r1[11] : 0.f, two ? r1[12] : 0.f, two ? r1[13] : 0.f};
+        const float Ql = q.step(b0), Qh = q.step(b1);
+        if (inst_weights) { Tlo = Ql; Thi = Qh; }
+      }
+      const int i = j * 32 + lane;
+      if (i < S) w[i] = (lane < 32 ? Tlo : Thi) * w[i];
+    }
+    if (lane == 0) {
+      opacity[ray] = s.opacity;
+      depth[ray] = s.depth;
+      rgb_map[ray * 3 + 0] = white_back ? s.r + 1.f - s.opacity : s.r;
+      rgb_map[ray * 3 + 1] = white_back ? s.g + 1.f - s.opacity : s.g;
+      rgb_map[ray * 3 + 2] = white_back ? s.b + 1.f - s.opacity : s.b;
+      if (has_inst) {
+        opacity_inst[ray] = q.opacity;
+        depth_inst[ray] = q.depth;
+        rgb_inst[ray * 3 + 0] = q.r + 1.f - q.opacity;      // always white-backed, rendering.py:223
+        rgb_inst[ray * 3 + 1] = q.g + 1.f - q.opacity;
+        rgb_inst[ray * 3 + 2] = q.b + 1.f - q.opacity;
+      }
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) composite_kernel(const objnerf_composite_args a) {
@@ -994,6 +1028,21 @@ int objnerf_points_in_boxes(const float* xyz, int64_t n, const double* boxes, in
   hipLaunchKernelGGL(points_in_boxes_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      xyz, (long)n, boxes, n_boxes, inside);
   return check_launch("points_in_boxes");
+}
+
+int objnerf_composite_finish(const float* seg_records, int64_t n_rays, int S, int has_instance, int inst_weights,
+                             int white_back, float* weights, float* opacity, float* rgb_map, float* depth, float* rgb_inst,
+                             float* depth_inst, float* opacity_inst, void* stream) {
+  if (n_rays < 0 || S < 32 || (S & 31)) return set_error(-1, "composite_finish: S must be a positive multiple of 32");
+  if (n_rays == 0) return 0;
+  if (!seg_records || !weights || !opacity || !rgb_map || !depth) return set_error(-1, "composite_finish: null pointer");
+  if (has_instance && (!rgb_inst || !depth_inst || !opacity_inst)) return set_error(-1, "composite_finish: instance outputs missing");
+  if (inst_weights && !has_instance) return set_error(-1, "composite_finish: inst_weights without the instance set");
+  const long waves = n_rays < 262144 ? n_rays : 262144;
+  hipLaunchKernelGGL(composite_finish_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, seg_records,
+                     (long)n_rays, S, has_instance != 0, white_back, weights, opacity, rgb_map, depth, rgb_inst, depth_inst,
+                     opacity_inst, inst_weights != 0);
+  return check_launch("composite_finish");
 }
 
 int objnerf_generate_rays_rows(int H, int W, float focal, const float* h_c2w, float near, float far, const double* h_box,

@@ -86,6 +86,16 @@ def mfma_mode():
     return m
 
 
+def composite_mode():
+    """Where a pass without occlusion mask / noise composites: "fused" (default; in the MLP kernel's epilogue, sigma / rgb
+    never written, include/objnerf_hip.h objnerf_mlp_args.comp_*) or "separate" (MLP kernel, then objnerf_composite).
+    Bit-equal results; the switch (environment variable OBJNERF_COMPOSITE) exists for that test and for A/B timing."""
+    m = os.environ.get("OBJNERF_COMPOSITE", "fused")
+    if m not in ("fused", "separate"):
+        raise RuntimeError("OBJNERF_COMPOSITE must be 'fused' or 'separate', got %r" % m)
+    return m
+
+
 def _train_packs(coarse, fine):
     mode = os.environ.get("OBJNERF_TRAIN_LAYERWISE", "")
     if mode == "1":
@@ -188,7 +198,8 @@ def render_rays(
         perturb=float(perturb), noise_std=float(noise_std), white_back=int(bool(white_back)),
         forward_instance=int(bool(forward_instance)), is_eval=int(is_eval),
         use_zero_as_last_delta=int(use_zero_as_last_delta), frustum_bound_th=float(frustum_bound_th),
-        rays_in_bbox=int(bool(rays_in_bbox)), mfma_bf16x3=int(mfma_mode() == "bf16x3"))
+        rays_in_bbox=int(bool(rays_in_bbox)), mfma_bf16x3=int(mfma_mode() == "bf16x3"),
+        separate_composite=int(composite_mode() == "separate"))
     l = _lib.lib()
     ws = torch.empty(l.objnerf_render_workspace_bytes(C.byref(cfg), n), dtype=torch.uint8, device=dev)
 

@@ -166,8 +166,18 @@ def test_c_abi_argument_validation():
     assert b"null weights" in l.objnerf_last_error()
     assert l.objnerf_sample_coarse(None, None, None, 0.0, 0, 4, 8, None, None) < 0
     assert l.objnerf_sample_pdf_merge(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None) < 0
-    cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
+    # workspace: sigma / rgb of both branches (32 B per sample) in the two-kernel form; only the 64-byte segment records
+    # per 32 samples when the passes composite in the MLP kernel's epilogue (no occlusion mask, no noise, S % 32 == 0)
+    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, separate_composite=1)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * 128 * 8 + 256
+    cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * (128 // 32) * _lib.SEG_REC_FLOATS + 256
+    for kw in (dict(noise_std=1.0), dict(is_eval=0, frustum_bound_th=0.025)):        # noise / occlusion mask: two-kernel form
+        c2 = _lib.RenderCfg(N_samples=64, N_importance=64, **kw)
+        assert l.objnerf_render_workspace_bytes(C.byref(c2), 1000) == 4 * 1000 * 128 * 8 + 256
+    # odd coarse count, fine count a multiple of 32: the coarse pass needs the two-kernel form, the fine pass does not
+    c3 = _lib.RenderCfg(N_samples=40, N_importance=24)
+    assert l.objnerf_render_workspace_bytes(C.byref(c3), 1000) == 4 * 1000 * 40 * 8 + 256
     # the multi-object entry points (round 2)
     assert l.objnerf_compact_rays(None, 10, 4, None, None, None, None) < 0 and b"compact_rays" in l.objnerf_last_error()
     assert l.objnerf_compact_scratch_ints(5000) == 5 + 1
@@ -204,6 +214,15 @@ def test_c_abi_argument_validation():
     a.emb_xyz = a.emb_dir = 64                                    # memory form
     a.n_points = 4
     assert l.objnerf_mlp_eval(C.byref(a), None) < 0 and b"fused form" in l.objnerf_last_error()
+    # compositing in the epilogue: fused form, scene branch, records, S % 32 == 0, no ray subset
+    b = _lib.MlpArgs()
+    b.blob = b.aux = b.rays = b.z_vals = 64
+    b.n_rays, b.S, b.do_scene, b.comp_w = 4, 40, 1, 64
+    assert l.objnerf_mlp_eval(C.byref(b), None) < 0 and b"comp_w needs" in l.objnerf_last_error()
+    b.S, b.comp_rec, b.do_scene, b.do_object = 64, 64, 0, 1
+    assert l.objnerf_mlp_eval(C.byref(b), None) < 0 and b"comp_w needs" in l.objnerf_last_error()
+    assert l.objnerf_composite_finish(None, 4, 40, 0, 0, 0, None, None, None, None, None, None, None, None) < 0
+    assert b"multiple of 32" in l.objnerf_last_error()
 
 
 def test_library_never_allocates_or_synchronises():

@@ -331,3 +331,38 @@ def test_full_frame_multi_properties():
     # and the golden pixels still match the reference
     g = cases.load_golden("multi_bench_edit_demo")
     grade_multi({k: v[pix] for k, v in r.items()}, g, "bench edit demo (pixels of the full frame)")
+
+
+FUSED_CASES = ["voxel_eval", "plain_eval", "voxel_scene_only", "voxel_disp_zero", "voxel_imp128", "plain_odd_sizes",
+               "bench_toydesk2", "bench_scannet_multi"]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_compositing_is_bit_equal_to_the_two_kernel_form(case, monkeypatch):
+    """Eval-mode passes composite in the MLP kernel's epilogue (sigma / rgb never written; objnerf_mlp_args.comp_*,
+    objnerf_composite_finish); OBJNERF_COMPOSITE=separate forces MLP kernel -> workspace -> objnerf_composite.  Both go
+    through csrc/composite_seg.h, so every result -- weights, maps, and the fine depths sampled from the coarse weights --
+    is bit-equal, on a 19,200-ray batch (every workgroup walks several tiles; rays straddle tiles at 192 samples) with
+    white background on the toy-desk case.  plain_odd_sizes: the 40-sample coarse pass cannot fuse, the 64-sample fine pass does."""
+    c = cases.RENDER_CASES[case]
+    sc = scene(c["scene"])
+    kw = dict(c["kw"], perturb=0, noise_std=0)
+    if case == "bench_toydesk2":
+        kw["white_back"] = True
+    if "frame" in c:
+        rays = synth.preset_rays(cases.SCENES[c["scene"]][2], 160, 120)
+    else:
+        rays = synth.camera_rays(160, 120, far=c.get("far", 3.0))
+    n = rays.shape[0]
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": synth.per_ray_ids(n).to(DEV)})["embedding_instance"]
+        monkeypatch.setenv("OBJNERF_COMPOSITE", "separate")
+        a = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, **kw)
+        monkeypatch.setenv("OBJNERF_COMPOSITE", "fused")
+        b = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, **kw)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), "%s: fused compositing differs from the two-kernel form at %s" % (case, k)
+    monkeypatch.setenv("OBJNERF_COMPOSITE", "both")
+    with pytest.raises(RuntimeError), torch.no_grad():
+        A.render_rays(sc.models, sc.embeddings, rays[:8].to(DEV), embedding_instance=codes[:8], **kw)
