@@ -140,7 +140,7 @@ def test_every_split_of_the_editing_frame_reassembles_bit_equal():
     whole = fn(sets(), **kw)
     keys = ("rgb_fine", "depth_fine", "opacity_fine")
     spread = {}
-    for rb in (None, 4):
+    for rb in (None, 2):      # 2-row blocks of the 240-row frame = the 4-row blocks of the 480-row one (120 blocks, 15 per rank)
         sh = RayShards.rows(H, W, world, rb)
         hits = []
         for r in range(world):
@@ -151,4 +151,4 @@ def test_every_split_of_the_editing_frame_reassembles_bit_equal():
                 assert torch.equal(out[k], whole[k][idx]), (rb, r, k)
             hits.append(sum(float((s[:, 7] > 0).sum()) for s in local))
         spread[rb] = max(hits) / (sum(hits) / world) - 1.0
-    assert spread[4] < 0.05 < spread[None], spread        # bands: the object rows carry far more rays; blocks: within 5 %
+    assert spread[2] < 0.05 < spread[None], spread        # bands: the object rows carry far more rays; blocks: within 5 %
