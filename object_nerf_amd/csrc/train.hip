@@ -11,7 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include "layout.h"
+#include <stdlib.h>
 #include "gemm.h"
+#include "wgrad.h"
 #include "host_api.h"
 
 namespace objnerf {
@@ -138,7 +140,9 @@ int objnerf_gemm(const float* A, int64_t lda, int a_k_contig, const float* B, in
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points) {
   return (kWsScene + (do_object ? kWsObj : 0)) * n_points;
 }
-int64_t objnerf_train_scratch_floats(int64_t n_points) { return (kWsScene + kWsObj) * n_points; }
+// gradients w.r.t. every layer's pre-activation output (the activation workspace's layout), then the partial tiles of
+// the grouped weight-gradient pass (wgrad.h)
+int64_t objnerf_train_scratch_floats(int64_t n_points) { return (kWsScene + kWsObj) * n_points + wgrad_scratch_floats(n_points); }
 
 int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
   if (!a || !a->h_params || !a->emb_xyz || !a->emb_dir || !a->workspace || !a->sigma || !a->rgb)
@@ -280,49 +284,59 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     }
   }
 
-  // ---- phase B: weight / bias gradients (dW = dY^T X, split over the points) and the gradients w.r.t. the inputs ----
+  // ---- phase B: weight / bias gradients dW = dY^T X.  All products of the pass go into ONE work list and one persistent,
+  // deterministic stream-K launch (wgrad.h); OBJNERF_WGRAD=atomic keeps round 2's one split-K launch with atomic
+  // accumulation per product (developer A/B switch) ----
+  static const bool atomic_wgrad = [] { const char* e = getenv("OBJNERF_WGRAD"); return e && !strcmp(e, "atomic"); }();
+  WgradBatch batch;
+  auto wgrad = [&](const float* dY, long lddy, const float* Xo, long ldx, long /*P*/, int out, int in, float* dW, long ldw, float* db = nullptr) {
+    if (atomic_wgrad) { lin_wgrad(c, dY, lddy, Xo, ldx, P, out, in, dW, ldw, db); return; }
+    if (out <= 3) batch.add_head(dY, out, Xo, ldx, in, dW, ldw, db);
+    else batch.add(dY, lddy, Xo, ldx, out, in, dW, ldw, db);
+  };
   // scene heads and the direction layer (cat([final, emb_dir]) as column blocks)
-  lin_wgrad(c, t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128, gB(P_SRGB));
-  lin_wgrad(c, d.dirh(), 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC, gB(P_SD));
-  lin_wgrad(c, d.dirh(), 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
-  lin_wgrad(c, d.final_(), 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256, gB(P_SF));
-  lin_wgrad(c, d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256, gB(P_SSIG));
+  wgrad(t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128, gB(P_SRGB));
+  wgrad(d.dirh(), 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC, gB(P_SD));
+  wgrad(d.dirh(), 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
+  wgrad(d.final_(), 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256, gB(P_SF));
+  wgrad(d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256, gB(P_SSIG));
   for (int l = 8; l >= 1; --l) {
     float* db = gB(P_S1 + l - 1);
     if (l == 5) {          // cat([input_xyz, h])
-      lin_wgrad(c, d.A(5), 256, X, cx, P, 256, cx, gW(P_S5), cx + 256, db);
-      lin_wgrad(c, d.A(5), 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
+      wgrad(d.A(5), 256, X, cx, P, 256, cx, gW(P_S5), cx + 256, db);
+      wgrad(d.A(5), 256, w.A(4), 256, P, 256, 256, gW(P_S5) + cx, cx + 256);
     } else if (l == 1) {
-      lin_wgrad(c, d.A(1), 256, X, cx, P, 256, cx, gW(P_S1), cx, db);
+      wgrad(d.A(1), 256, X, cx, P, 256, cx, gW(P_S1), cx, db);
     } else {
-      lin_wgrad(c, d.A(l), 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256, db);
+      wgrad(d.A(l), 256, w.A(l - 1), 256, P, 256, 256, gW(P_S1 + l - 1), 256, db);
     }
   }
   if (obj) {
     const int ov = vox ? kObjVoxPE : 0;
-    lin_wgrad(c, t2i, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64, gB(P_ORGB));
-    lin_wgrad(c, d.odirh(), 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC, gB(P_OD));
-    lin_wgrad(c, d.odirh(), 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
-    lin_wgrad(c, d.ofinal(), 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128, gB(P_OF));
-    lin_wgrad(c, d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128, gB(P_OSIG));
+    wgrad(t2i, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64, gB(P_ORGB));
+    wgrad(d.odirh(), 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC, gB(P_OD));
+    wgrad(d.odirh(), 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
+    wgrad(d.ofinal(), 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128, gB(P_OF));
+    wgrad(d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128, gB(P_OSIG));
     // one layer fed by cat([emb_xyz, obj_voxel, obj_code]): three column blocks of its weight
     auto obj_in_bwd = [&](const float* dY, int wid, int ldw, float* db) {
-      lin_wgrad(c, dY, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
-      if (vox) lin_wgrad(c, dY, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
-      lin_wgrad(c, dY, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
+      wgrad(dY, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
+      if (vox) wgrad(dY, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
+      wgrad(dY, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
     };
     for (int l = 4; l >= 1; --l) {
       float* db = gB(P_O1 + l - 1);
       if (l == 3) {        // cat([input_x, x_])
-        lin_wgrad(c, d.B(3), 128, w.B(2), 128, P, 128, 128, gW(P_O3) + co, co + 128);
+        wgrad(d.B(3), 128, w.B(2), 128, P, 128, 128, gW(P_O3) + co, co + 128);
         obj_in_bwd(d.B(3), P_O3, co + 128, db);
       } else if (l == 1) {
         obj_in_bwd(d.B(1), P_O1, co, db);
       } else {
-        lin_wgrad(c, d.B(l), 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128, db);
+        wgrad(d.B(l), 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128, db);
       }
     }
   }
+  if (!atomic_wgrad && !c.rc) c.rc = batch.launch(P, scratch + (kWsScene + kWsObj) * P, c.s);
   // ---- gradients w.r.t. the embeddings: every consumer layer's dY W block in one segmented product per input ----
   {
     const int ov = vox ? kObjVoxPE : 0;

@@ -1,0 +1,308 @@
+// wgrad.hip -- grouped, stream-K, deterministic weight gradients of one backward pass (wgrad.h).
+#include <hip/hip_runtime.h>
+#include "wgrad.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+// weighted k iterations of a tile: KT iterations of `ncol` quarter-tiles each
+__device__ __forceinline__ long tile_weight(const WgTile& t, long KT) { return KT * (long)t.ncol; }
+
+// The share of workgroup g: weighted range [W g / G, W (g + 1) / G).  A tile's k iterations [ka, kb) inside a weighted
+// range [lo, hi) are ceil((lo - start) / ncol) .. ceil((hi - start) / ncol): both neighbours of a boundary round it the
+// same way, so the pieces of a tile neither overlap nor leave a gap.
+struct Piece { long ka, kb; };
+__device__ __forceinline__ Piece piece_of(long start, int ncol, long KT, long lo, long hi) {
+  const long a = lo - start, b = hi - start;
+  long ka = a <= 0 ? 0 : (a + ncol - 1) / ncol;
+  long kb = b <= 0 ? 0 : (b + ncol - 1) / ncol;
+  if (ka > KT) ka = KT;
+  if (kb > KT) kb = KT;
+  return Piece{ka, kb};
+}
+
+template <bool TAIL>
+__device__ __forceinline__ void wgrad_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend, bool full,
+                                            float* slot, float* lds, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
+  const int ncol = TAIL ? tl.ncol : 4;
+  f32x16 acc[TAIL ? 3 : 4];
+#pragma unroll
+  for (int i = 0; i < (TAIL ? 3 : 4); ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float rsum = 0.f;
+  const bool want_rowsum = pr.rowsum != nullptr && tl.bx == 0;
+  GemmOperand<false> opa, opb;
+  opa.init(pr.A, pr.lda, m0, pr.M, kbeg, tid);
+  opb.init(pr.B, pr.ldb, n0, pr.N, kbeg, tid);
+  opa.fetch(kbeg, kend, tid);
+  opb.fetch(kbeg, kend, tid);
+  const int half = lane >> 5, rl = lane & 31;
+  float* As = lds;
+  float* Bs = lds + GTILE;
+  for (long k0 = kbeg; k0 < kend; k0 += GBK) {
+    const bool more = k0 + GBK < kend;
+    __syncthreads();                     // every wave is done reading the previous tile
+    opa.put(As, tid);
+    opb.put(Bs, tid);
+    __syncthreads();
+    if (more) {                          // next tile's global loads fly under this tile's MFMAs
+      opa.fetch(k0 + GBK, kend, tid);
+      opb.fetch(k0 + GBK, kend, tid);
+    }
+    if (want_rowsum) {                   // A' tile is [k][row]: thread -> row tid % 128, 16 of the 32 k
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) rsum += As[((tid >> 7) * 16 + kk) * GLDR + (tid & 127)];
+    }
+    if constexpr (TAIL) {
+      if (m0 + wave * 32 < pr.M) {       // wave-uniform: this wave's row sub-tile exists
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const f32x4 a = GemmOperand<false>::frag(As, wave * 32 + rl, half, s4);
+          f32x4 b[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (j < ncol) b[j] = GemmOperand<false>::frag(Bs, j * 32 + rl, half, s4);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              if (j < ncol) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j][s], acc[j], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {   // 4 MFMA steps per fragment read
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = GemmOperand<false>::frag(As, wm * 64 + i * 32 + rl, half, s4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = GemmOperand<false>::frag(Bs, wn * 64 + j * 32 + rl, half, s4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[2 * i + j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                       // the next piece's first tile overwrites the LDS buffers
+  // row sums: the two 16-k halves of a row live in threads tid and tid + 128: combine through LDS (fixed order)
+  if (want_rowsum) {
+    if (tid >= 128) lds[tid - 128] = rsum;
+    __syncthreads();
+    if (tid < 128) {
+      const float v = rsum + lds[tid];
+      if (full) { if (m0 + tid < pr.M) pr.rowsum[m0 + tid] += v; }
+      else slot[128 * 128 + tid] = v;
+    }
+    __syncthreads();
+  }
+  // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Destination: the tile of dW itself when
+  // this workgroup contracted the whole K range (sole owner: plain read-modify-write), else the partial slot.
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
+  float* dst = full ? pr.C + m0 * pr.ldc + n0 : slot;
+  const long ld = full ? pr.ldc : 128;
+  const int mlim = full ? (int)(pr.M - m0) : 128, nlim = full ? (int)(pr.N - n0) : 128;
+#pragma unroll
+  for (int t = 0; t < (TAIL ? 3 : 4); ++t) {
+    const int i = t >> 1, j = t & 1;
+    if (TAIL && t >= ncol) continue;
+    const int nl = TAIL ? t * 32 + col : wn * 64 + j * 32 + col;           // column inside the tile
+    if (nl >= nlim) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (TAIL ? wave * 32 : wm * 64 + i * 32) + (r & 3) + 8 * (r >> 2) + rbase;
+      if (ml >= mlim) continue;
+      float* q = dst + ml * ld + nl;
+      *q = full ? *q + acc[t][r] : acc[t][r];
+    }
+  }
+}
+
+// The lists travel as kernel arguments (no device copy to enqueue, no allocation) and are parked in device memory by this
+// one-workgroup kernel: indexing a by-value argument struct with a run-time index would make every kernel that does it
+// keep a private copy of the 2.5 KB struct in scratch memory.
+__global__ void __launch_bounds__(256) wgrad_list_kernel(const WgradArgs a, WgradArgs* __restrict__ out) {
+  const unsigned* src = (const unsigned*)&a;
+  unsigned* dst = (unsigned*)out;
+  for (unsigned i = threadIdx.x; i < sizeof(WgradArgs) / 4; i += 256) dst[i] = src[i];
+}
+
+// TAIL = false: the full tiles of the list ([0, nfull)), TAIL = true: the ragged ones ([nfull, ntile)); one persistent
+// launch each (one code path per kernel keeps it at 3 workgroups per CU), slots of the second launch behind the first's.
+template <bool TAIL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) wgrad_streamk_kernel(const WgradArgs* __restrict__ ap) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * GTILE];
+  const WgradArgs& a = *ap;
+  const int tid = threadIdx.x;
+  const long KT = (a.P + GBK - 1) / GBK;
+  const int t0 = TAIL ? a.nfull : 0, t1 = TAIL ? a.ntile : a.nfull;
+  long W = 0;
+  for (int t = t0; t < t1; ++t) W += tile_weight(a.tile[t], KT);
+  const long g = blockIdx.x, G = gridDim.x;
+  const long lo = W * g / G, hi = W * (g + 1) / G;
+  float* slots = a.partials + (TAIL ? (long)kWgradGrid * 2 * kWgradSlotFloats : 0);
+  long start = 0;
+  int nslot = 0;
+  for (int t = t0; t < t1 && start < hi; ++t) {
+    const WgTile tl = a.tile[t];
+    const long w = tile_weight(tl, KT);
+    if (start + w > lo) {
+      const Piece pc = piece_of(start, tl.ncol, KT, lo, hi);
+      if (pc.ka < pc.kb) {               // uniform per workgroup
+        const bool full = pc.ka == 0 && pc.kb == KT;
+        float* slot = slots + (g * 2 + nslot) * kWgradSlotFloats;
+        const long kbeg = pc.ka * GBK, kend = pc.kb * GBK < a.P ? pc.kb * GBK : a.P;
+        wgrad_piece<TAIL>(a.prod[tl.prod], tl, kbeg, kend, full, slot, lds, tid);
+        if (!full) ++nslot;
+      }
+    }
+    start += w;
+  }
+}
+
+// One workgroup per tile: adds the partial slots of the tile in ascending workgroup order (the k ranges ascend with it).
+__global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __restrict__ ap) {
+  const WgradArgs& a = *ap;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const long KT = (a.P + GBK - 1) / GBK;
+  const bool tail = t >= a.nfull;
+  const int t0 = tail ? a.nfull : 0, t1 = tail ? a.ntile : a.nfull;
+  const long G = tail ? kWgradTailGrid : kWgradGrid;
+  const float* slots = a.partials + (tail ? (long)kWgradGrid * 2 * kWgradSlotFloats : 0);
+  long W = 0, start = 0;
+  for (int i = t0; i < t1; ++i) {
+    if (i == t) start = W;
+    W += tile_weight(a.tile[i], KT);
+  }
+  const WgTile tl = a.tile[t];
+  const WgProduct pr = a.prod[tl.prod];
+  const long w = tile_weight(tl, KT);
+  // workgroups whose share touches [start, start + w)
+  long g0 = start * G / W;
+  while (g0 > 0 && W * g0 / G > start) --g0;
+  float acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+  float rs = 0.f;
+  bool any = false;
+  for (long g = g0; g < G; ++g) {
+    const long lo = W * g / G, hi = W * (g + 1) / G;
+    if (lo >= start + w) break;
+    const Piece pc = piece_of(start, tl.ncol, KT, lo, hi);
+    if (pc.ka >= pc.kb || (pc.ka == 0 && pc.kb == KT)) continue;       // nothing of this tile, or the sole owner (added directly)
+    // the slot index the main kernel used: 0 unless an earlier tile of that workgroup's share was also partial
+    int nslot = 0;
+    {
+      long s2 = 0;
+      for (int i = t0; i < t; ++i) {
+        const long w2 = tile_weight(a.tile[i], KT);
+        if (s2 + w2 > lo && s2 < hi) {
+          const Piece p2 = piece_of(s2, a.tile[i].ncol, KT, lo, hi);
+          if (p2.ka < p2.kb && !(p2.ka == 0 && p2.kb == KT)) ++nslot;
+        }
+        s2 += w2;
+      }
+    }
+    const float* slot = slots + (g * 2 + nslot) * kWgradSlotFloats;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] += slot[i * 256 + tid];
+    if (tid < 128) rs += slot[128 * 128 + tid];
+    any = true;
+  }
+  if (!any) return;
+  const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int e = i * 256 + tid, ml = e >> 7, nl = e & 127;
+    if (m0 + ml < pr.M && n0 + nl < pr.N && nl < 32 * (int)tl.ncol) pr.C[(m0 + ml) * pr.ldc + n0 + nl] += acc[i];
+  }
+  if (pr.rowsum && tl.bx == 0 && tid < 128 && m0 + tid < pr.M) pr.rowsum[m0 + tid] += rs;
+}
+
+// ---- the 1- and 3-row heads on the VALU ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) heads_wgrad_kernel(const HeadArgs a) {
+  const HeadItem h = a.h[blockIdx.y];
+  const int tid = threadIdx.x;
+  const long p0 = (long)blockIdx.x * kHeadChunk, p1 = p0 + kHeadChunk < a.P ? p0 + kHeadChunk : a.P;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, b = 0.f;
+  if (tid < h.ni) {
+    for (long p = p0; p < p1; ++p) {
+      const float x = h.X[p * h.ldx + tid];
+      s0 += h.dY[p * h.no] * x;
+      if (h.no > 1) { s1 += h.dY[p * h.no + 1] * x; s2 += h.dY[p * h.no + 2] * x; }
+    }
+  }
+  if (tid < h.no) for (long p = p0; p < p1; ++p) b += h.dY[p * h.no + tid];
+  float* slot = a.partials + ((long)blockIdx.y * a.nchunks + blockIdx.x) * kHeadSlotFloats;
+  slot[tid] = s0; slot[256 + tid] = s1; slot[512 + tid] = s2;
+  if (tid < 3) slot[768 + tid] = b;
+}
+__global__ void __launch_bounds__(256) heads_fixup_kernel(const HeadArgs a) {
+  const HeadItem h = a.h[blockIdx.x];
+  const int tid = threadIdx.x;
+  float s[3] = {0.f, 0.f, 0.f}, b = 0.f;
+  for (int c = 0; c < a.nchunks; ++c) {
+    const float* slot = a.partials + ((long)blockIdx.x * a.nchunks + c) * kHeadSlotFloats;
+    s[0] += slot[tid]; s[1] += slot[256 + tid]; s[2] += slot[512 + tid];
+    if (tid < 3) b += slot[768 + tid];
+  }
+  if (tid < h.ni)
+    for (int o = 0; o < h.no; ++o) h.dW[o * h.ldw + tid] += s[o];
+  if (h.db && tid < h.no) h.db[tid] += b;
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------
+void WgradBatch::add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db) {
+  if (a.nprod >= kWgradMaxProducts) { overflow = true; return; }
+  const int pi = a.nprod++;
+  a.prod[pi] = WgProduct{dY, lddy, X, ldx, dW, ldw, db, out, in};
+  const int ny = (out + GBM - 1) / GBM, nx = (in + GBN - 1) / GBN;
+  for (int by = 0; by < ny; ++by)
+    for (int bx = 0; bx < nx; ++bx) {
+      if (a.ntile >= kWgradMaxTiles) { overflow = true; return; }
+      const int cols = in - bx * GBN < GBN ? in - bx * GBN : GBN;
+      const int sub = (cols + 31) / 32;                          // live 32-column sub-tiles
+      const WgTile tl{(unsigned char)pi, (unsigned char)by, (unsigned char)bx, (unsigned char)(sub >= 4 ? 4 : sub)};
+      if (tl.ncol == 4) {                                        // full tiles first, ragged ones behind them
+        for (int i = a.ntile; i > a.nfull; --i) a.tile[i] = a.tile[i - 1];
+        a.tile[a.nfull++] = tl;
+        ++a.ntile;
+      } else {
+        a.tile[a.ntile++] = tl;
+      }
+    }
+}
+void WgradBatch::add_head(const float* dY, int no, const float* X, long ldx, int ni, float* dW, long ldw, float* db) {
+  if (h.nheads >= kMaxHeads || no > 3 || ni > 256) { overflow = true; return; }
+  h.h[h.nheads++] = HeadItem{dY, X, dW, db, ldx, ldw, no, ni};
+}
+int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
+  if (overflow) return set_error(-3, "wgrad: work list overflow");
+  if (P <= 0) return 0;
+  a.P = P;
+  a.partials = scratch;
+  if (a.ntile > 0) {
+    static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
+    WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
+    hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
+    if (a.nfull > 0) hipLaunchKernelGGL(wgrad_streamk_kernel<false>, dim3(kWgradGrid), dim3(256), 0, s, (const WgradArgs*)dev);
+    if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_streamk_kernel<true>, dim3(kWgradTailGrid), dim3(256), 0, s, (const WgradArgs*)dev);
+    hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile), dim3(256), 0, s, (const WgradArgs*)dev);
+  }
+  if (h.nheads > 0) {
+    h.P = P;
+    h.nchunks = (int)((P + kHeadChunk - 1) / kHeadChunk);
+    h.partials = scratch + (long)(kWgradGrid + kWgradTailGrid) * 2 * kWgradSlotFloats;
+    hipLaunchKernelGGL(heads_wgrad_kernel, dim3(h.nchunks, h.nheads), dim3(256), 0, s, h);
+    hipLaunchKernelGGL(heads_fixup_kernel, dim3(h.nheads), dim3(256), 0, s, h);
+  }
+  return check_launch("wgrad");
+}
+
+}  // namespace objnerf
