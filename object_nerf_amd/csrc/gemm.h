@@ -45,6 +45,9 @@ struct GemmArgs {
   long segK[4];
 };
 
+// a 16-byte load of four consecutive floats at ANY 4-byte-aligned address: gfx950 global loads need dword alignment only,
+// so rows of 271 / 439 / 527 / 27 floats (the embedding blocks and their weight columns) still move as dwordx4
+typedef f32x4 f32x4u __attribute__((aligned(4)));
 constexpr int GBM = 128, GBN = 128, GBK = 32;
 constexpr int GLDK = 36;      // K-contiguous operands sit in LDS as [row][k], rows padded to 36 floats against bank conflicts
 constexpr int GLDR = 128;     // row-contiguous operands sit in LDS as [k][row]
@@ -91,6 +94,7 @@ struct GemmOperand {
   long rows_left;        // row-contiguous: rows - (first of this thread's 4 rows); K-contiguous: unused
   bool ok[4];            // K-contiguous: piece's row is inside the operand
   bool fast;             // uniform: every full k tile can be fetched with unconditional 16-byte loads
+  bool aligned;          // ... whose addresses are 16-byte aligned (else the unaligned-vector form of the same load)
   f32x4 v[4];
 
   __device__ __forceinline__ void init(const float* src, long ld, long row0, long rows, long kbeg, int tid) {
@@ -106,7 +110,8 @@ struct GemmOperand {
       }
       step = GBK;
       rows_left = 0;
-      fast = vec;
+      fast = true;
+      aligned = vec;
     } else {
       // thread -> k = tid/32 + 8 i, rows 4 (tid % 32) .. + 3
       const long r = row0 + 4 * (tid & 31);
@@ -117,15 +122,21 @@ struct GemmOperand {
         p[i] = src + (kbeg + (tid >> 5) + 8 * i) * ld + (rows_left > 0 ? r : 0);
       }
       step = GBK * ld;
-      fast = vec && row0 + GBM <= rows;
+      fast = row0 + GBM <= rows;
+      aligned = vec;
     }
   }
   // k0: first k of the tile being fetched.  The contraction range must be zero-filled in BOTH operands
   // (0 x garbage could be NaN), which only the last tile of a split needs.
   __device__ __forceinline__ void fetch(long k0, long kend, int tid) {
-    if (fast && k0 + GBK <= kend) {            // uniform branch
+    if (fast && k0 + GBK <= kend) {            // uniform branches
+      if (aligned) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)p[i];
+        for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)p[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(const f32x4u*)p[i];
+      }
     } else if (K_CONTIG) {
       const long gk = k0 + 4 * (tid & 7);
 #pragma unroll

@@ -49,7 +49,7 @@ struct HeadItem {              // dW (no x ni) += dY^T (no x P) X (P x ni), db (
   long ldx, ldw;
   int no, ni;
 };
-constexpr int kHeadChunk = 2048;                      // points per workgroup of heads_wgrad_kernel
+constexpr int kHeadChunk = 512;                      // points per workgroup of heads_wgrad_kernel
 constexpr int kHeadSlotFloats = 4 * 256;              // rows 0..2: partial dW[o][:], row 3: partial db[0..2]
 constexpr int kMaxHeads = 4;
 struct HeadArgs {

@@ -169,7 +169,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 // One workgroup per tile: adds the partial slots of the tile in ascending workgroup order (the k ranges ascend with it).
 __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __restrict__ ap) {
   const WgradArgs& a = *ap;
-  const int t = blockIdx.x, tid = threadIdx.x;
+  // blockIdx.y: which eighth of the tile's 16,384 elements (8 x 256 threads x 8 elements)
+  const int t = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
   const long KT = (a.P + GBK - 1) / GBK;
   const bool tail = t >= a.nfull;
   const int t0 = tail ? a.nfull : 0, t1 = tail ? a.ntile : a.nfull;
@@ -186,9 +187,9 @@ __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __res
   // workgroups whose share touches [start, start + w)
   long g0 = start * G / W;
   while (g0 > 0 && W * g0 / G > start) --g0;
-  float acc[64];
+  float acc[8];
 #pragma unroll
-  for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   float rs = 0.f;
   bool any = false;
   for (long g = g0; g < G; ++g) {
@@ -211,18 +212,18 @@ __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __res
     }
     const float* slot = slots + (g * 2 + nslot) * kWgradSlotFloats;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) acc[i] += slot[i * 256 + tid];
-    if (tid < 128) rs += slot[128 * 128 + tid];
+    for (int i = 0; i < 8; ++i) acc[i] += slot[(part * 8 + i) * 256 + tid];
+    if (part == 0 && tid < 128) rs += slot[128 * 128 + tid];
     any = true;
   }
   if (!any) return;
   const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
 #pragma unroll
-  for (int i = 0; i < 64; ++i) {
-    const int e = i * 256 + tid, ml = e >> 7, nl = e & 127;
+  for (int i = 0; i < 8; ++i) {
+    const int e = (part * 8 + i) * 256 + tid, ml = e >> 7, nl = e & 127;
     if (m0 + ml < pr.M && n0 + nl < pr.N && nl < 32 * (int)tl.ncol) pr.C[(m0 + ml) * pr.ldc + n0 + nl] += acc[i];
   }
-  if (pr.rowsum && tl.bx == 0 && tid < 128 && m0 + tid < pr.M) pr.rowsum[m0 + tid] += rs;
+  if (part == 0 && pr.rowsum && tl.bx == 0 && tid < 128 && m0 + tid < pr.M) pr.rowsum[m0 + tid] += rs;
 }
 
 // ---- the 1- and 3-row heads on the VALU ---------------------------------------------------------------------------
@@ -231,11 +232,26 @@ __global__ void __launch_bounds__(256) heads_wgrad_kernel(const HeadArgs a) {
   const int tid = threadIdx.x;
   const long p0 = (long)blockIdx.x * kHeadChunk, p1 = p0 + kHeadChunk < a.P ? p0 + kHeadChunk : a.P;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, b = 0.f;
+  // thread = input column; 8 points per trip so that 8 row loads are in flight (the loop is latency-bound otherwise);
+  // the sums stay sequential in p: fixed order
   if (tid < h.ni) {
-    for (long p = p0; p < p1; ++p) {
-      const float x = h.X[p * h.ldx + tid];
-      s0 += h.dY[p * h.no] * x;
-      if (h.no > 1) { s1 += h.dY[p * h.no + 1] * x; s2 += h.dY[p * h.no + 2] * x; }
+    const float* x = h.X + tid;
+    long p = p0;
+    for (; p + 8 <= p1; p += 8) {
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = x[(p + u) * h.ldx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* dy = h.dY + (p + u) * h.no;
+        s0 += dy[0] * xv[u];
+        if (h.no > 1) { s1 += dy[1] * xv[u]; s2 += dy[2] * xv[u]; }
+      }
+    }
+    for (; p < p1; ++p) {
+      const float xv = x[p * h.ldx];
+      s0 += h.dY[p * h.no] * xv;
+      if (h.no > 1) { s1 += h.dY[p * h.no + 1] * xv; s2 += h.dY[p * h.no + 2] * xv; }
     }
   }
   if (tid < h.no) for (long p = p0; p < p1; ++p) b += h.dY[p * h.no + tid];
@@ -293,7 +309,7 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
     hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
     if (a.nfull > 0) hipLaunchKernelGGL(wgrad_streamk_kernel<false>, dim3(kWgradGrid), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_streamk_kernel<true>, dim3(kWgradTailGrid), dim3(256), 0, s, (const WgradArgs*)dev);
-    hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile), dim3(256), 0, s, (const WgradArgs*)dev);
+    hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);
   }
   if (h.nheads > 0) {
     h.P = P;
