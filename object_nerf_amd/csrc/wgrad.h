@@ -1,16 +1,15 @@
-// wgrad.h -- ONE launch for all weight-gradient products of a model's backward.
+// wgrad.h -- all weight-gradient products of a model's backward in one grouped, deterministic pass.
 //
 // dW_l = dY_l^T X_l for the 20 Linear layers of an ObjectNeRF (28 products: the torch.cat inputs are column blocks): each
 // product has only 1-6 output tiles of 128 x 128 but contracts over 10^5..10^6 sample points.  Round 2 launched one
-// split-K GEMM per product (~70 launches per step incl. the ragged-tile launches), each workgroup contracting ~1024 points
-// and then adding its 128 x 128 tile with 16K fp32 atomics: the atomic epilogues cost a third of the MFMA time, and the
-// sums were not reproducible run to run.  Here:
-//   * a list of output tiles over ALL products, each weighted by its k iterations x live 32-column sub-tiles;
-//   * a persistent grid (kWgradGrid workgroups); workgroup g takes the g-th equal share of the weighted list -- a
-//     contiguous run of k iterations that may end one tile and begin the next ("stream-K");
-//   * a tile contracted entirely by one workgroup is added to dW directly; otherwise the partial tile goes to a scratch
-//     slot and wgrad_fixup_kernel adds a tile's slots in ascending workgroup order: bit-reproducible gradients, and
-//     <= 2 partial tiles per workgroup instead of one atomic tile per 1024 points;
+// split-K GEMM per product (~70 launches per step incl. the ragged-tile launches) whose workgroups added their tiles with
+// fp32 atomics: sums in arrival order, not reproducible run to run.  Here:
+//   * ONE list of output tiles over all products; work unit = (tile, slice of ~4096 points), numbered so that the
+//     workgroups resident together contract the same points for the neighbouring tiles of one product (operand panels
+//     come from HBM once and are re-read from L2);
+//   * every unit leaves its partial tile in its own scratch slot and wgrad_fixup_kernel adds a tile's slices in ascending
+//     order: bit-reproducible gradients (tests/test_gpu_train.py), no atomics;
+//   * two launches (full tiles, ragged tiles) + the fix-up per backward pass instead of ~35;
 //   * the 1- and 3-row head products (sigma, rgb) are not MFMA work (a 128-row tile would be 97-99 % empty):
 //     heads_wgrad_kernel reduces them on the VALU, also through ordered partial sums.
 // The MFMA loop and the operand staging are gemm.h's (both operands row-contiguous: A' = dY^T, B' = X).
@@ -31,8 +30,7 @@ struct WgTile {                // one output tile: rows [128 by, +128), columns 
   unsigned char ncol;          // 4: full tile (2 x 2 waves of 2 x 2 MFMA tiles); 1..3: ragged last column tile with that many
                                // live 32-column sub-tiles (4 x 1 waves, one row sub-tile each): ncol / 4 of a full tile's work
 };
-constexpr int kWgradGrid = 768;                       // full tiles: 3 workgroups per CU (36 KiB of LDS, ~150 registers each)
-constexpr int kWgradTailGrid = 256;                   // ragged tiles (about a twentieth of the work): a second persistent launch
+constexpr int kWgradMaxSlices = 64;                    // k slices per tile (~4096 points each, fewer and longer beyond 262,144 points)
 constexpr int kWgradMaxProducts = 32;
 constexpr int kWgradMaxTiles = 96;
 constexpr long kWgradSlotFloats = 128 * 128 + 128;    // a partial tile + its partial row sums
@@ -41,7 +39,7 @@ struct WgradArgs {             // passed by value (2.5 KB of kernel arguments: n
   WgTile tile[kWgradMaxTiles];
   int nprod, ntile, nfull;     // tile[0 .. nfull) are full tiles, tile[nfull .. ntile) ragged ones
   long P;
-  float* partials;             // (kWgradGrid + kWgradTailGrid) x 2 slots of kWgradSlotFloats
+  float* partials;             // slot (tile t, slice z) at (t * slices + z) * kWgradSlotFloats
 };
 
 struct HeadItem {              // dW (no x ni) += dY^T (no x P) X (P x ni), db (no) += column sums of dY; no <= 3, ni <= 256
@@ -49,7 +47,7 @@ struct HeadItem {              // dW (no x ni) += dY^T (no x P) X (P x ni), db (
   long ldx, ldw;
   int no, ni;
 };
-constexpr int kHeadChunk = 512;                      // points per workgroup of heads_wgrad_kernel
+constexpr int kHeadChunk = 2048;                      // points per workgroup of heads_wgrad_kernel
 constexpr int kHeadSlotFloats = 4 * 256;              // rows 0..2: partial dW[o][:], row 3: partial db[0..2]
 constexpr int kMaxHeads = 4;
 struct HeadArgs {
@@ -61,9 +59,15 @@ struct HeadArgs {
 
 // floats of scratch the grouped weight-gradient pass needs for P points (appended to the dgrad scratch, train.hip)
 constexpr long kWgradListFloats = 1024;               // device copy of the WgradArgs lists (<= 4 KB), at the end
+// number of k slices of every tile: ~128 k iterations (4096 points) each, at most kWgradMaxSlices
+__host__ __device__ inline int wgrad_slices(long P) {
+  const long KT = (P + GBK - 1) / GBK;
+  const long nz = (KT + 127) / 128;
+  return (int)(nz < 1 ? 1 : (nz > kWgradMaxSlices ? kWgradMaxSlices : nz));
+}
+inline long wgrad_slot_floats(long P) { return (long)kWgradMaxTiles * wgrad_slices(P) * kWgradSlotFloats; }
 inline long wgrad_scratch_floats(long P) {
-  return (long)(kWgradGrid + kWgradTailGrid) * 2 * kWgradSlotFloats + (long)kMaxHeads * ((P + kHeadChunk - 1) / kHeadChunk) * kHeadSlotFloats +
-         kWgradListFloats;
+  return wgrad_slot_floats(P) + (long)kMaxHeads * ((P + kHeadChunk - 1) / kHeadChunk) * kHeadSlotFloats + kWgradListFloats;
 }
 
 // host side: collects the products of one backward pass, then three launches on the stream

@@ -5,22 +5,6 @@
 
 namespace objnerf {
 
-// weighted k iterations of a tile: KT iterations of `ncol` quarter-tiles each
-__device__ __forceinline__ long tile_weight(const WgTile& t, long KT) { return KT * (long)t.ncol; }
-
-// The share of workgroup g: weighted range [W g / G, W (g + 1) / G).  A tile's k iterations [ka, kb) inside a weighted
-// range [lo, hi) are ceil((lo - start) / ncol) .. ceil((hi - start) / ncol): both neighbours of a boundary round it the
-// same way, so the pieces of a tile neither overlap nor leave a gap.
-struct Piece { long ka, kb; };
-__device__ __forceinline__ Piece piece_of(long start, int ncol, long KT, long lo, long hi) {
-  const long a = lo - start, b = hi - start;
-  long ka = a <= 0 ? 0 : (a + ncol - 1) / ncol;
-  long kb = b <= 0 ? 0 : (b + ncol - 1) / ncol;
-  if (ka > KT) ka = KT;
-  if (kb > KT) kb = KT;
-  return Piece{ka, kb};
-}
-
 template <bool TAIL>
 __device__ __forceinline__ void wgrad_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend, bool full,
                                             float* slot, float* lds, int tid) {
@@ -133,97 +117,66 @@ __global__ void __launch_bounds__(256) wgrad_list_kernel(const WgradArgs a, Wgra
   for (unsigned i = threadIdx.x; i < sizeof(WgradArgs) / 4; i += 256) dst[i] = src[i];
 }
 
-// TAIL = false: the full tiles of the list ([0, nfull)), TAIL = true: the ragged ones ([nfull, ntile)); one persistent
-// launch each (one code path per kernel keeps it at 3 workgroups per CU), slots of the second launch behind the first's.
+// One workgroup per UNIT = (tile, k slice).  TAIL = false: the full tiles of the list ([0, nfull)), TAIL = true: the
+// ragged ones ([nfull, ntile)), one launch each (one code path per kernel keeps it at 3 workgroups per CU).  Units are
+// numbered product by product, inside a product slice by slice, inside a slice tile by tile: workgroups that are resident
+// together contract the SAME points for the neighbouring tiles of one product, so each 32-point panel of dY / X is
+// fetched from HBM once and re-read from L2 (a tile-major order -- every workgroup a different k range of one tile --
+// streamed the operands 4-6 times: measured HBM-bound).  Every unit leaves its partial tile in its own slot.
 template <bool TAIL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) wgrad_streamk_kernel(const WgradArgs* __restrict__ ap) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) wgrad_units_kernel(const WgradArgs* __restrict__ ap) {
   __shared__ __attribute__((aligned(16))) float lds[2 * GTILE];
   const WgradArgs& a = *ap;
   const int tid = threadIdx.x;
   const long KT = (a.P + GBK - 1) / GBK;
+  const int nz = wgrad_slices(a.P);
+  const long L = (KT + nz - 1) / nz;                       // k iterations per slice
   const int t0 = TAIL ? a.nfull : 0, t1 = TAIL ? a.ntile : a.nfull;
-  long W = 0;
-  for (int t = t0; t < t1; ++t) W += tile_weight(a.tile[t], KT);
-  const long g = blockIdx.x, G = gridDim.x;
-  const long lo = W * g / G, hi = W * (g + 1) / G;
-  float* slots = a.partials + (TAIL ? (long)kWgradGrid * 2 * kWgradSlotFloats : 0);
-  long start = 0;
-  int nslot = 0;
-  for (int t = t0; t < t1 && start < hi; ++t) {
-    const WgTile tl = a.tile[t];
-    const long w = tile_weight(tl, KT);
-    if (start + w > lo) {
-      const Piece pc = piece_of(start, tl.ncol, KT, lo, hi);
-      if (pc.ka < pc.kb) {               // uniform per workgroup
-        const bool full = pc.ka == 0 && pc.kb == KT;
-        float* slot = slots + (g * 2 + nslot) * kWgradSlotFloats;
-        const long kbeg = pc.ka * GBK, kend = pc.kb * GBK < a.P ? pc.kb * GBK : a.P;
-        wgrad_piece<TAIL>(a.prod[tl.prod], tl, kbeg, kend, full, slot, lds, tid);
-        if (!full) ++nslot;
-      }
-    }
-    start += w;
+  // unit -> (tile, slice): walk the runs of tiles that belong to one product
+  long u = blockIdx.x;
+  int t = t0, z = 0;
+  while (t < t1) {
+    int run = 1;
+    while (t + run < t1 && a.tile[t + run].prod == a.tile[t].prod) ++run;
+    if (u < (long)run * nz) { z = (int)(u / run); t += (int)(u % run); break; }
+    u -= (long)run * nz;
+    t += run;
   }
+  if (t >= t1) return;
+  const WgTile tl = a.tile[t];
+  const long kbeg = (long)z * L * GBK;
+  long kend = kbeg + L * GBK;
+  if (kend > a.P) kend = a.P;
+  float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
+  wgrad_piece<TAIL>(a.prod[tl.prod], tl, kbeg, kend, false, slot, lds, tid);      // an empty slice writes zeros
 }
 
-// One workgroup per tile: adds the partial slots of the tile in ascending workgroup order (the k ranges ascend with it).
+// Adds a tile's slices to dW in ascending slice order (= ascending points): every bit of the result is reproducible.
+// grid (tile, eighth of the tile's 16,384 elements)
 __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __restrict__ ap) {
   const WgradArgs& a = *ap;
-  // blockIdx.y: which eighth of the tile's 16,384 elements (8 x 256 threads x 8 elements)
   const int t = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
-  const long KT = (a.P + GBK - 1) / GBK;
-  const bool tail = t >= a.nfull;
-  const int t0 = tail ? a.nfull : 0, t1 = tail ? a.ntile : a.nfull;
-  const long G = tail ? kWgradTailGrid : kWgradGrid;
-  const float* slots = a.partials + (tail ? (long)kWgradGrid * 2 * kWgradSlotFloats : 0);
-  long W = 0, start = 0;
-  for (int i = t0; i < t1; ++i) {
-    if (i == t) start = W;
-    W += tile_weight(a.tile[i], KT);
-  }
+  const int nz = wgrad_slices(a.P);
   const WgTile tl = a.tile[t];
   const WgProduct pr = a.prod[tl.prod];
-  const long w = tile_weight(tl, KT);
-  // workgroups whose share touches [start, start + w)
-  long g0 = start * G / W;
-  while (g0 > 0 && W * g0 / G > start) --g0;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   float rs = 0.f;
-  bool any = false;
-  for (long g = g0; g < G; ++g) {
-    const long lo = W * g / G, hi = W * (g + 1) / G;
-    if (lo >= start + w) break;
-    const Piece pc = piece_of(start, tl.ncol, KT, lo, hi);
-    if (pc.ka >= pc.kb || (pc.ka == 0 && pc.kb == KT)) continue;       // nothing of this tile, or the sole owner (added directly)
-    // the slot index the main kernel used: 0 unless an earlier tile of that workgroup's share was also partial
-    int nslot = 0;
-    {
-      long s2 = 0;
-      for (int i = t0; i < t; ++i) {
-        const long w2 = tile_weight(a.tile[i], KT);
-        if (s2 + w2 > lo && s2 < hi) {
-          const Piece p2 = piece_of(s2, a.tile[i].ncol, KT, lo, hi);
-          if (p2.ka < p2.kb && !(p2.ka == 0 && p2.kb == KT)) ++nslot;
-        }
-        s2 += w2;
-      }
-    }
-    const float* slot = slots + (g * 2 + nslot) * kWgradSlotFloats;
+  const bool want_rs = part == 0 && pr.rowsum && tl.bx == 0 && tid < 128;
+  for (int z = 0; z < nz; ++z) {
+    const float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] += slot[(part * 8 + i) * 256 + tid];
-    if (part == 0 && tid < 128) rs += slot[128 * 128 + tid];
-    any = true;
+    if (want_rs) rs += slot[128 * 128 + tid];
   }
-  if (!any) return;
   const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int e = (part * 8 + i) * 256 + tid, ml = e >> 7, nl = e & 127;
     if (m0 + ml < pr.M && n0 + nl < pr.N && nl < 32 * (int)tl.ncol) pr.C[(m0 + ml) * pr.ldc + n0 + nl] += acc[i];
   }
-  if (part == 0 && pr.rowsum && tl.bx == 0 && tid < 128 && m0 + tid < pr.M) pr.rowsum[m0 + tid] += rs;
+  if (want_rs && m0 + tid < pr.M) pr.rowsum[m0 + tid] += rs;
 }
 
 // ---- the 1- and 3-row heads on the VALU ---------------------------------------------------------------------------
@@ -307,14 +260,15 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
     hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
-    if (a.nfull > 0) hipLaunchKernelGGL(wgrad_streamk_kernel<false>, dim3(kWgradGrid), dim3(256), 0, s, (const WgradArgs*)dev);
-    if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_streamk_kernel<true>, dim3(kWgradTailGrid), dim3(256), 0, s, (const WgradArgs*)dev);
+    const int nz = wgrad_slices(P);
+    if (a.nfull > 0) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3(a.nfull * nz), dim3(256), 0, s, (const WgradArgs*)dev);
+    if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);
   }
   if (h.nheads > 0) {
     h.P = P;
     h.nchunks = (int)((P + kHeadChunk - 1) / kHeadChunk);
-    h.partials = scratch + (long)(kWgradGrid + kWgradTailGrid) * 2 * kWgradSlotFloats;
+    h.partials = scratch + wgrad_slot_floats(P);
     hipLaunchKernelGGL(heads_wgrad_kernel, dim3(h.nchunks, h.nheads), dim3(256), 0, s, h);
     hipLaunchKernelGGL(heads_fixup_kernel, dim3(h.nheads), dim3(256), 0, s, h);
   }
