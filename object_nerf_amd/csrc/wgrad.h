@@ -30,7 +30,8 @@ struct WgTile {                // one output tile: rows [128 by, +128), columns 
   unsigned char ncol;          // 4: full tile (2 x 2 waves of 2 x 2 MFMA tiles); 1..3: ragged last column tile with that many
                                // live 32-column sub-tiles (4 x 1 waves, one row sub-tile each): ncol / 4 of a full tile's work
 };
-constexpr int kWgradMaxSlices = 64;                    // k slices per tile (~4096 points each, fewer and longer beyond 262,144 points)
+constexpr int kWgradMaxSlices = 256;                   // k slices per tile (fewer and longer ones beyond that)
+constexpr int kWgradSliceIters = 64;                  // k iterations (of 32 points) per slice
 constexpr int kWgradMaxProducts = 32;
 constexpr int kWgradMaxTiles = 96;
 constexpr long kWgradSlotFloats = 128 * 128 + 128;    // a partial tile + its partial row sums
@@ -38,6 +39,7 @@ struct WgradArgs {             // passed by value (2.5 KB of kernel arguments: n
   WgProduct prod[kWgradMaxProducts];
   WgTile tile[kWgradMaxTiles];
   int nprod, ntile, nfull;     // tile[0 .. nfull) are full tiles, tile[nfull .. ntile) ragged ones
+  int nz;                      // k slices per tile
   long P;
   float* partials;             // slot (tile t, slice z) at (t * slices + z) * kWgradSlotFloats
 };
@@ -47,7 +49,7 @@ struct HeadItem {              // dW (no x ni) += dY^T (no x P) X (P x ni), db (
   long ldx, ldw;
   int no, ni;
 };
-constexpr int kHeadChunk = 2048;                      // points per workgroup of heads_wgrad_kernel
+constexpr int kHeadChunk = 1024;                      // points per workgroup of heads_wgrad_kernel
 constexpr int kHeadSlotFloats = 4 * 256;              // rows 0..2: partial dW[o][:], row 3: partial db[0..2]
 constexpr int kMaxHeads = 4;
 struct HeadArgs {
@@ -59,12 +61,9 @@ struct HeadArgs {
 
 // floats of scratch the grouped weight-gradient pass needs for P points (appended to the dgrad scratch, train.hip)
 constexpr long kWgradListFloats = 1024;               // device copy of the WgradArgs lists (<= 4 KB), at the end
-// number of k slices of every tile: ~128 k iterations (4096 points) each, at most kWgradMaxSlices
-__host__ __device__ inline int wgrad_slices(long P) {
-  const long KT = (P + GBK - 1) / GBK;
-  const long nz = (KT + 127) / 128;
-  return (int)(nz < 1 ? 1 : (nz > kWgradMaxSlices ? kWgradMaxSlices : nz));
-}
+// number of k slices of every tile (host): kWgradSliceIters k iterations each (OBJNERF_WGRAD_KITERS overrides: tuning),
+// at most kWgradMaxSlices
+int wgrad_slices(long P);
 inline long wgrad_slot_floats(long P) { return (long)kWgradMaxTiles * wgrad_slices(P) * kWgradSlotFloats; }
 inline long wgrad_scratch_floats(long P) {
   return wgrad_slot_floats(P) + (long)kMaxHeads * ((P + kHeadChunk - 1) / kHeadChunk) * kHeadSlotFloats + kWgradListFloats;

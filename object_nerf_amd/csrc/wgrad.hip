@@ -1,5 +1,6 @@
 // wgrad.hip -- grouped, stream-K, deterministic weight gradients of one backward pass (wgrad.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "wgrad.h"
 #include "host_api.h"
 
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const WgradArgs& a = *ap;
   const int tid = threadIdx.x;
   const long KT = (a.P + GBK - 1) / GBK;
-  const int nz = wgrad_slices(a.P);
+  const int nz = a.nz;
   const long L = (KT + nz - 1) / nz;                       // k iterations per slice
   const int t0 = TAIL ? a.nfull : 0, t1 = TAIL ? a.ntile : a.nfull;
   // unit -> (tile, slice): walk the runs of tiles that belong to one product
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __restrict__ ap) {
   const WgradArgs& a = *ap;
   const int t = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
-  const int nz = wgrad_slices(a.P);
+  const int nz = a.nz;
   const WgTile tl = a.tile[t];
   const WgProduct pr = a.prod[tl.prod];
   float acc[8];
@@ -227,6 +228,17 @@ __global__ void __launch_bounds__(256) heads_fixup_kernel(const HeadArgs a) {
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
+int wgrad_slices(long P) {
+  static const long iters = [] {
+    const char* e = getenv("OBJNERF_WGRAD_KITERS");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : (long)kWgradSliceIters;
+  }();
+  const long KT = (P + GBK - 1) / GBK;
+  const long nz = (KT + iters - 1) / iters;
+  return (int)(nz < 1 ? 1 : (nz > kWgradMaxSlices ? kWgradMaxSlices : nz));
+}
+
 void WgradBatch::add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db) {
   if (a.nprod >= kWgradMaxProducts) { overflow = true; return; }
   const int pi = a.nprod++;
@@ -259,8 +271,8 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
   if (a.ntile > 0) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
+    const int nz = a.nz = wgrad_slices(P);
     hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
-    const int nz = wgrad_slices(P);
     if (a.nfull > 0) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3(a.nfull * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);
