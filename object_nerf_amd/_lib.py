@@ -22,6 +22,7 @@ c_f64_p = C.POINTER(C.c_double)
 
 BOX_DOUBLES = 31
 SEG_REC_FLOATS = 16     # OBJNERF_SEG_REC_FLOATS
+RAY_BIAS_FLOATS = 448   # OBJNERF_RAY_BIAS_FLOATS
 
 
 class VoxelGrid(C.Structure):
@@ -48,6 +49,7 @@ class MlpArgs(C.Structure):
         ("sigma_only", C.c_int32), ("mfma_bf16x3", C.c_int32),
         ("ray_index", C.c_void_p), ("n_active", C.c_void_p),
         ("comp_w", C.c_void_p), ("comp_rec", C.c_void_p), ("comp_last_delta", C.c_float), ("comp_inst_weights", C.c_int32),
+        ("ray_bias", C.c_void_p),
     ]
 
 
@@ -96,7 +98,7 @@ class RenderCfg(C.Structure):
         ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32),
         ("forward_instance", C.c_int32), ("is_eval", C.c_int32), ("use_zero_as_last_delta", C.c_int32),
         ("frustum_bound_th", C.c_float), ("rays_in_bbox", C.c_int32), ("mfma_bf16x3", C.c_int32),
-        ("separate_composite", C.c_int32),
+        ("separate_composite", C.c_int32), ("no_hoist", C.c_int32),
     ]
 
 
@@ -124,6 +126,7 @@ class RenderMultiCfg(C.Structure):
     _fields_ = [
         ("use_voxel", C.c_int32), ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("use_disp", C.c_int32),
         ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32), ("mfma_bf16x3", C.c_int32),
+        ("no_hoist", C.c_int32),
     ]
 
 
@@ -171,6 +174,7 @@ SIGNATURES = {
     "objnerf_pos_encode": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
     "objnerf_voxel_embed": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP]),
     "objnerf_mlp_eval": (C.c_int, [C.POINTER(MlpArgs), _VP]),
+    "objnerf_ray_bias": (C.c_int, [C.POINTER(MlpArgs), _VP, _VP]),
     "objnerf_composite": (C.c_int, [C.POINTER(CompositeArgs), _VP]),
     "objnerf_composite_finish": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "objnerf_sample_pdf_merge": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP]),

@@ -223,6 +223,8 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
   const bool fused = a->emb_xyz == nullptr;
   const bool comp = a->comp_w != nullptr;      // compositing in the epilogue: sigma / rgb need not be written
+  if (a->ray_bias && (!fused || a->mfma_bf16x3 || a->sigma_only))
+    return set_error(-1, "mlp_eval: ray_bias needs the fused form in fp32 arithmetic");
   if (comp) {
     if (!fused || !a->do_scene || !a->comp_rec || a->ray_index || a->sigma_only || a->S < 32 || (a->S & 31))
       return set_error(-1, "mlp_eval: comp_w needs the fused form, the scene branch, comp_rec, S % 32 == 0 and no ray subset");
@@ -302,11 +304,16 @@ static bool pass_fuses(const objnerf_render_cfg* cfg, int S) {
 static int64_t pass_floats(const objnerf_render_cfg* cfg, int64_t n_rays, int S) {
   return pass_fuses(cfg, S) ? n_rays * (S / 32) * OBJNERF_SEG_REC_FLOATS : n_rays * S * 8;
 }
-int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_rays) {
-  if (!cfg || n_rays < 0) return -1;
+// per-ray vectors of the hoisted terms (objnerf_ray_bias), re-computed per pass (coarse / fine weights): behind the pass area
+static bool hoists(const objnerf_render_cfg* cfg) { return !cfg->no_hoist && !cfg->mfma_bf16x3; }
+static int64_t pass_area_floats(const objnerf_render_cfg* cfg, int64_t n_rays) {
   const int64_t c = pass_floats(cfg, n_rays, cfg->N_samples);
   const int64_t f = cfg->N_importance > 0 ? pass_floats(cfg, n_rays, cfg->N_samples + cfg->N_importance) : 0;
-  return (int64_t)sizeof(float) * (c > f ? c : f) + 256;
+  return c > f ? c : f;
+}
+int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_rays) {
+  if (!cfg || n_rays < 0) return -1;
+  return (int64_t)sizeof(float) * (pass_area_floats(cfg, n_rays) + (hoists(cfg) ? n_rays * OBJNERF_RAY_BIAS_FLOATS : 0)) + 256;
 }
 
 static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* out,
@@ -327,6 +334,12 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
   m.rays = in->rays; m.z_vals = out->z_vals; m.n_rays = N; m.S = S;
   m.codes = in->codes; m.code_stride = in->code_stride; m.grid = in->grid;
   const bool inst_weights = cfg->rays_in_bbox && cfg->forward_instance;          // rendering.py:228-229
+  if (hoists(cfg)) {
+    float* rb = ws + pass_area_floats(cfg, N);
+    const int rc = objnerf_ray_bias(&m, rb, stream);
+    if (rc) return rc;
+    m.ray_bias = rb;
+  }
   if (fuse) {
     m.comp_w = out->weights; m.comp_rec = ws;
     m.comp_last_delta = cfg->use_zero_as_last_delta ? 0.f : 1e10f;               // rendering.py:143-153
@@ -391,7 +404,11 @@ namespace {
 struct MultiWs {
   int64_t N; int S, I, Smax;
   char* base;
-  int64_t set_floats() const { return N * ((int64_t)S + (S + I) + 4LL * Smax + S) + N; }
+  bool hoist;
+  // per set: the arrays listed above, padded to 64 bytes, then (fp32 passes) the per-ray vectors of objnerf_ray_bias
+  int64_t head_floats() const { return (N * ((int64_t)S + (S + I) + 4LL * Smax + S) + N + 15) / 16 * 16; }
+  int64_t set_floats() const { return head_floats() + (hoist ? N * OBJNERF_RAY_BIAS_FLOATS : 0); }
+  float* ray_bias(int k) const { return set(k) + head_floats(); }
   float* set(int k) const { return (float*)base + set_floats() * k; }
   float* zc(int k) const { return set(k); }
   float* zf(int k) const { return zc(k) + N * S; }
@@ -407,7 +424,7 @@ struct MultiWs {
 int64_t objnerf_render_multi_workspace_bytes(const objnerf_render_multi_cfg* cfg, int32_t K, int64_t n_rays) {
   if (!cfg || K < 1 || n_rays < 0) return -1;
   const int I = cfg->N_importance > 0 ? cfg->N_importance : 0;
-  MultiWs w{n_rays, cfg->N_samples, I, cfg->N_samples + I, nullptr};
+  MultiWs w{n_rays, cfg->N_samples, I, cfg->N_samples + I, nullptr, !cfg->no_hoist && !cfg->mfma_bf16x3};
   return 4 * (w.set_floats() * K + 64LL * K + objnerf_compact_scratch_ints(n_rays)) + 256;
 }
 
@@ -435,7 +452,7 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
     if (in->h_obj_ids[k] > 0 && !in->code_table) return set_error(-1, "render_rays_multi: object sets need the code table");
     if (in->h_obj_ids[k] < 0) return set_error(-1, "render_rays_multi: negative object id");
   }
-  MultiWs w{N, S, I, S + I, (char*)in->workspace};
+  MultiWs w{N, S, I, S + I, (char*)in->workspace, !cfg->no_hoist && !cfg->mfma_bf16x3};
 
   auto one_pass = [&](bool is_fine, const float* blob, const float* aux, const objnerf_render_multi_out* out) -> int {
     const int Sp = is_fine ? S + I : S;
@@ -469,6 +486,11 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
         m.inst_sigma = w.sigma(k); m.inst_rgb = w.rgb(k);
       } else {              // background: scene branch
         m.do_scene = 1; m.sigma = w.sigma(k); m.rgb = w.rgb(k);
+      }
+      if (w.hoist) {
+        rc = objnerf_ray_bias(&m, w.ray_bias(k), stream);
+        if (rc) return rc;
+        m.ray_bias = w.ray_bias(k);
       }
       rc = objnerf_mlp_eval(&m, stream);
       if (rc) return rc;

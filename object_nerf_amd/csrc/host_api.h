@@ -13,6 +13,7 @@ int check_launch(const char* what);
 // save_ws != nullptr: training forward, every layer's activations are also written to the train.hip workspace
 int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
 int launch_mlp_fused_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws);   // mfma_bf16x3
+int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);                // ray_bias
 int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
 // training: fused dgrad chain through the hidden layers (mlp_bwd.hip); act / dz in the workspace layout of train.hip
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,

@@ -215,6 +215,10 @@ static_assert(aux_bias_off(L_COUNT) == kAuxSSig, "aux layout");
 
 constexpr uint32_t kPackZero = 0xFFFFFFFFu;   // index-map entry meaning "0.0f"
 
+// per-ray vectors of the hoisted terms (mlp_kernel HOIST, ray_bias_kernel): [O1 128 | O3 128 | SD 128 | OD 64] in the
+// aux-bias layout of each layer
+constexpr int kRayBiasFloats = 448;
+
 // ---- split-bf16 weight stream (OBJNERF_MFMA=bf16x3, fused inference kernel) --------------------------
 // fp32 products on the bf16 matrix pipe: w = w_hi + w_mid + w_lo with three 8-bit-mantissa pieces (truncation splits
 // are EXACT for a 24-bit mantissa), likewise the activations, and 6 of the 9 cross products (everything down to 2^-16

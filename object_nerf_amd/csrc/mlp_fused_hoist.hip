@@ -1,0 +1,33 @@
+// mlp_fused_hoist.hip -- fp32-MFMA inference instantiations of the fused MLP kernel with the per-ray constant terms
+// hoisted (mlp_kernel.h HOIST, objnerf_mlp_args.ray_bias); a translation unit of its own so that it compiles in parallel
+// with mlp_fused.hip / mlp_fused_b3.hip.
+#include "mlp_kernel.h"
+#include "host_api.h"
+
+namespace objnerf {
+
+template <bool VOXEL, bool SC, bool OB>
+static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB, false, false, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+}
+
+int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+  const bool sc = a.do_scene != 0, ob = a.do_object != 0;
+#ifdef OBJ_TUNE_ONLY_MAIN   // tuning builds (tools/tune_mlp.py): only the bench instantiation, to compile fast
+  if (!(a.use_voxel && sc && ob)) return set_error(-9, "tuning build: only voxel scene+object is compiled");
+  launch<true, true, true>(a, ntiles, grid, s);
+#else
+  if (a.use_voxel) {
+    if (sc && ob) launch<true, true, true>(a, ntiles, grid, s);
+    else if (sc) launch<true, true, false>(a, ntiles, grid, s);
+    else launch<true, false, true>(a, ntiles, grid, s);
+  } else {
+    if (sc && ob) launch<false, true, true>(a, ntiles, grid, s);
+    else if (sc) launch<false, true, false>(a, ntiles, grid, s);
+    else launch<false, false, true>(a, ntiles, grid, s);
+  }
+#endif
+  return check_launch("mlp_eval(fused, hoisted)");
+}
+
+}  // namespace objnerf

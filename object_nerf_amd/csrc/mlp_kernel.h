@@ -257,12 +257,20 @@ struct NoHook {
 template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream>
 __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier);
 
-template <int NT, int KS, class Src, class Hook = NoHook, bool ZERO = false, class Stream = WeightStream>
-__device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier = Hook{}) {
+// SK0, SK1: the 4-k-step groups [SK0, SK1) of the layer are SKIPPED -- no A reads, no MFMAs -- while the weight stream
+// keeps its schedule (their chunks are opened and the next chunk's DMA pieces issued as usual).  Used when the terms of
+// those k-steps are constant along a ray and arrive through objnerf_mlp_args.ray_bias instead (HOIST, see mlp_kernel).
+template <int A, int B> struct SkipGroups { static constexpr int k0 = A, k1 = B; };
+using NoSkip = SkipGroups<0, 0>;
+template <int NT, int KS, class Src, class Hook = NoHook, bool ZERO = false, class Stream = WeightStream, class SkipT = NoSkip>
+__device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier = Hook{}, SkipT = SkipT{}) {
+  constexpr int SK0 = SkipT::k0, SK1 = SkipT::k1;
   if constexpr (Stream::kBytes == kB3ChunkBytes) {
+    static_assert(SK0 == SK1, "the split-bf16 contraction has no skip ranges");
     layer_mac_b3<NT, KS, Src, Hook, ZERO>(acc, st, src, after_barrier);
     return;
   }
+  static_assert(SK0 == SK1 || SK0 > 0, "group 0 is never skipped");
   constexpr int NG4 = (KS + 3) / 4;
   constexpr int KG = kChunkTiles / NT;
   // spread mode: the 8 DMA pieces of the chunk after the current one are issued in front of the chunk's MFMA groups
@@ -286,8 +294,11 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
     ATiles<NT>& a = abuf[g & 1];
     pieces(std::integral_constant<int, g % GPC>{});              // group g's share (after the barrier that opened its chunk)
     after_barrier.template group<g>();
+    constexpr bool skipped = g >= SK0 && g < SK1;
     if constexpr (g + 1 < NG4) {
-      load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
+      constexpr bool next_skipped = g + 1 >= SK0 && g + 1 < SK1;
+      if constexpr (!next_skipped) load_group<NT, g + 1>(abuf[(g + 1) & 1], st);
+      else if constexpr (((g + 1) * 4) % KG == 0) st.next_chunk();        // a skipped group still opens its chunk
       if constexpr (((g + 1) * 4) % KG == 0) after_barrier(std::integral_constant<int, ((g + 1) * 4) / KG>{});
     } else if constexpr (OBJ_SPREAD_DMA) {
       // end of the layer: pieces the (shorter) last chunk had no group for
@@ -301,7 +312,7 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
     static_for<4>([&](auto J) __attribute__((always_inline)) {
       constexpr int j = decltype(J)::value;
       constexpr int ks = ks0 + j;
-      if constexpr (ks < KS) {
+      if constexpr (ks < KS && !skipped) {
 #if OBJ_EMB_PIPE
         const float b = b_next;
         if constexpr (ks + 1 < KS) b_next = src.template get<ks + 1>();
@@ -510,6 +521,32 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT])
 #else
     for (int r = 0; r < 16; ++r) h[m][r] = ACT ? leaky(acc[m][r]) : acc[m][r];
 #endif
+}
+
+// HOIST: per-ray vectors (objnerf_mlp_args.ray_bias, aux-bias layout [m][half][16]) and the epilogue that adds them
+constexpr int kRbO1 = 0, kRbO3 = 128, kRbSD = 256, kRbOD = 384;
+template <int NT>
+__device__ __forceinline__ void load_rb(f32x16 (&dst)[NT], const float* p) {
+#pragma unroll
+  for (int m = 0; m < NT; ++m) dst[m] = *(const f32x16*)(p + m * 32);
+}
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+}
+// h = act(acc + add); `add` may alias h
+template <int NT, bool ACT>
+__device__ __forceinline__ void finish_add(const f32x16 (&acc)[NT], const f32x16 (&add)[NT], f32x16 (&h)[NT]) {
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[m][r] + add[m][r];
+      h[m][r] = ACT ? leaky(v) : v;
+    }
 }
 
 // dot of this lane's NT*16 hidden features with a packed head row, summed over both halves
@@ -922,9 +959,15 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false>
+// HOIST: the terms of the direction layers (27 of 283 / 155 inputs) and of the object branch's input layers (the 64-d code:
+// 64 of 439 / 567 inputs) that are CONSTANT ALONG A RAY -- the direction embedding and the object code are per-ray
+// quantities the reference repeats over the samples (rendering.py:89-94) -- are not contracted per sample: their k-steps
+// are skipped (340 of 13,876 MFMAs per 32 points, 2.45 %) and  bias + W[:, those columns] . x  arrives once per ray from
+// ray_bias_kernel (objnerf_ray_bias), added in the layer's epilogue.  Same sums in another association: fp32-roundoff class.
+template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false, bool HOIST = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr) {
   static_assert(!B3 || (FUSED && !SIGMA_ONLY), "split-bf16 mode: fused form only");
+  static_assert(!HOIST || (FUSED && !SAVE && !B3 && !SIGMA_ONLY), "hoisting: fp32 inference form of the fused kernel");
   constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");
@@ -1007,6 +1050,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
     bool valid;
     float comp_z = 0.f, comp_zn = 0.f, comp_sg = 0.f, comp_c[3] = {0.f, 0.f, 0.f};
     bool comp_last = false;
+    const float* rbp = nullptr;      // HOIST: this lane's ray vectors (+ half * 16)
     Src src;
     src.half = half;
     if constexpr (FUSED) {
@@ -1022,6 +1066,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       }
       p = pre.p;
       valid = pre.valid;
+      if constexpr (HOIST) rbp = a.ray_bias + pre.ray * kRayBiasFloats + half * 16;
       if constexpr (COMP) {
         // compositing in the epilogue: this sample's depth and the next one's (the prologue registers are re-used for
         // the NEXT tile during the object branch); one extra load per tile, consumed a whole pass later
@@ -1091,10 +1136,18 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       finish<8, false>(acc, h);
       // dir_encoding: cat([final, dir]) -> W/2, LeakyReLU
       f32x16 acc4[4], hd[4];
-      src.launder();
-      load_bias<4>(acc4, aux, L_SD, half);
-      { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal())); }
-      finish<4, true>(acc4, hd);
+      if constexpr (HOIST) {
+        // bias + W[:, 256:283] . PE(dir) comes per ray; the 14 direction k-steps (groups 32..35) are skipped
+        load_rb<4>(hd, rbp + kRbSD);
+        zero_acc<4>(acc4);
+        { HidSrc<8> s{h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal()), SkipGroups<32, (128 + kKsDir + 3) / 4>{}); }
+        finish_add<4, true>(acc4, hd, hd);
+      } else {
+        src.launder();
+        load_bias<4>(acc4, aux, L_SD, half);
+        { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal())); }
+        finish<4, true>(acc4, hd);
+      }
       if constexpr (SAVE) save_tiles<4>(hd, ws.sdirh(), 128, stg);
       float col[3];
 #pragma unroll
@@ -1110,12 +1163,23 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
 
     if constexpr (DO_OBJ) {
       f32x16 acc[4], h[4];
-      src.fetch_code();      // 8 x 16-B loads, consumed ~190 k-steps later: latency fully hidden
+      // code k-steps of the object input list: the last kKsCode of its NO k-steps = whole groups [NOC / 4, NO / 4)
+      constexpr int NOC = NO - kKsCode;
+      static_assert(NOC % 4 == 0 && NO % 4 == 0, "the code block is a whole number of 4-k-step groups");
+      using SkipCode = SkipGroups<NOC / 4, NO / 4>;
+      if constexpr (!HOIST) src.fetch_code();      // 8 x 16-B loads, consumed ~190 k-steps later: latency fully hidden
       if constexpr (PREFETCH) pre.stage_a(a, tile_next, P, wave, lane);
       src.launder();
-      load_bias<4>(acc, aux, L_O1, half);
-      { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
-      finish<4, true>(acc, h);
+      if constexpr (HOIST) {
+        load_rb<4>(h, rbp + kRbO1);                // bias + W[:, code columns] . code, per ray; consumed by the epilogue
+        zero_acc<4>(acc);
+        { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s, NoHook{}, SkipCode{}); }
+        finish_add<4, true>(acc, h, h);
+      } else {
+        load_bias<4>(acc, aux, L_O1, half);
+        { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
+        finish<4, true>(acc, h);
+      }
       auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 4>{h, mat, 128, stg}; };
       if constexpr (PREFETCH) pre.stage_b(a.grid);
       load_bias<4>(acc, aux, L_O2, half);
@@ -1123,9 +1187,17 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       finish<4, true>(acc, h);
       if constexpr (PREFETCH) pre.template stage_rows<0>(a.grid, half);
       src.launder();
-      load_bias<4>(acc, aux, L_O3, half);
-      { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2))); }
-      finish<4, true>(acc, h);
+      if constexpr (HOIST) {
+        f32x16 t3[4];                              // h is this layer's input: the ray vector waits in registers of its own
+        load_rb<4>(t3, rbp + kRbO3);
+        zero_acc<4>(acc);
+        { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2)), SkipCode{}); }
+        finish_add<4, true>(acc, t3, h);
+      } else {
+        load_bias<4>(acc, aux, L_O3, half);
+        { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2))); }
+        finish<4, true>(acc, h);
+      }
       if constexpr (PREFETCH) { pre.template stage_acc<0>(); pre.template stage_rows<1>(a.grid, half); }
       load_bias<4>(acc, aux, L_O4, half);
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(3))); }
@@ -1139,10 +1211,17 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(4))); }
       finish<4, false>(acc, h);
       f32x16 acc2[2], hd[2];
-      src.launder();
-      load_bias<2>(acc2, aux, L_OD, half);
-      { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal())); }
-      finish<2, true>(acc2, hd);
+      if constexpr (HOIST) {
+        load_rb<2>(hd, rbp + kRbOD);
+        zero_acc<2>(acc2);
+        { HidSrc<4> s{h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal()), SkipGroups<16, (64 + kKsDir + 3) / 4>{}); }
+        finish_add<2, true>(acc2, hd, hd);
+      } else {
+        src.launder();
+        load_bias<2>(acc2, aux, L_OD, half);
+        { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal())); }
+        finish<2, true>(acc2, hd);
+      }
       if constexpr (SAVE) save_tiles<2>(hd, ws.odirh(), 64, stg);
       float col[3];
 #pragma unroll

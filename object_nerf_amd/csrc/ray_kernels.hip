@@ -779,6 +779,99 @@ __global__ void ray_box_kernel(const float* __restrict__ rays_o, const float* __
   hit[idx] = h ? 1 : 0; near[idx] = nr; far[idx] = fr;
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-ray vectors of the hoisted terms (mlp_kernel HOIST).  For the layers whose input is cat([.., x]) with x constant
+// along a ray -- the object code in instance_encoding_1 / _3 (nerf_model.py:128-138), the direction embedding in
+// dir_encoding / inst_dir_encoding (116, 147) -- out[ray] = bias + W[:, columns of x] . x, written in the layer's
+// D-register order so that a lane of the MLP kernel reads its 16 values as one 64-byte piece.
+// Block = 448 threads, thread = one output row (its weights live in registers: read once from the packed stream, by the
+// same layout arithmetic as the packer's), 8 rays per trip staged in LDS.
+// ------------------------------------------------------------------------------------------
+struct RayBiasArgs {
+  const float* blob; const float* aux; const float* rays; const float* codes;
+  long code_stride, n_rays;
+  int use_voxel, do_scene, do_object;
+  float* out;
+};
+__device__ __forceinline__ float blob_weight(const float* blob, bool vox, int l, int ks, int half, int row) {
+  const int nt = layer_nt(l), kg = kChunkTiles / nt;
+  const long base = (long)layer_chunk_start(vox, l) * kChunkFloats;
+  const int chunk = ks / kg, kl = ks % kg, g4 = kl / 4, j = kl % 4, m = row >> 5, lane = (row & 31) + 32 * half;
+  return blob[base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j];
+}
+constexpr int kRbRays = 8;
+__global__ void __launch_bounds__(448) ray_bias_kernel(const RayBiasArgs a) {
+  __shared__ float sx[kRbRays][96];          // per ray: code (64) | PE4(dir) (27)
+  const int o = threadIdx.x;
+  const bool vox = a.use_voxel != 0;
+  // output row -> layer, row inside it, position in the vector
+  int l, row, off;
+  if (o < 128) { l = L_O1; row = o; off = 0; }
+  else if (o < 256) { l = L_O3; row = o - 128; off = 128; }
+  else if (o < 384) { l = L_SD; row = o - 256; off = 256; }
+  else { l = L_OD; row = o - 384; off = 384; }
+  const bool is_code = o < 256;               // wave-uniform (waves 0-3 / 4-6)
+  const bool live = is_code ? a.do_object != 0 : (l == L_SD ? a.do_scene != 0 : a.do_object != 0);
+  const int w5 = row & 31;
+  const int pos = off + (row >> 5) * 32 + ((w5 >> 2) & 1) * 16 + (w5 & 3) + 4 * (w5 >> 3);   // [m][half][reg]: row = 32 m + (r & 3) + 8 (r >> 2) + 4 half
+  float w[64];
+  float bias = 0.f;
+  if (live) {
+    bias = a.aux[aux_bias_off(l) + (pos - off)];
+    if (is_code) {
+      const int ks0 = ks_emb(vox) + (vox ? kKsObjVox : 0);        // first code k-step of the object input list (layout.h)
+#pragma unroll
+      for (int c = 0; c < 64; ++c) w[c] = blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
+    } else {
+      const int nh = l == L_SD ? 128 : 64;
+#pragma unroll
+      for (int c = 0; c < 27; ++c) w[c] = 0.f;
+#pragma unroll
+      for (int i = 0; i < kKsDir; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = dir_slot_col(i, h);
+          if (c >= 0) w[c] = blob_weight(a.blob, vox, l, nh + i, h, row);
+        }
+    }
+  }
+  for (long r0 = (long)blockIdx.x * kRbRays; r0 < a.n_rays; r0 += (long)gridDim.x * kRbRays) {
+    __syncthreads();
+    for (int e = o; e < kRbRays * 96; e += 448) {
+      const int rr = e / 96, c = e % 96;
+      const long ray = r0 + rr < a.n_rays ? r0 + rr : a.n_rays - 1;
+      float v = 0.f;
+      if (c < 64) {
+        v = a.codes ? a.codes[ray * a.code_stride + c] : 0.f;
+      } else if (c < 64 + kDirC) {
+        // Embedding(3, 4): [d, sin(2^k d), cos(2^k d)] (embedding_helper.py:69-74), the MLP kernel's own sin / cos
+        const int cc = c - 64;
+        if (cc < 3) v = a.rays[ray * 8 + 3 + cc];
+        else {
+          const int q = cc - 3, k = q / 6, fn = (q / 3) & 1, coord = q % 3;
+          const SinCos sc = psincos(a.rays[ray * 8 + 3 + coord] * (float)(1 << k));
+          v = fn ? sc.c : sc.s;
+        }
+      }
+      sx[rr][c] = v;
+    }
+    __syncthreads();
+    if (live) {
+      for (int rr = 0; rr < kRbRays && r0 + rr < a.n_rays; ++rr) {
+        float acc = bias;
+        if (is_code) {
+#pragma unroll
+          for (int c = 0; c < 64; ++c) acc = fmaf(w[c], sx[rr][c], acc);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 27; ++c) acc = fmaf(w[c], sx[rr][64 + c], acc);
+        }
+        a.out[(r0 + rr) * kRayBiasFloats + pos] = acc;
+      }
+    }
+  }
+}
+
 // volume_rendering_multi (multi_rendering.py:96-157): joint stable sort by z of K*S samples,
 // gather, composite with last delta 0.  One wave per ray, everything staged in LDS.
 constexpr int kMaxSets = 16;
@@ -1043,6 +1136,17 @@ int objnerf_composite_finish(const float* seg_records, int64_t n_rays, int S, in
                      (long)n_rays, S, has_instance != 0, white_back, weights, opacity, rgb_map, depth, rgb_inst, depth_inst,
                      opacity_inst, inst_weights != 0);
   return check_launch("composite_finish");
+}
+
+int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
+  if (!m || !out || !m->blob || !m->aux || !m->rays || m->n_rays < 0) return set_error(-1, "ray_bias: bad arguments");
+  if (m->mfma_bf16x3) return set_error(-1, "ray_bias: the fp32 weight stream is needed (not the split-bf16 one)");
+  if (m->do_object && !m->codes) return set_error(-1, "ray_bias: the object branch needs codes");
+  if (m->n_rays == 0) return 0;
+  RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out};
+  const long blocks = (m->n_rays + kRbRays - 1) / kRbRays;
+  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(448), 0, (hipStream_t)stream, a);
+  return check_launch("ray_bias");
 }
 
 int objnerf_generate_rays_rows(int H, int W, float focal, const float* h_c2w, float near, float far, const double* h_box,

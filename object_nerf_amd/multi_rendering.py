@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .bbox import pack_boxes
 from .embedding_helper import EmbeddingVoxel
-from .rendering import _linspace, mfma_mode
+from .rendering import _linspace, hoist_enabled, mfma_mode
 
 __all__ = ["render_rays_multi"]
 
@@ -82,7 +82,7 @@ def render_rays_multi(
     b3 = mfma_mode() == "bf16x3"
     cfg = _lib.RenderMultiCfg(use_voxel=int(use_voxel), N_samples=S, N_importance=I, use_disp=int(bool(use_disp)),
                               perturb=float(perturb), noise_std=float(noise_std), white_back=int(bool(white_back)),
-                              mfma_bf16x3=int(b3))
+                              mfma_bf16x3=int(b3), no_hoist=int(not hoist_enabled()))
     ws = torch.empty(l.objnerf_render_multi_workspace_bytes(C.byref(cfg), K, n), dtype=torch.uint8, device=dev)
     rin = _lib.RenderMultiIn()
     rin.n_rays, rin.K = n, K

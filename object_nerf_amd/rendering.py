@@ -96,6 +96,16 @@ def composite_mode():
     return m
 
 
+def hoist_enabled():
+    """fp32 inference passes take the terms that are constant along a ray (the object code's and the direction embedding's
+    share of four layers) from per-ray vectors instead of contracting them per sample point (include/objnerf_hip.h,
+    objnerf_mlp_args.ray_bias).  OBJNERF_HOIST=0 switches that off (A/B timing, tolerance tests)."""
+    m = os.environ.get("OBJNERF_HOIST", "1")
+    if m not in ("0", "1"):
+        raise RuntimeError("OBJNERF_HOIST must be '0' or '1', got %r" % m)
+    return m == "1"
+
+
 def _train_packs(coarse, fine):
     mode = os.environ.get("OBJNERF_TRAIN_LAYERWISE", "")
     if mode == "1":
@@ -199,7 +209,7 @@ def render_rays(
         forward_instance=int(bool(forward_instance)), is_eval=int(is_eval),
         use_zero_as_last_delta=int(use_zero_as_last_delta), frustum_bound_th=float(frustum_bound_th),
         rays_in_bbox=int(bool(rays_in_bbox)), mfma_bf16x3=int(mfma_mode() == "bf16x3"),
-        separate_composite=int(composite_mode() == "separate"))
+        separate_composite=int(composite_mode() == "separate"), no_hoist=int(not hoist_enabled()))
     l = _lib.lib()
     ws = torch.empty(l.objnerf_render_workspace_bytes(C.byref(cfg), n), dtype=torch.uint8, device=dev)
 

@@ -167,24 +167,32 @@ def test_c_abi_argument_validation():
     assert l.objnerf_sample_coarse(None, None, None, 0.0, 0, 4, 8, None, None) < 0
     assert l.objnerf_sample_pdf_merge(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None) < 0
     # workspace: sigma / rgb of both branches (32 B per sample) in the two-kernel form; only the 64-byte segment records
-    # per 32 samples when the passes composite in the MLP kernel's epilogue (no occlusion mask, no noise, S % 32 == 0)
-    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, separate_composite=1)
+    # per 32 samples when the passes composite in the MLP kernel's epilogue (no occlusion mask, no noise, S % 32 == 0);
+    # plus, in fp32 arithmetic, the per-ray vectors of the hoisted terms (1792 B per ray) unless no_hoist
+    rb = _lib.RAY_BIAS_FLOATS
+    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, separate_composite=1, no_hoist=1)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * 128 * 8 + 256
+    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1)
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * (128 // 32) * _lib.SEG_REC_FLOATS + 256
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * ((128 // 32) * _lib.SEG_REC_FLOATS + rb) + 256
+    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, mfma_bf16x3=1)            # split-bf16 passes do not hoist
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * (128 // 32) * _lib.SEG_REC_FLOATS + 256
     for kw in (dict(noise_std=1.0), dict(is_eval=0, frustum_bound_th=0.025)):        # noise / occlusion mask: two-kernel form
-        c2 = _lib.RenderCfg(N_samples=64, N_importance=64, **kw)
+        c2 = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1, **kw)
         assert l.objnerf_render_workspace_bytes(C.byref(c2), 1000) == 4 * 1000 * 128 * 8 + 256
     # odd coarse count, fine count a multiple of 32: the coarse pass needs the two-kernel form, the fine pass does not
-    c3 = _lib.RenderCfg(N_samples=40, N_importance=24)
+    c3 = _lib.RenderCfg(N_samples=40, N_importance=24, no_hoist=1)
     assert l.objnerf_render_workspace_bytes(C.byref(c3), 1000) == 4 * 1000 * 40 * 8 + 256
     # the multi-object entry points (round 2)
     assert l.objnerf_compact_rays(None, 10, 4, None, None, None, None) < 0 and b"compact_rays" in l.objnerf_last_error()
     assert l.objnerf_compact_scratch_ints(5000) == 5 + 1
     assert l.objnerf_sample_pdf_merge_clip(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None, None) < 0
-    mc = _lib.RenderMultiCfg(N_samples=64, N_importance=64)
-    per_set = 1000 * (64 + 128 + 4 * 128 + 64) + 1000            # depths, sigma / rgb, own weights, ray index
+    mc = _lib.RenderMultiCfg(N_samples=64, N_importance=64, no_hoist=1)
+    per_set = (1000 * (64 + 128 + 4 * 128 + 64) + 1000 + 15) // 16 * 16       # depths, sigma / rgb, own weights, ray index; 64-byte units
     assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * per_set + 64 * 3 + 2) + 256
+    mc = _lib.RenderMultiCfg(N_samples=64, N_importance=64)                    # + the per-ray vectors of each set (fp32 passes)
+    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * (per_set + 1000 * _lib.RAY_BIAS_FLOATS) + 64 * 3 + 2) + 256
     rin, out = _lib.RenderMultiIn(), _lib.RenderMultiOut()
     rin.n_rays, rin.K = 8, 0
     assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0
@@ -221,6 +229,10 @@ def test_c_abi_argument_validation():
     assert l.objnerf_mlp_eval(C.byref(b), None) < 0 and b"comp_w needs" in l.objnerf_last_error()
     b.S, b.comp_rec, b.do_scene, b.do_object = 64, 64, 0, 1
     assert l.objnerf_mlp_eval(C.byref(b), None) < 0 and b"comp_w needs" in l.objnerf_last_error()
+    b.do_scene, b.do_object, b.comp_w, b.comp_rec, b.sigma = 1, 0, None, None, 64
+    b.ray_bias, b.mfma_bf16x3 = 64, 1
+    assert l.objnerf_mlp_eval(C.byref(b), None) < 0 and b"ray_bias needs" in l.objnerf_last_error()
+    assert l.objnerf_ray_bias(C.byref(b), C.c_void_p(64), None) < 0 and b"fp32 weight stream" in l.objnerf_last_error()
     assert l.objnerf_composite_finish(None, 4, 40, 0, 0, 0, None, None, None, None, None, None, None, None) < 0
     assert b"multiple of 32" in l.objnerf_last_error()
 
