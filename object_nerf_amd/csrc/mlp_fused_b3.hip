@@ -17,6 +17,23 @@ static void launch_save(const objnerf_mlp_args& a, long ntiles, unsigned grid, h
 }
 #endif
 
+// memory form (pre-embedded inputs: ObjectNeRF.forward / forward_instance) in the split-bf16 mode: the teacher-forced
+// per-branch parity test grades the mode on it at the fp32 kernel's tolerance
+template <bool VOXEL, bool SC, bool OB>
+static void launch_mem(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, false, SC, OB, false, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+}
+int launch_mlp_memory_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
+#ifdef OBJ_TUNE_ONLY_MAIN
+  return set_error(-9, "tuning build: memory-form kernels are not compiled");
+#else
+  const bool sc = a.do_scene != 0;
+  if (a.use_voxel) { if (sc) launch_mem<true, true, false>(a, ntiles, grid, s); else launch_mem<true, false, true>(a, ntiles, grid, s); }
+  else { if (sc) launch_mem<false, true, false>(a, ntiles, grid, s); else launch_mem<false, false, true>(a, ntiles, grid, s); }
+  return check_launch("mlp_eval(memory, split-bf16)");
+#endif
+}
+
 int launch_mlp_fused_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws) {
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
 #ifdef OBJ_TUNE_ONLY_MAIN

@@ -966,7 +966,7 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 // ray_bias_kernel (objnerf_ray_bias), added in the layer's epilogue.  Same sums in another association: fp32-roundoff class.
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false, bool HOIST = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr) {
-  static_assert(!B3 || (FUSED && !SIGMA_ONLY), "split-bf16 mode: fused form only");
+  static_assert(!B3 || !SIGMA_ONLY, "split-bf16 mode: every layer (no density-only variant)");
   static_assert(!HOIST || (FUSED && !SAVE && !B3 && !SIGMA_ONLY), "hoisting: fp32 inference form of the fused kernel");
   constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");

@@ -256,11 +256,16 @@ class ObjectNeRF(nn.Module):
             raise RuntimeError("emb_xyz has %d channels, expected %d" % (emb_xyz.shape[-1], self.in_channels_xyz))
         if emb_dir is None:   # sigma_only callers may omit it (tools/extract_mesh.py:85-108)
             emb_dir = torch.zeros(n, self.in_channels_dir, device=dev)
-        blob, aux = self.packed()
+        # OBJNERF_MFMA=bf16x3: the split-bf16 arithmetic mode also for these stand-alone forwards (the density-only variant
+        # stays on the fp32 kernel: it exists for extract_mesh.py's grid query, where the mode is not offered)
+        from .rendering import mfma_mode
+        b3 = mfma_mode() == "bf16x3" and not sigma_only
+        blob, aux = self.packed(split_bf16=b3)
         a = _lib.MlpArgs()
         a.use_voxel = int(self.use_voxel_embedding)
         a.do_scene, a.do_object = (1, 0) if scene else (0, 1)
         a.sigma_only = int(bool(sigma_only))
+        a.mfma_bf16x3 = int(b3)
         a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
         exyz, edir = _lib.as_f32(emb_xyz), _lib.as_f32(emb_dir)
         a.emb_xyz, a.emb_dir, a.n_points = exyz.data_ptr(), edir.data_ptr(), n

@@ -15,7 +15,9 @@ import sys
 KERNEL = "mlp_kernel"
 
 
-def main(pmc_dir, out_json, evals=58982400):
+def main(pmc_dir, out_json, evals=58982400, mfma_per_32=13536):
+    """mfma_per_32: v_mfma_f32_32x32x2_f32 per 32 points with both branches: 13,876 contracted per sample point, 13,536 with
+    the per-ray constant terms hoisted (round 3 default; OBJNERF_HOIST=0 -> pass 13876)"""
     sums, wall = {}, None
     for f in sorted(glob.glob(os.path.join(pmc_dir, "pass*", "*counter_collection.csv"))):
         per_dispatch = {}
@@ -29,7 +31,7 @@ def main(pmc_dir, out_json, evals=58982400):
             launches = len(per_dispatch)
     g = sums.get
     mfma = g("SQ_INSTS_MFMA", 0.0)
-    d = {"launches_per_pass": launches, "mfma_instructions": mfma, "mfma_instructions_expected": evals / 32.0 * 13876,
+    d = {"launches_per_pass": launches, "mfma_instructions": mfma, "mfma_instructions_expected": evals / 32.0 * mfma_per_32,
          "kernel_wall_s_all_launches": wall}
     if mfma:
         d["mfma_busy_cycles_per_instruction"] = g("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / mfma
@@ -59,4 +61,4 @@ def main(pmc_dir, out_json, evals=58982400):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], *[int(x) for x in sys.argv[3:4]])
+    main(sys.argv[1], sys.argv[2], *[int(x) for x in sys.argv[3:5]])
