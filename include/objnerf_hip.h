@@ -157,7 +157,7 @@ typedef struct {
   float* comp_rec;
   float comp_last_delta;
   int32_t comp_inst_weights;
-  /* fused form, fp32 arithmetic only, optional: (n_rays, OBJNERF_RAY_BIAS_FLOATS) vectors written by objnerf_ray_bias for
+  /* fused form, optional (either arithmetic mode): (n_rays, OBJNERF_RAY_BIAS_FLOATS) vectors written by objnerf_ray_bias for
    * the SAME blob / aux / rays / codes.  The parts of four layers' pre-activations that are constant along a ray -- the
    * object code's share of instance_encoding_1 / _3 and the direction embedding's share of dir_encoding /
    * inst_dir_encoding: the reference repeats both over the samples (rendering.py:89-94) -- are then taken from there
@@ -334,7 +334,7 @@ typedef struct {
    * 1: always the two-kernel form (MLP kernel -> sigma / rgb in the workspace -> objnerf_composite).  Results are
    * bit-equal either way. */
   int32_t separate_composite;
-  /* 0 (default): fp32 passes take the per-ray constant terms from objnerf_ray_bias (objnerf_mlp_args.ray_bias;
+  /* 0 (default): the passes take the per-ray constant terms from objnerf_ray_bias (objnerf_mlp_args.ray_bias;
    * 1792 B of workspace per ray); 1: every term contracted per sample point as in round 2 (A/B switch) */
   int32_t no_hoist;
 } objnerf_render_cfg;

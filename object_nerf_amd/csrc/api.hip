@@ -223,8 +223,7 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
   const bool fused = a->emb_xyz == nullptr;
   const bool comp = a->comp_w != nullptr;      // compositing in the epilogue: sigma / rgb need not be written
-  if (a->ray_bias && (!fused || a->mfma_bf16x3 || a->sigma_only))
-    return set_error(-1, "mlp_eval: ray_bias needs the fused form in fp32 arithmetic");
+  if (a->ray_bias && (!fused || a->sigma_only)) return set_error(-1, "mlp_eval: ray_bias needs the fused form");
   if (comp) {
     if (!fused || !a->do_scene || !a->comp_rec || a->ray_index || a->sigma_only || a->S < 32 || (a->S & 31))
       return set_error(-1, "mlp_eval: comp_w needs the fused form, the scene branch, comp_rec, S % 32 == 0 and no ray subset");
@@ -305,7 +304,7 @@ static int64_t pass_floats(const objnerf_render_cfg* cfg, int64_t n_rays, int S)
   return pass_fuses(cfg, S) ? n_rays * (S / 32) * OBJNERF_SEG_REC_FLOATS : n_rays * S * 8;
 }
 // per-ray vectors of the hoisted terms (objnerf_ray_bias), re-computed per pass (coarse / fine weights): behind the pass area
-static bool hoists(const objnerf_render_cfg* cfg) { return !cfg->no_hoist && !cfg->mfma_bf16x3; }
+static bool hoists(const objnerf_render_cfg* cfg) { return !cfg->no_hoist; }
 static int64_t pass_area_floats(const objnerf_render_cfg* cfg, int64_t n_rays) {
   const int64_t c = pass_floats(cfg, n_rays, cfg->N_samples);
   const int64_t f = cfg->N_importance > 0 ? pass_floats(cfg, n_rays, cfg->N_samples + cfg->N_importance) : 0;
@@ -424,7 +423,7 @@ struct MultiWs {
 int64_t objnerf_render_multi_workspace_bytes(const objnerf_render_multi_cfg* cfg, int32_t K, int64_t n_rays) {
   if (!cfg || K < 1 || n_rays < 0) return -1;
   const int I = cfg->N_importance > 0 ? cfg->N_importance : 0;
-  MultiWs w{n_rays, cfg->N_samples, I, cfg->N_samples + I, nullptr, !cfg->no_hoist && !cfg->mfma_bf16x3};
+  MultiWs w{n_rays, cfg->N_samples, I, cfg->N_samples + I, nullptr, !cfg->no_hoist};
   return 4 * (w.set_floats() * K + 64LL * K + objnerf_compact_scratch_ints(n_rays)) + 256;
 }
 
@@ -452,7 +451,7 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
     if (in->h_obj_ids[k] > 0 && !in->code_table) return set_error(-1, "render_rays_multi: object sets need the code table");
     if (in->h_obj_ids[k] < 0) return set_error(-1, "render_rays_multi: negative object id");
   }
-  MultiWs w{N, S, I, S + I, (char*)in->workspace, !cfg->no_hoist && !cfg->mfma_bf16x3};
+  MultiWs w{N, S, I, S + I, (char*)in->workspace, !cfg->no_hoist};
 
   auto one_pass = [&](bool is_fine, const float* blob, const float* aux, const objnerf_render_multi_out* out) -> int {
     const int Sp = is_fine ? S + I : S;

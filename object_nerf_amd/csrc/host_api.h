@@ -14,6 +14,7 @@ int check_launch(const char* what);
 int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
 int launch_mlp_fused_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws);   // mfma_bf16x3
 int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);                // ray_bias
+int launch_mlp_fused_b3_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);             // ray_bias + mfma_bf16x3
 int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
 int launch_mlp_memory_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);                  // mfma_bf16x3
 // training: fused dgrad chain through the hidden layers (mlp_bwd.hip); act / dz in the workspace layout of train.hip

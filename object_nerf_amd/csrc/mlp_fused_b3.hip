@@ -35,6 +35,7 @@ int launch_mlp_memory_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, 
 }
 
 int launch_mlp_fused_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws) {
+  if (a.ray_bias && !save_ws) return launch_mlp_fused_b3_hoist(a, ntiles, grid, s);
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
 #ifdef OBJ_TUNE_ONLY_MAIN
   if (save_ws) return set_error(-9, "tuning build: training kernels are not compiled");

@@ -254,20 +254,19 @@ struct NoHook {
 };
 // ZERO: acc = W * B instead of acc += W * B (the first k-step's MFMA takes the constant 0 as its C operand; the
 // accumulators need no initialisation pass).
-template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream>
+template <int A, int B> struct SkipGroups { static constexpr int k0 = A, k1 = B; };
+using NoSkip = SkipGroups<0, 0>;
+template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream, class SkipT>
 __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier);
 
 // SK0, SK1: the 4-k-step groups [SK0, SK1) of the layer are SKIPPED -- no A reads, no MFMAs -- while the weight stream
 // keeps its schedule (their chunks are opened and the next chunk's DMA pieces issued as usual).  Used when the terms of
 // those k-steps are constant along a ray and arrive through objnerf_mlp_args.ray_bias instead (HOIST, see mlp_kernel).
-template <int A, int B> struct SkipGroups { static constexpr int k0 = A, k1 = B; };
-using NoSkip = SkipGroups<0, 0>;
 template <int NT, int KS, class Src, class Hook = NoHook, bool ZERO = false, class Stream = WeightStream, class SkipT = NoSkip>
 __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier = Hook{}, SkipT = SkipT{}) {
   constexpr int SK0 = SkipT::k0, SK1 = SkipT::k1;
   if constexpr (Stream::kBytes == kB3ChunkBytes) {
-    static_assert(SK0 == SK1, "the split-bf16 contraction has no skip ranges");
-    layer_mac_b3<NT, KS, Src, Hook, ZERO>(acc, st, src, after_barrier);
+    layer_mac_b3<NT, KS, Src, Hook, ZERO, Stream, SkipT>(acc, st, src, after_barrier);
     return;
   }
   static_assert(SK0 == SK1 || SK0 > 0, "group 0 is never skipped");
@@ -363,8 +362,20 @@ struct B3Operand { u32x4 hi, mid, lo; };
 
 __device__ __forceinline__ unsigned bf16_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
 
-template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream>
+// SkipT (layer_mac): the k-steps [4 k0, 4 k1) arrive per ray instead (HOIST).  Here an s-step covers 8 k-steps: s-steps made
+// only of hoisted (or padding) k-steps are skipped -- no A reads, no MFMAs, the stream keeps its schedule --, the hoisted
+// k-steps of a partly covered s-step enter as zeros.
+template <int KS, int HK0, int HK1>
+constexpr bool b3_skip_step(int s) {
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * s + j;
+    if (k < KS && !(k >= HK0 && k < HK1)) return false;
+  }
+  return true;
+}
+template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream, class SkipT>
 __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier) {
+  constexpr int HK0 = 4 * SkipT::k0, HK1 = 4 * SkipT::k1;
   constexpr int NS = (KS + 7) / 8;
   constexpr int SPC = kChunkTiles / NT / 8;      // s-steps per chunk
   constexpr int G = OBJ_B3_GROUP < NT ? OBJ_B3_GROUP : NT;      // out tiles whose products are interleaved
@@ -379,8 +390,8 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
       constexpr int jj = decltype(J0_)::value + decltype(J)::value;
       constexpr int k0 = 8 * s + 2 * jj, k1 = k0 + 1;
       float x0 = 0.f, x1 = 0.f;
-      if constexpr (k0 < KS) x0 = src.template get<k0>();
-      if constexpr (k1 < KS) x1 = src.template get<k1>();
+      if constexpr (k0 < KS && !(k0 >= HK0 && k0 < HK1)) x0 = src.template get<k0>();
+      if constexpr (k1 < KS && !(k1 >= HK0 && k1 < HK1)) x1 = src.template get<k1>();
       const unsigned h0 = bf16_trunc(x0), h1 = bf16_trunc(x1);
       const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
       const unsigned m0 = bf16_trunc(r0), m1 = bf16_trunc(r1);
@@ -412,13 +423,17 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
 #ifdef OBJ_ABL_B3_ALOAD    // timing ablation only: A tiles read from LDS once per layer
     if constexpr (gi <= AD) load_a(abuf[gi % (AD + 1)], 0, 0);
 #else
-    if constexpr (gi < NGTOT) load_a(abuf[gi % (AD + 1)], (gi / NGRP) % SPC, gi % NGRP);
+    if constexpr (gi < NGTOT) {
+      if constexpr (!b3_skip_step<KS, HK0, HK1>(gi / NGRP)) load_a(abuf[gi % (AD + 1)], (gi / NGRP) % SPC, gi % NGRP);
+    }
 #endif
   };
   split(std::integral_constant<int, 0>{}, bop[0]);
   static_for<NS>([&](auto S_) __attribute__((always_inline)) {
     constexpr int s = decltype(S_)::value;
     constexpr int sl = s % SPC;
+    constexpr bool skipped = b3_skip_step<KS, HK0, HK1>(s);
+    static_assert(!(skipped && s == 0), "the first s-step is never skipped");
     // The layer's first chunk is opened here; every later one is opened EARLY, in front of the MFMAs of the previous
     // chunk's last group (below): by then that group's A tiles sit in registers, so the barrier may recycle the slot,
     // and the next chunk's first A tiles are fetched under those MFMAs instead of behind an idle barrier.
@@ -462,8 +477,11 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
         split_part(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1], std::integral_constant<int, grp * (4 / NGRP)>{},
                    std::integral_constant<int, 4 / NGRP>{});
 #else
-      if constexpr (grp == 0 && s + 1 < NS) split(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1]);
+      if constexpr (grp == 0 && s + 1 < NS) {
+        if constexpr (!b3_skip_step<KS, HK0, HK1>(s + 1)) split(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1]);
+      }
 #endif
+      if constexpr (!skipped) {
       bf16x8 ah[G], am[G], al[G];
 #pragma unroll
       for (int t = 0; t < G; ++t) {
@@ -491,6 +509,7 @@ __device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src&
       for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bm, acc[grp * G + t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[grp * G + t], 0, 0, 0);
+      }
     });
     // last s-step of the layer: the pieces the (shorter) last chunk had no MFMA group for
     if constexpr (OBJ_B3_SPREAD_DMA && s == NS - 1) {
@@ -967,7 +986,7 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false, bool HOIST = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr) {
   static_assert(!B3 || !SIGMA_ONLY, "split-bf16 mode: every layer (no density-only variant)");
-  static_assert(!HOIST || (FUSED && !SAVE && !B3 && !SIGMA_ONLY), "hoisting: fp32 inference form of the fused kernel");
+  static_assert(!HOIST || (FUSED && !SAVE && !SIGMA_ONLY), "hoisting: inference form of the fused kernel");
   constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");

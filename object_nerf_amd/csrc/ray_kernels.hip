@@ -799,7 +799,18 @@ __device__ __forceinline__ float blob_weight(const float* blob, bool vox, int l,
   const int chunk = ks / kg, kl = ks % kg, g4 = kl / 4, j = kl % 4, m = row >> 5, lane = (row & 31) + 32 * half;
   return blob[base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j];
 }
+// the same element of the split-bf16 stream: hi + mid + lo of the three planes (exactly the fp32 weight)
+__device__ __forceinline__ float blob_weight_b3(const void* blob, bool vox, int l, int ks, int half, int row) {
+  const int nt = layer_nt(l), spc = b3_steps_per_chunk(nt);
+  const int s = ks >> 3, j = ks & 7, chunk = s / spc, sl = s % spc, m = row >> 5, lane = (row & 31) + 32 * half;
+  const uint16_t* p = (const uint16_t*)((const char*)blob + ((long)layer_chunk_start(vox, l) + chunk) * kB3ChunkBytes +
+                                        (long)((sl * nt + m) * 3) * 1024 + lane * 16 + j * 2);
+  const float hi = __uint_as_float((uint32_t)p[0] << 16), mid = __uint_as_float((uint32_t)p[512] << 16),
+              lo = __uint_as_float((uint32_t)p[1024] << 16);
+  return (hi + mid) + lo;
+}
 constexpr int kRbRays = 8;
+template <bool B3>
 __global__ void __launch_bounds__(448) ray_bias_kernel(const RayBiasArgs a) {
   __shared__ float sx[kRbRays][96];          // per ray: code (64) | PE4(dir) (27)
   const int o = threadIdx.x;
@@ -821,7 +832,8 @@ __global__ void __launch_bounds__(448) ray_bias_kernel(const RayBiasArgs a) {
     if (is_code) {
       const int ks0 = ks_emb(vox) + (vox ? kKsObjVox : 0);        // first code k-step of the object input list (layout.h)
 #pragma unroll
-      for (int c = 0; c < 64; ++c) w[c] = blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
+      for (int c = 0; c < 64; ++c)
+        w[c] = B3 ? blob_weight_b3(a.blob, vox, l, ks0 + (c & 31), c >> 5, row) : blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
     } else {
       const int nh = l == L_SD ? 128 : 64;
 #pragma unroll
@@ -831,7 +843,7 @@ __global__ void __launch_bounds__(448) ray_bias_kernel(const RayBiasArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int c = dir_slot_col(i, h);
-          if (c >= 0) w[c] = blob_weight(a.blob, vox, l, nh + i, h, row);
+          if (c >= 0) w[c] = B3 ? blob_weight_b3(a.blob, vox, l, nh + i, h, row) : blob_weight(a.blob, vox, l, nh + i, h, row);
         }
     }
   }
@@ -1140,12 +1152,13 @@ int objnerf_composite_finish(const float* seg_records, int64_t n_rays, int S, in
 
 int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   if (!m || !out || !m->blob || !m->aux || !m->rays || m->n_rays < 0) return set_error(-1, "ray_bias: bad arguments");
-  if (m->mfma_bf16x3) return set_error(-1, "ray_bias: the fp32 weight stream is needed (not the split-bf16 one)");
   if (m->do_object && !m->codes) return set_error(-1, "ray_bias: the object branch needs codes");
   if (m->n_rays == 0) return 0;
   RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out};
   const long blocks = (m->n_rays + kRbRays - 1) / kRbRays;
-  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(448), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048));
+  if (m->mfma_bf16x3) hipLaunchKernelGGL(ray_bias_kernel<true>, grid, dim3(448), 0, (hipStream_t)stream, a);     // blob = the split-bf16 stream
+  else hipLaunchKernelGGL(ray_bias_kernel<false>, grid, dim3(448), 0, (hipStream_t)stream, a);
   return check_launch("ray_bias");
 }
 

@@ -176,8 +176,8 @@ def test_c_abi_argument_validation():
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * (128 // 32) * _lib.SEG_REC_FLOATS + 256
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * ((128 // 32) * _lib.SEG_REC_FLOATS + rb) + 256
-    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, mfma_bf16x3=1)            # split-bf16 passes do not hoist
-    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * (128 // 32) * _lib.SEG_REC_FLOATS + 256
+    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, mfma_bf16x3=1)            # the split-bf16 mode hoists as well
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * ((128 // 32) * _lib.SEG_REC_FLOATS + rb) + 256
     for kw in (dict(noise_std=1.0), dict(is_eval=0, frustum_bound_th=0.025)):        # noise / occlusion mask: two-kernel form
         c2 = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1, **kw)
         assert l.objnerf_render_workspace_bytes(C.byref(c2), 1000) == 4 * 1000 * 128 * 8 + 256
@@ -230,9 +230,9 @@ def test_c_abi_argument_validation():
     b.S, b.comp_rec, b.do_scene, b.do_object = 64, 64, 0, 1
     assert l.objnerf_mlp_eval(C.byref(b), None) < 0 and b"comp_w needs" in l.objnerf_last_error()
     b.do_scene, b.do_object, b.comp_w, b.comp_rec, b.sigma = 1, 0, None, None, 64
-    b.ray_bias, b.mfma_bf16x3 = 64, 1
+    b.ray_bias, b.emb_xyz, b.emb_dir, b.n_points = 64, 64, 64, 4                  # memory form: no rays to hoist over
     assert l.objnerf_mlp_eval(C.byref(b), None) < 0 and b"ray_bias needs" in l.objnerf_last_error()
-    assert l.objnerf_ray_bias(C.byref(b), C.c_void_p(64), None) < 0 and b"fp32 weight stream" in l.objnerf_last_error()
+    assert l.objnerf_ray_bias(C.byref(b), None, None) < 0 and b"ray_bias: bad arguments" in l.objnerf_last_error()
     assert l.objnerf_composite_finish(None, 4, 40, 0, 0, 0, None, None, None, None, None, None, None, None) < 0
     assert b"multiple of 32" in l.objnerf_last_error()
 

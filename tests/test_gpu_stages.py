@@ -360,13 +360,14 @@ def test_composite_multi_matches_oracle(variant):
         check(own[i], want, 2e-5, "own weights %d" % i)
 
 
-@pytest.mark.single_mode
+@pytest.mark.parametrize("b3", [False, True])
 @pytest.mark.parametrize("sname", ["voxel", "plain"])
-def test_hoisted_per_ray_terms_match_the_per_sample_contraction(sname):
+def test_hoisted_per_ray_terms_match_the_per_sample_contraction(sname, b3):
     """objnerf_ray_bias + objnerf_mlp_args.ray_bias (the object code's and the direction embedding's share of four layers
     computed once per ray, their k-steps skipped in the MLP kernel: 2.45 % fewer MFMAs) against the same kernel contracting
     every term per sample point -- same sums in another association: sigma / rgb of both branches within 2e-6 (normwise), on a
-    batch whose rays straddle waves (S = 40) and on one with S = 64; per-ray codes."""
+    batch whose rays straddle waves (S = 40) and on one with S = 64; per-ray codes; fp32-MFMA and split-bf16 arithmetic
+    (there whole 8-k-step groups are skipped and the hoisted k-steps of a partly covered group enter as zeros)."""
     sc = cases.scene_for(A, sname, device=DEV)
     use_voxel = cases.SCENES[sname][0]
     l = _lib.lib()
@@ -375,12 +376,12 @@ def test_hoisted_per_ray_terms_match_the_per_sample_contraction(sname):
         n = rays.shape[0]
         z = (rays[:, 6:7] + (rays[:, 7:8] - rays[:, 6:7]) * torch.linspace(0, 1, S, device=DEV)).contiguous()
         codes = sc.code_library({"instance_ids": synth.per_ray_ids(n, seed=9).to(DEV)})["embedding_instance"].detach().contiguous()
-        blob, aux = sc.models["coarse"].packed(split_bf16=False)
+        blob, aux = sc.models["coarse"].packed(split_bf16=b3)
         outs = []
         for hoist in (False, True):
             buf = {k: torch.empty(n, S, *sh, device=DEV) for k, sh in dict(sigma=(), rgb=(3,), isig=(), irgb=(3,)).items()}
             a = _lib.MlpArgs()
-            a.use_voxel, a.do_scene, a.do_object = int(use_voxel), 1, 1
+            a.use_voxel, a.do_scene, a.do_object, a.mfma_bf16x3 = int(use_voxel), 1, 1, int(b3)
             a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
             a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), z.data_ptr(), n, S
             a.codes, a.code_stride = codes.data_ptr(), 64
