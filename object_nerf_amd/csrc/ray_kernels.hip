@@ -785,7 +785,7 @@ __global__ void ray_box_kernel(const float* __restrict__ rays_o, const float* __
 // dir_encoding / inst_dir_encoding (116, 147) -- out[ray] = bias + W[:, columns of x] . x, written in the layer's
 // D-register order so that a lane of the MLP kernel reads its 16 values as one 64-byte piece.
 // Block = 448 threads, thread = one output row (its weights live in registers: read once from the packed stream, by the
-// same layout arithmetic as the packer's), 8 rays per trip staged in LDS.
+// same layout arithmetic as the packer's), 16 rays per trip staged in LDS.
 // ------------------------------------------------------------------------------------------
 struct RayBiasArgs {
   const float* blob; const float* aux; const float* rays; const float* codes;
@@ -809,10 +809,10 @@ __device__ __forceinline__ float blob_weight_b3(const void* blob, bool vox, int 
               lo = __uint_as_float((uint32_t)p[1024] << 16);
   return (hi + mid) + lo;
 }
-constexpr int kRbRays = 8;
+constexpr int kRbRays = 16;
 template <bool B3>
 __global__ void __launch_bounds__(448) ray_bias_kernel(const RayBiasArgs a) {
-  __shared__ float sx[kRbRays][96];          // per ray: code (64) | PE4(dir) (27)
+  __shared__ __attribute__((aligned(16))) float sx[kRbRays][96];          // per ray: code (64) | PE4(dir) (27)
   const int o = threadIdx.x;
   const bool vox = a.use_voxel != 0;
   // output row -> layer, row inside it, position in the vector
@@ -871,12 +871,22 @@ __global__ void __launch_bounds__(448) ray_bias_kernel(const RayBiasArgs a) {
     if (live) {
       for (int rr = 0; rr < kRbRays && r0 + rr < a.n_rays; ++rr) {
         float acc = bias;
+        // the ray's inputs are the same for every thread: 16-byte LDS broadcasts, 4 terms per read
         if (is_code) {
 #pragma unroll
-          for (int c = 0; c < 64; ++c) acc = fmaf(w[c], sx[rr][c], acc);
+          for (int c4 = 0; c4 < 16; ++c4) {
+            const f32x4 x = *(const f32x4*)&sx[rr][4 * c4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = fmaf(w[4 * c4 + j], x[j], acc);
+          }
         } else {
 #pragma unroll
-          for (int c = 0; c < 27; ++c) acc = fmaf(w[c], sx[rr][64 + c], acc);
+          for (int c4 = 0; c4 < 7; ++c4) {
+            const f32x4 x = *(const f32x4*)&sx[rr][64 + 4 * c4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (4 * c4 + j < 27) acc = fmaf(w[4 * c4 + j], x[j], acc);
+          }
         }
         a.out[(r0 + rr) * kRayBiasFloats + pos] = acc;
       }

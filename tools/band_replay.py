@@ -31,7 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out", nargs="?", default="gpurun_out/r03_band_replay.md")
     ap.add_argument("--world", type=int, default=8)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--row-block", type=int, default=4)
     a = ap.parse_args()
     import ctypes as C
@@ -48,7 +48,7 @@ def main():
     lines = ["# Band replay: the %d ranks' shares of one strong-scaling frame, rendered one after the other on ONE MI355X (round 3)" % a.world, "",
              "`tools/band_replay.py`. render ms = hipEvents around the rank's whole share (ray generation for configs[4], "
              "both passes, compositing), MLP ms = the fused kernel alone; spread = max / mean - 1; predicted efficiency = "
-             "mean / (max + gather). %d timed steps per rank after one warm-up." % a.steps, ""]
+             "mean / (max + gather). Median of %d timed steps per rank after one warm-up." % a.steps, ""]
     summ = ["| config | split | mean render ms | max render ms | spread | gather ms (measured part + modelled wire) | predicted %d-rank efficiency | pixels bit-equal to the unsharded frame |" % a.world,
             "|---|---|---|---|---|---|---|---|"]
     for cfg in (3, 4):
@@ -76,7 +76,9 @@ def main():
                 launches, kms = C.c_int64(0), C.c_double(0.0)
                 lib.objnerf_timing_read(C.byref(launches), C.byref(kms))
                 lib.objnerf_timing_enable(0)
-                render_ms, _ = wl.phase_ms()
+                # median over the timed steps: one step that catches a clock dip must not pass for imbalance
+                per_step = sorted(x.elapsed_time(y) for x, y, _ in wl.marks)
+                render_ms = per_step[len(per_step) // 2]
                 idx = shards.local_index(r, dev)
                 for k in wl.gather_keys:
                     equal = equal and torch.equal(wl.last[k], whole[k][idx])
