@@ -165,8 +165,10 @@ typedef struct {
   const float* ray_bias;
 } objnerf_mlp_args;
 #define OBJNERF_RAY_BIAS_FLOATS 448
-/* out (n_rays, OBJNERF_RAY_BIAS_FLOATS) for objnerf_mlp_args.ray_bias: uses blob, aux, rays, codes / code_stride, n_rays,
- * use_voxel, do_scene, do_object of `args`. */
+/* out: objnerf_ray_bias_floats(n_rays) floats -- the (n_rays, OBJNERF_RAY_BIAS_FLOATS) vectors for
+ * objnerf_mlp_args.ray_bias, followed by the call's own scratch (the hoisted weight columns as a compact matrix).
+ * Uses blob, aux, mfma_bf16x3, rays, codes / code_stride, n_rays, use_voxel, do_scene, do_object of `args`. */
+int64_t objnerf_ray_bias_floats(int64_t n_rays);
 int objnerf_ray_bias(const objnerf_mlp_args* args, float* out, void* stream);
 #define OBJNERF_SEG_REC_FLOATS 16
 int objnerf_mlp_eval(const objnerf_mlp_args* args, void* stream);

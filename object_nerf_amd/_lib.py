@@ -175,6 +175,7 @@ SIGNATURES = {
     "objnerf_voxel_embed": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP]),
     "objnerf_mlp_eval": (C.c_int, [C.POINTER(MlpArgs), _VP]),
     "objnerf_ray_bias": (C.c_int, [C.POINTER(MlpArgs), _VP, _VP]),
+    "objnerf_ray_bias_floats": (C.c_int64, [C.c_int64]),
     "objnerf_composite": (C.c_int, [C.POINTER(CompositeArgs), _VP]),
     "objnerf_composite_finish": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "objnerf_sample_pdf_merge": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, _VP, _VP, _VP]),

@@ -312,7 +312,7 @@ static int64_t pass_area_floats(const objnerf_render_cfg* cfg, int64_t n_rays) {
 }
 int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_rays) {
   if (!cfg || n_rays < 0) return -1;
-  return (int64_t)sizeof(float) * (pass_area_floats(cfg, n_rays) + (hoists(cfg) ? n_rays * OBJNERF_RAY_BIAS_FLOATS : 0)) + 256;
+  return (int64_t)sizeof(float) * (pass_area_floats(cfg, n_rays) + (hoists(cfg) ? objnerf_ray_bias_floats(n_rays) : 0)) + 256;
 }
 
 static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* out,
@@ -406,7 +406,7 @@ struct MultiWs {
   bool hoist;
   // per set: the arrays listed above, padded to 64 bytes, then (fp32 passes) the per-ray vectors of objnerf_ray_bias
   int64_t head_floats() const { return (N * ((int64_t)S + (S + I) + 4LL * Smax + S) + N + 15) / 16 * 16; }
-  int64_t set_floats() const { return head_floats() + (hoist ? N * OBJNERF_RAY_BIAS_FLOATS : 0); }
+  int64_t set_floats() const { return head_floats() + (hoist ? (objnerf_ray_bias_floats(N) + 15) / 16 * 16 : 0); }
   float* ray_bias(int k) const { return set(k) + head_floats(); }
   float* set(int k) const { return (float*)base + set_floats() * k; }
   float* zc(int k) const { return set(k); }

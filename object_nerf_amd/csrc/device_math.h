@@ -7,6 +7,8 @@
 namespace objnerf {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+// four consecutive floats at ANY 4-byte-aligned address as one 16-byte access (gfx950 global memory needs dword alignment only)
+typedef f32x4 f32x4u __attribute__((aligned(4)));
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // sin / cos with 3-term Cody-Waite reduction by pi/2 and the classic degree-7/8 minimax

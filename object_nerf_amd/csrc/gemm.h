@@ -45,9 +45,8 @@ struct GemmArgs {
   long segK[4];
 };
 
-// a 16-byte load of four consecutive floats at ANY 4-byte-aligned address: gfx950 global loads need dword alignment only,
-// so rows of 271 / 439 / 527 / 27 floats (the embedding blocks and their weight columns) still move as dwordx4
-typedef f32x4 f32x4u __attribute__((aligned(4)));
+// operand rows of 271 / 439 / 527 / 27 floats (the embedding blocks and their weight columns) still move as dwordx4: f32x4u
+// (device_math.h), a 16-byte load at any 4-byte-aligned address
 constexpr int GBM = 128, GBN = 128, GBK = 32;
 constexpr int GLDK = 36;      // K-contiguous operands sit in LDS as [row][k], rows padded to 36 floats against bank conflicts
 constexpr int GLDR = 128;     // row-contiguous operands sit in LDS as [k][row]

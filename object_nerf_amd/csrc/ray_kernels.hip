@@ -784,8 +784,9 @@ __global__ void ray_box_kernel(const float* __restrict__ rays_o, const float* __
 // along a ray -- the object code in instance_encoding_1 / _3 (nerf_model.py:128-138), the direction embedding in
 // dir_encoding / inst_dir_encoding (116, 147) -- out[ray] = bias + W[:, columns of x] . x, written in the layer's
 // D-register order so that a lane of the MLP kernel reads its 16 values as one 64-byte piece.
-// Block = 448 threads, thread = one output row (its weights live in registers: read once from the packed stream, by the
-// same layout arithmetic as the packer's), 16 rays per trip staged in LDS.
+// Two steps: a one-workgroup gather of the weight columns into a compact matrix, then lane = ray with the weights as
+// wave-uniform operands (round 3 first tried thread = output row with the rays' inputs broadcast from LDS: 1.07 ms per
+// frame pass, bound by one wave-level LDS read per 4 terms).
 // ------------------------------------------------------------------------------------------
 struct RayBiasArgs {
   const float* blob; const float* aux; const float* rays; const float* codes;
@@ -809,88 +810,88 @@ __device__ __forceinline__ float blob_weight_b3(const void* blob, bool vox, int 
               lo = __uint_as_float((uint32_t)p[1024] << 16);
   return (hi + mid) + lo;
 }
-constexpr int kRbRays = 16;
+// Step 1 (one workgroup): the hoisted weight columns as a compact matrix wm[group][c][16] + bias[group][16], group = 16
+// consecutive floats of the per-ray vector (one (layer, out tile, lane half) of the MLP kernel's D layout), c = input
+// column (64 code columns or 27 direction columns) -- read from the packed stream by the packer's own layout arithmetic.
+constexpr int kRbGroups = kRayBiasFloats / 16;                  // 28: O1 8 | O3 8 | SD 8 | OD 4
+constexpr int kRbMatFloats = kRbGroups * 64 * 16 + kRbGroups * 16;
 template <bool B3>
-__global__ void __launch_bounds__(448) ray_bias_kernel(const RayBiasArgs a) {
-  __shared__ __attribute__((aligned(16))) float sx[kRbRays][96];          // per ray: code (64) | PE4(dir) (27)
-  const int o = threadIdx.x;
+__global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs a, float* __restrict__ wm) {
+  const int o = threadIdx.x;                  // position in the per-ray vector
   const bool vox = a.use_voxel != 0;
-  // output row -> layer, row inside it, position in the vector
-  int l, row, off;
-  if (o < 128) { l = L_O1; row = o; off = 0; }
-  else if (o < 256) { l = L_O3; row = o - 128; off = 128; }
-  else if (o < 384) { l = L_SD; row = o - 256; off = 256; }
-  else { l = L_OD; row = o - 384; off = 384; }
-  const bool is_code = o < 256;               // wave-uniform (waves 0-3 / 4-6)
-  const bool live = is_code ? a.do_object != 0 : (l == L_SD ? a.do_scene != 0 : a.do_object != 0);
-  const int w5 = row & 31;
-  const int pos = off + (row >> 5) * 32 + ((w5 >> 2) & 1) * 16 + (w5 & 3) + 4 * (w5 >> 3);   // [m][half][reg]: row = 32 m + (r & 3) + 8 (r >> 2) + 4 half
-  float w[64];
-  float bias = 0.f;
-  if (live) {
-    bias = a.aux[aux_bias_off(l) + (pos - off)];
-    if (is_code) {
-      const int ks0 = ks_emb(vox) + (vox ? kKsObjVox : 0);        // first code k-step of the object input list (layout.h)
+  const int l = o < 128 ? L_O1 : (o < 256 ? L_O3 : (o < 384 ? L_SD : L_OD));
+  const int off = o < 128 ? 0 : (o < 256 ? 128 : (o < 384 ? 256 : 384));
+  const int q = o - off, m = q >> 5, half = (q >> 4) & 1, r = q & 15;
+  const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;   // D layout
+  const int g = o >> 4, j = o & 15;
+  float* wrow = wm + (long)g * 64 * 16 + j;
+  for (int c = 0; c < 64; ++c) wrow[c * 16] = 0.f;
+  if (o < 256) {
+    const int ks0 = ks_emb(vox) + (vox ? kKsObjVox : 0);        // first code k-step of the object input list (layout.h)
+    for (int c = 0; c < 64; ++c)
+      wrow[c * 16] = B3 ? blob_weight_b3(a.blob, vox, l, ks0 + (c & 31), c >> 5, row) : blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
+  } else {
+    const int nh = l == L_SD ? 128 : 64;
+    for (int i = 0; i < kKsDir; ++i)
+      for (int h = 0; h < 2; ++h) {
+        const int c = dir_slot_col(i, h);
+        if (c >= 0) wrow[c * 16] = B3 ? blob_weight_b3(a.blob, vox, l, nh + i, h, row) : blob_weight(a.blob, vox, l, nh + i, h, row);
+      }
+  }
+  wm[kRbGroups * 64 * 16 + o] = a.aux[aux_bias_off(l) + q];
+}
+// Step 2: lane = ray (its code and direction embedding in registers), the weights of 16 outputs at a time as wave-uniform
+// (scalar) operands; every lane stores the 16 outputs as one 64-byte piece of its ray's vector.
+__global__ void __launch_bounds__(256) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ wm) {
+  const long ray = (long)blockIdx.x * 256 + threadIdx.x;
+  if (ray >= a.n_rays) return;
+  float x[64], pe[28];
+  if (a.do_object) {
+    const float* cp = a.codes + ray * a.code_stride;
 #pragma unroll
-      for (int c = 0; c < 64; ++c)
-        w[c] = B3 ? blob_weight_b3(a.blob, vox, l, ks0 + (c & 31), c >> 5, row) : blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
-    } else {
-      const int nh = l == L_SD ? 128 : 64;
+    for (int c4 = 0; c4 < 16; ++c4) {
+      const f32x4 v = *(const f32x4u*)(cp + 4 * c4);
 #pragma unroll
-      for (int c = 0; c < 27; ++c) w[c] = 0.f;
-#pragma unroll
-      for (int i = 0; i < kKsDir; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int c = dir_slot_col(i, h);
-          if (c >= 0) w[c] = B3 ? blob_weight_b3(a.blob, vox, l, nh + i, h, row) : blob_weight(a.blob, vox, l, nh + i, h, row);
-        }
+      for (int j = 0; j < 4; ++j) x[4 * c4 + j] = v[j];
     }
   }
-  for (long r0 = (long)blockIdx.x * kRbRays; r0 < a.n_rays; r0 += (long)gridDim.x * kRbRays) {
-    __syncthreads();
-    for (int e = o; e < kRbRays * 96; e += 448) {
-      const int rr = e / 96, c = e % 96;
-      const long ray = r0 + rr < a.n_rays ? r0 + rr : a.n_rays - 1;
-      float v = 0.f;
-      if (c < 64) {
-        v = a.codes ? a.codes[ray * a.code_stride + c] : 0.f;
-      } else if (c < 64 + kDirC) {
-        // Embedding(3, 4): [d, sin(2^k d), cos(2^k d)] (embedding_helper.py:69-74), the MLP kernel's own sin / cos
-        const int cc = c - 64;
-        if (cc < 3) v = a.rays[ray * 8 + 3 + cc];
-        else {
-          const int q = cc - 3, k = q / 6, fn = (q / 3) & 1, coord = q % 3;
-          const SinCos sc = psincos(a.rays[ray * 8 + 3 + coord] * (float)(1 << k));
-          v = fn ? sc.c : sc.s;
-        }
-      }
-      sx[rr][c] = v;
+  // Embedding(3, 4): [d, sin(2^k d), cos(2^k d)] (embedding_helper.py:69-74), the MLP kernel's own sin / cos
+  const float d[3] = {a.rays[ray * 8 + 3], a.rays[ray * 8 + 4], a.rays[ray * 8 + 5]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pe[c] = d[c];
+#pragma unroll
+  for (int k = 0; k < kFreqDir; ++k)
+#pragma unroll
+    for (int coord = 0; coord < 3; ++coord) {
+      const SinCos sc = psincos(d[coord] * (float)(1 << k));
+      pe[3 + 6 * k + coord] = sc.s;
+      pe[3 + 6 * k + 3 + coord] = sc.c;
     }
-    __syncthreads();
-    if (live) {
-      for (int rr = 0; rr < kRbRays && r0 + rr < a.n_rays; ++rr) {
-        float acc = bias;
-        // the ray's inputs are the same for every thread: 16-byte LDS broadcasts, 4 terms per read
-        if (is_code) {
+  pe[27] = 0.f;
+  float* out = a.out + ray * kRayBiasFloats;
+  const float* bias = wm + kRbGroups * 64 * 16;
+#pragma unroll 1
+  for (int g = 0; g < kRbGroups; ++g) {
+    const bool is_code = g < 16;
+    const bool live = is_code ? a.do_object != 0 : (g < 24 ? a.do_scene != 0 : a.do_object != 0);
+    if (!live) continue;                       // uniform
+    const float* w = wm + (long)g * 64 * 16;
+    float acc[16];
 #pragma unroll
-          for (int c4 = 0; c4 < 16; ++c4) {
-            const f32x4 x = *(const f32x4*)&sx[rr][4 * c4];
+    for (int j = 0; j < 16; ++j) acc[j] = bias[g * 16 + j];
+    if (is_code) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = fmaf(w[4 * c4 + j], x[j], acc);
-          }
-        } else {
+      for (int c = 0; c < 64; ++c)
 #pragma unroll
-          for (int c4 = 0; c4 < 7; ++c4) {
-            const f32x4 x = *(const f32x4*)&sx[rr][64 + 4 * c4];
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(w[c * 16 + j], x[c], acc[j]);
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (4 * c4 + j < 27) acc = fmaf(w[4 * c4 + j], x[j], acc);
-          }
-        }
-        a.out[(r0 + rr) * kRayBiasFloats + pos] = acc;
-      }
+      for (int c = 0; c < 27; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(w[c * 16 + j], pe[c], acc[j]);
     }
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) *(f32x4u*)(out + g * 16 + 4 * j4) = f32x4{acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]};
   }
 }
 
@@ -1160,15 +1161,17 @@ int objnerf_composite_finish(const float* seg_records, int64_t n_rays, int S, in
   return check_launch("composite_finish");
 }
 
+int64_t objnerf_ray_bias_floats(int64_t n_rays) { return n_rays < 0 ? -1 : n_rays * kRayBiasFloats + kRbMatFloats; }
+
 int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   if (!m || !out || !m->blob || !m->aux || !m->rays || m->n_rays < 0) return set_error(-1, "ray_bias: bad arguments");
   if (m->do_object && !m->codes) return set_error(-1, "ray_bias: the object branch needs codes");
   if (m->n_rays == 0) return 0;
   RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out};
-  const long blocks = (m->n_rays + kRbRays - 1) / kRbRays;
-  const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048));
-  if (m->mfma_bf16x3) hipLaunchKernelGGL(ray_bias_kernel<true>, grid, dim3(448), 0, (hipStream_t)stream, a);     // blob = the split-bf16 stream
-  else hipLaunchKernelGGL(ray_bias_kernel<false>, grid, dim3(448), 0, (hipStream_t)stream, a);
+  float* wm = out + m->n_rays * kRayBiasFloats;          // the compact weight matrix lives behind the vectors
+  if (m->mfma_bf16x3) hipLaunchKernelGGL(ray_bias_weights_kernel<true>, dim3(1), dim3(448), 0, (hipStream_t)stream, a, wm);   // blob = the split-bf16 stream
+  else hipLaunchKernelGGL(ray_bias_weights_kernel<false>, dim3(1), dim3(448), 0, (hipStream_t)stream, a, wm);
+  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (const float*)wm);
   return check_launch("ray_bias");
 }
 

@@ -170,14 +170,16 @@ def test_c_abi_argument_validation():
     # per 32 samples when the passes composite in the MLP kernel's epilogue (no occlusion mask, no noise, S % 32 == 0);
     # plus, in fp32 arithmetic, the per-ray vectors of the hoisted terms (1792 B per ray) unless no_hoist
     rb = _lib.RAY_BIAS_FLOATS
+    rb_total = l.objnerf_ray_bias_floats(1000)                    # the vectors + the call's compact weight matrix
+    assert rb_total == 1000 * rb + 28 * 64 * 16 + 28 * 16
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64, separate_composite=1, no_hoist=1)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * 128 * 8 + 256
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * (128 // 32) * _lib.SEG_REC_FLOATS + 256
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
-    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * ((128 // 32) * _lib.SEG_REC_FLOATS + rb) + 256
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * (1000 * (128 // 32) * _lib.SEG_REC_FLOATS + rb_total) + 256
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64, mfma_bf16x3=1)            # the split-bf16 mode hoists as well
-    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * ((128 // 32) * _lib.SEG_REC_FLOATS + rb) + 256
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * (1000 * (128 // 32) * _lib.SEG_REC_FLOATS + rb_total) + 256
     for kw in (dict(noise_std=1.0), dict(is_eval=0, frustum_bound_th=0.025)):        # noise / occlusion mask: two-kernel form
         c2 = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1, **kw)
         assert l.objnerf_render_workspace_bytes(C.byref(c2), 1000) == 4 * 1000 * 128 * 8 + 256
@@ -192,7 +194,7 @@ def test_c_abi_argument_validation():
     per_set = (1000 * (64 + 128 + 4 * 128 + 64) + 1000 + 15) // 16 * 16       # depths, sigma / rgb, own weights, ray index; 64-byte units
     assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * per_set + 64 * 3 + 2) + 256
     mc = _lib.RenderMultiCfg(N_samples=64, N_importance=64)                    # + the per-ray vectors of each set (fp32 passes)
-    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * (per_set + 1000 * _lib.RAY_BIAS_FLOATS) + 64 * 3 + 2) + 256
+    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * (per_set + (l.objnerf_ray_bias_floats(1000) + 15) // 16 * 16) + 64 * 3 + 2) + 256
     rin, out = _lib.RenderMultiIn(), _lib.RenderMultiOut()
     rin.n_rays, rin.K = 8, 0
     assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0

@@ -389,7 +389,7 @@ def test_hoisted_per_ray_terms_match_the_per_sample_contraction(sname, b3):
                 a.grid = sc.embeddings["xyz"].grid_struct()
             a.sigma, a.rgb, a.inst_sigma, a.inst_rgb = (buf[k].data_ptr() for k in ("sigma", "rgb", "isig", "irgb"))
             if hoist:
-                rb = torch.empty(n, _lib.RAY_BIAS_FLOATS, device=DEV)
+                rb = torch.empty(l.objnerf_ray_bias_floats(n), device=DEV)
                 _lib.check(l.objnerf_ray_bias(C.byref(a), _lib.ptr(rb), _lib.stream_ptr()), "ray_bias")
                 a.ray_bias = rb.data_ptr()
             _lib.check(l.objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval")

@@ -27,8 +27,10 @@ def main(db, n=307200, S=64, I=64):
             b, note = n * (32 + 4 * S), ""
         elif "composite_finish" in name:
             b, note = n * (10 * (S + S + I) / 2.0 + 40), "mean of the coarse (S) and fine (S + I) launch; half of each wave idles on the weights"
+        elif "ray_bias_weights" in name:
+            continue
         elif "ray_bias" in name:
-            b, note = n * (268 + 1792), "weights of the four layers in registers, 8 rays per trip"
+            b, note = n * (268 + 1792), "lane = ray, weights as wave-uniform operands, 64-byte stores"
         elif "sample_pdf_merge" in name:
             b, note = n * (8 * S + 4 * (S + I)), "not bandwidth-bound: one wave per ray (float64 prefix scan of the cdf, per-lane binary searches, merge)"
         else:
