@@ -57,19 +57,33 @@ def issue_render_rays(sc, call, codes=None):
                          pass_through_mask=ptm, chunk=call["scalars"]["chunk"], _randoms=rnd, **kw)
 
 
-def grade(out, gold, prefix, coarse_tol=1e-4, fine_tol=2e-2):
+def floors_of(sc, calls, gold, prefix):
+    """the reference's own fp32-vs-fp64 distance per result key on these calls: the CPU oracle in float64 on the recorded
+    inputs (chunk by chunk, concatenated like the caller does) against the reference run's outputs"""
+    chunks = []
+    for c in calls:
+        t = c["tens"]
+        kw = {k: v for k, v in c["scalars"].items() if k != "chunk"}
+        rnd = None
+        if "perturb_rand" in t:
+            rnd = dict(perturb_rand=t["perturb_rand"], u_rand=t["u_rand"], noise=[t["noise%d" % i] for i in range(4)])
+        chunks.append(H.oracle_f64(sc, True, t["rays"], t["embedding_instance"], t.get("pass_through_mask"), rnd, kw))
+    f64 = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}
+    return {k: H.normwise(gold[prefix + k], f64[k]) for k in f64}
+
+
+def grade(out, gold, prefix, floors, coarse_tol=1e-4):
+    """coarse-pass keys: the BASELINE contract, 1e-4; fine-pass keys (downstream of the data-dependent sampling): 3x the
+    reference's own fp32-vs-fp64 distance on the same calls, as in test_gpu_render.py (round 2 allowed a flat 2e-2)"""
     keys = [k[len(prefix):] for k in gold if k.startswith(prefix) and not k.startswith(prefix + "_") and
             not k.startswith(prefix + "dL_") and not k.startswith(prefix + "grad")]
     assert sorted(out) == sorted(keys)
     for k in keys:
         g = gold[prefix + k]
         assert out[k].shape == g.shape, k
-        if k == "obj_ids_coarse":
-            nz = gold[prefix + "z_vals_coarse"] != 0
-            assert torch.equal(out[k].cpu()[nz], g[nz])
-            continue
         err = H.normwise(out[k], g)
-        assert err <= (coarse_tol if k.endswith("coarse") else fine_tol), "%s%s: %.3e" % (prefix, k, err)
+        tol = coarse_tol if k.endswith("coarse") else max(H.FLOOR_FACTOR * floors[k], 2e-5)
+        assert err <= tol, "%s%s: %.3e > %.3e (fp64 floor %.3e)" % (prefix, k, err, tol, floors[k])
 
 
 def test_validation_step_chunk_loop(scene, gold):
@@ -78,7 +92,7 @@ def test_validation_step_chunk_loop(scene, gold):
     with torch.no_grad():
         chunks = [issue_render_rays(scene, c) for c in calls]
     out = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}          # train.py:101-104
-    grade(out, gold, "val_")
+    grade(out, gold, "val_", floors_of(scene, calls, gold, "val_"))
     # the numbers validation_step derives from the result dict (models/losses.py, utils/metrics.py)
     mse = ((out["rgb_fine"].cpu() - gold["val_rgb_fine"]) ** 2).mean()
     assert -10 * torch.log10(mse.clamp_min(1e-20)) > 60.0
@@ -103,7 +117,7 @@ def test_training_step_forward_and_backward(scene, gold):
             assert torch.equal(table.detach()[ids], rows)
             chunks.append(issue_render_rays(scene, c, codes=scene.code_library({"instance_ids": ids})["embedding_instance"]))
         out = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}
-        grade({k: v.detach() for k, v in out.items()}, gold, "train_")
+        grade({k: v.detach() for k, v in out.items()}, gold, "train_", floors_of(scene, calls, gold, "train_"))
         heads = [k for k in out if ("train_dL_" + k) in gold]
         assert "rgb_fine" in heads and "opacity_instance_coarse" in heads
         torch.autograd.backward([out[k] for k in heads], [gold["train_dL_" + k].to(DEV) for k in heads])
@@ -165,7 +179,9 @@ def test_editable_renderer_chunk_loops(scene, gold, scenario, prefix, n_sets):
                                             rays_list=[c["tens"]["rays_%d" % i].to(DEV) for i in range(n_sets)],
                                             background_skip_bbox=boxes if boxes else None, **kw))
     out = {k: torch.cat([c[k] for c in chunks], 0) for k in chunks[0]}          # editable_renderer.py:289-292 / 143-150
-    grade(out, gold, prefix)
+    g = {k[len(prefix):]: v for k, v in gold.items() if k.startswith(prefix)}
+    assert sorted(out) == sorted(g)
+    H.grade_multi(out, g, scenario)            # settled rays 5e-3 on every key, <= 10 % unsettled, pixels 2e-2 (test_gpu_render.py)
 
 
 @pytest.mark.single_mode
