@@ -7,7 +7,7 @@
 namespace objnerf {
 
 template <bool TAIL>
-__device__ __forceinline__ void wgrad_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend, bool full,
+__device__ __forceinline__ void wgrad_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend,
                                             float* slot, float* lds, int tid) {
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
@@ -80,31 +80,21 @@ __device__ __forceinline__ void wgrad_piece(const WgProduct& pr, const WgTile& t
   if (want_rowsum) {
     if (tid >= 128) lds[tid - 128] = rsum;
     __syncthreads();
-    if (tid < 128) {
-      const float v = rsum + lds[tid];
-      if (full) { if (m0 + tid < pr.M) pr.rowsum[m0 + tid] += v; }
-      else slot[128 * 128 + tid] = v;
-    }
+    if (tid < 128) slot[128 * 128 + tid] = rsum + lds[tid];
     __syncthreads();
   }
-  // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Destination: the tile of dW itself when
-  // this workgroup contracted the whole K range (sole owner: plain read-modify-write), else the partial slot.
+  // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); the partial tile goes to the unit's slot
+  // as a dense 128 x 128 block (rows / columns past the product's extent are never read back)
   const int col = lane & 31, rbase = 4 * (lane >> 5);
-  float* dst = full ? pr.C + m0 * pr.ldc + n0 : slot;
-  const long ld = full ? pr.ldc : 128;
-  const int mlim = full ? (int)(pr.M - m0) : 128, nlim = full ? (int)(pr.N - n0) : 128;
 #pragma unroll
   for (int t = 0; t < (TAIL ? 3 : 4); ++t) {
     const int i = t >> 1, j = t & 1;
     if (TAIL && t >= ncol) continue;
     const int nl = TAIL ? t * 32 + col : wn * 64 + j * 32 + col;           // column inside the tile
-    if (nl >= nlim) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ml = (TAIL ? wave * 32 : wm * 64 + i * 32) + (r & 3) + 8 * (r >> 2) + rbase;
-      if (ml >= mlim) continue;
-      float* q = dst + ml * ld + nl;
-      *q = full ? *q + acc[t][r] : acc[t][r];
+      slot[ml * 128 + nl] = acc[t][r];
     }
   }
 }
@@ -149,7 +139,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   long kend = kbeg + L * GBK;
   if (kend > a.P) kend = a.P;
   float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
-  wgrad_piece<TAIL>(a.prod[tl.prod], tl, kbeg, kend, false, slot, lds, tid);      // an empty slice writes zeros
+  wgrad_piece<TAIL>(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);      // an empty slice writes zeros
 }
 
 // Adds a tile's slices to dW in ascending slice order (= ascending points): every bit of the result is reproducible.
