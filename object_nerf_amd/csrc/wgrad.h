@@ -40,6 +40,7 @@ struct WgradArgs {             // passed by value (2.5 KB of kernel arguments: n
   WgTile tile[kWgradMaxTiles];
   int nprod, ntile, nfull;     // tile[0 .. nfull) are full tiles, tile[nfull .. ntile) ragged ones
   int nz;                      // k slices per tile
+  int xcd;                     // XCD-aware unit map (tuning switch OBJNERF_WGRAD_XCD)
   long P;
   float* partials;             // slot (tile t, slice z) at (t * slices + z) * kWgradSlotFloats
 };

@@ -123,8 +123,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const int nz = a.nz;
   const long L = (KT + nz - 1) / nz;                       // k iterations per slice
   const int t0 = TAIL ? a.nfull : 0, t1 = TAIL ? a.ntile : a.nfull;
-  // unit -> (tile, slice): walk the runs of tiles that belong to one product
+  // unit -> (tile, slice): walk the runs of tiles that belong to one product.  Workgroups are dealt round-robin to the 8
+  // XCDs; with a.xcd every XCD takes one contiguous eighth of the units, so the tiles of one slice (which read the same
+  // operand panels) run on ONE XCD and share its L2
   long u = blockIdx.x;
+  if (a.xcd) {
+    const long per = (gridDim.x + 7) / 8;
+    u = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (u >= gridDim.x) return;
+  }
   int t = t0, z = 0;
   while (t < t1) {
     int run = 1;
@@ -262,6 +269,8 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
     const int nz = a.nz = wgrad_slices(P);
+    static const int xcd = [] { const char* e = getenv("OBJNERF_WGRAD_XCD"); return e ? atoi(e) : 0; }();
+    a.xcd = xcd;
     hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
     if (a.nfull > 0) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3(a.nfull * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
