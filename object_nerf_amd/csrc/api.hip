@@ -303,70 +303,90 @@ static bool pass_fuses(const objnerf_render_cfg* cfg, int S) {
 static int64_t pass_floats(const objnerf_render_cfg* cfg, int64_t n_rays, int S) {
   return pass_fuses(cfg, S) ? n_rays * (S / 32) * OBJNERF_SEG_REC_FLOATS : n_rays * S * 8;
 }
-// per-ray vectors of the hoisted terms (objnerf_ray_bias), re-computed per pass (coarse / fine weights): behind the pass area
+// A pass walks the batch in SLABS of at most kRenderSlabRays rays (MLP kernel -> compositing per slab, back to back on the
+// stream): rays are independent, so results are identical, and the workspace -- segment records or sigma / rgb, and the
+// per-ray vectors of the hoisted terms -- is bounded by the slab instead of growing with the frame (a 4K frame would
+// otherwise carry 15 GB of per-ray vectors).  A 640 x 480 frame is one slab.
+constexpr int64_t kRenderSlabRays = 1 << 20;
 static bool hoists(const objnerf_render_cfg* cfg) { return !cfg->no_hoist; }
-static int64_t pass_area_floats(const objnerf_render_cfg* cfg, int64_t n_rays) {
-  const int64_t c = pass_floats(cfg, n_rays, cfg->N_samples);
-  const int64_t f = cfg->N_importance > 0 ? pass_floats(cfg, n_rays, cfg->N_samples + cfg->N_importance) : 0;
+static int64_t slab_rays(int64_t n_rays) { return n_rays < kRenderSlabRays ? n_rays : kRenderSlabRays; }
+static int64_t pass_area_floats(const objnerf_render_cfg* cfg, int64_t slab) {
+  const int64_t c = pass_floats(cfg, slab, cfg->N_samples);
+  const int64_t f = cfg->N_importance > 0 ? pass_floats(cfg, slab, cfg->N_samples + cfg->N_importance) : 0;
   return c > f ? c : f;
 }
 int64_t objnerf_render_workspace_bytes(const objnerf_render_cfg* cfg, int64_t n_rays) {
   if (!cfg || n_rays < 0) return -1;
-  return (int64_t)sizeof(float) * (pass_area_floats(cfg, n_rays) + (hoists(cfg) ? objnerf_ray_bias_floats(n_rays) : 0)) + 256;
+  const int64_t slab = slab_rays(n_rays);
+  return (int64_t)sizeof(float) * (pass_area_floats(cfg, slab) + (hoists(cfg) ? objnerf_ray_bias_floats(slab) : 0)) + 256;
 }
 
 static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* out,
                        const float* blob, const float* aux, int S, const float* noise, const float* noise_inst,
                        void* stream) {
-  const int64_t N = in->n_rays;
   float* ws = (float*)in->workspace;
   const bool fuse = pass_fuses(cfg, S);
-  float* sigma = ws;
-  float* rgb = sigma + N * S;
-  float* isig = rgb + 3 * N * S;
-  float* irgb = isig + N * S;
-
-  objnerf_mlp_args m;
-  memset(&m, 0, sizeof(m));
-  m.use_voxel = cfg->use_voxel; m.do_scene = 1; m.do_object = cfg->forward_instance;
-  m.blob = blob; m.aux = aux; m.mfma_bf16x3 = cfg->mfma_bf16x3;
-  m.rays = in->rays; m.z_vals = out->z_vals; m.n_rays = N; m.S = S;
-  m.codes = in->codes; m.code_stride = in->code_stride; m.grid = in->grid;
   const bool inst_weights = cfg->rays_in_bbox && cfg->forward_instance;          // rendering.py:228-229
-  if (hoists(cfg)) {
-    float* rb = ws + pass_area_floats(cfg, N);
-    const int rc = objnerf_ray_bias(&m, rb, stream);
-    if (rc) return rc;
-    m.ray_bias = rb;
-  }
-  if (fuse) {
-    m.comp_w = out->weights; m.comp_rec = ws;
-    m.comp_last_delta = cfg->use_zero_as_last_delta ? 0.f : 1e10f;               // rendering.py:143-153
-    m.comp_inst_weights = inst_weights;
+  const int64_t slab = slab_rays(in->n_rays);
+  float* rb = ws + pass_area_floats(cfg, slab);
+  for (int64_t lo = 0; lo < in->n_rays; lo += slab) {
+    const int64_t N = in->n_rays - lo < slab ? in->n_rays - lo : slab;
+    float* sigma = ws;
+    float* rgb = sigma + N * S;
+    float* isig = rgb + 3 * N * S;
+    float* irgb = isig + N * S;
+    float* z = out->z_vals + lo * S;
+    float* w = out->weights + lo * S;
+
+    objnerf_mlp_args m;
+    memset(&m, 0, sizeof(m));
+    m.use_voxel = cfg->use_voxel; m.do_scene = 1; m.do_object = cfg->forward_instance;
+    m.blob = blob; m.aux = aux; m.mfma_bf16x3 = cfg->mfma_bf16x3;
+    m.rays = in->rays + lo * 8; m.z_vals = z; m.n_rays = N; m.S = S;
+    m.codes = in->codes + lo * in->code_stride; m.code_stride = in->code_stride; m.grid = in->grid;
+    if (hoists(cfg)) {
+      const int rc = objnerf_ray_bias(&m, rb, stream);
+      if (rc) return rc;
+      m.ray_bias = rb;
+    }
+    if (fuse) {
+      m.comp_w = w; m.comp_rec = ws;
+      m.comp_last_delta = cfg->use_zero_as_last_delta ? 0.f : 1e10f;             // rendering.py:143-153
+      m.comp_inst_weights = inst_weights;
+      int rc = objnerf_mlp_eval(&m, stream);
+      if (rc) return rc;
+      rc = objnerf_composite_finish(ws, N, S, cfg->forward_instance, inst_weights, cfg->white_back, w, out->opacity + lo,
+                                    out->rgb + lo * 3, out->depth + lo, out->rgb_instance ? out->rgb_instance + lo * 3 : nullptr,
+                                    out->depth_instance ? out->depth_instance + lo : nullptr,
+                                    out->opacity_instance ? out->opacity_instance + lo : nullptr, stream);
+      if (rc) return rc;
+      continue;
+    }
+    m.sigma = sigma; m.rgb = rgb;
+    m.inst_sigma = cfg->forward_instance ? isig : nullptr;
+    m.inst_rgb = cfg->forward_instance ? irgb : nullptr;
     int rc = objnerf_mlp_eval(&m, stream);
     if (rc) return rc;
-    return objnerf_composite_finish(ws, N, S, cfg->forward_instance, inst_weights, cfg->white_back, out->weights, out->opacity,
-                                    out->rgb, out->depth, out->rgb_instance, out->depth_instance, out->opacity_instance, stream);
-  }
-  m.sigma = sigma; m.rgb = rgb;
-  m.inst_sigma = cfg->forward_instance ? isig : nullptr;
-  m.inst_rgb = cfg->forward_instance ? irgb : nullptr;
-  int rc = objnerf_mlp_eval(&m, stream);
-  if (rc) return rc;
 
-  objnerf_composite_args c;
-  memset(&c, 0, sizeof(c));
-  c.n_rays = N; c.S = S; c.z_vals = out->z_vals; c.sigma = sigma; c.rgb = rgb;
-  c.inst_sigma = m.inst_sigma; c.inst_rgb = m.inst_rgb;
-  c.noise = noise; c.noise_inst = noise_inst; c.noise_std = cfg->noise_std;
-  c.white_back = cfg->white_back; c.use_zero_as_last_delta = cfg->use_zero_as_last_delta;
-  c.occlusion = (!cfg->is_eval && cfg->frustum_bound_th > 0.f) ? 1 : 0;     // rendering.py:192
-  c.frustum_bound_th = cfg->frustum_bound_th;
-  c.pass_through_mask = in->pass_through_mask;
-  c.rays_in_bbox = inst_weights;
-  c.weights = out->weights; c.opacity = out->opacity; c.rgb_map = out->rgb; c.depth = out->depth;
-  c.rgb_inst = out->rgb_instance; c.depth_inst = out->depth_instance; c.opacity_inst = out->opacity_instance;
-  return objnerf_composite(&c, stream);
+    objnerf_composite_args c;
+    memset(&c, 0, sizeof(c));
+    c.n_rays = N; c.S = S; c.z_vals = z; c.sigma = sigma; c.rgb = rgb;
+    c.inst_sigma = m.inst_sigma; c.inst_rgb = m.inst_rgb;
+    c.noise = noise ? noise + lo * S : nullptr; c.noise_inst = noise_inst ? noise_inst + lo * S : nullptr;
+    c.noise_std = cfg->noise_std;
+    c.white_back = cfg->white_back; c.use_zero_as_last_delta = cfg->use_zero_as_last_delta;
+    c.occlusion = (!cfg->is_eval && cfg->frustum_bound_th > 0.f) ? 1 : 0;     // rendering.py:192
+    c.frustum_bound_th = cfg->frustum_bound_th;
+    c.pass_through_mask = in->pass_through_mask ? in->pass_through_mask + lo : nullptr;
+    c.rays_in_bbox = inst_weights;
+    c.weights = w; c.opacity = out->opacity + lo; c.rgb_map = out->rgb + lo * 3; c.depth = out->depth + lo;
+    c.rgb_inst = out->rgb_instance ? out->rgb_instance + lo * 3 : nullptr;
+    c.depth_inst = out->depth_instance ? out->depth_instance + lo : nullptr;
+    c.opacity_inst = out->opacity_instance ? out->opacity_instance + lo : nullptr;
+    rc = objnerf_composite(&c, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* in, const objnerf_render_out* coarse,

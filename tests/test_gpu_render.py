@@ -366,3 +366,27 @@ def test_fused_compositing_is_bit_equal_to_the_two_kernel_form(case, monkeypatch
     monkeypatch.setenv("OBJNERF_COMPOSITE", "both")
     with pytest.raises(RuntimeError), torch.no_grad():
         A.render_rays(sc.models, sc.embeddings, rays[:8].to(DEV), embedding_instance=codes[:8], **kw)
+
+
+def test_batches_beyond_one_slab_are_walked_in_slabs():
+    """objnerf_render_rays walks a batch in slabs of 2^20 rays (workspace bounded by the slab, csrc/api.hip): a 1,052,676-ray
+    call (one full slab + 4,100 rays), 32 + 32 samples, against the same rays rendered alone around the slab boundary and
+    at the end -- bit-equal on every key; and the workspace of the call is the slab's, not the batch's."""
+    import ctypes as C
+    from object_nerf_amd import _lib
+    sc = scene("voxel")
+    base = synth.camera_rays(640, 480).to(DEV)
+    n = (1 << 20) + 4100
+    idx = (torch.arange(n, device=DEV) * 7919) % base.shape[0]
+    rays = base[idx].contiguous()
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": synth.per_ray_ids(n).to(DEV)})["embedding_instance"].contiguous()
+        kw = dict(N_samples=32, N_importance=32, perturb=0, noise_std=0, is_eval=True)
+        r = A.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, **kw)
+        for lo, hi in (((1 << 20) - 2050, (1 << 20) + 2050), (n - 4100, n)):
+            rs = A.render_rays(sc.models, sc.embeddings, rays[lo:hi].contiguous(), embedding_instance=codes[lo:hi].contiguous(), **kw)
+            for k in r:
+                assert torch.equal(r[k][lo:hi], rs[k]), "slab-dependent: %s at rays [%d, %d)" % (k, lo, hi)
+    cfg = _lib.RenderCfg(N_samples=32, N_importance=32, is_eval=1, mfma_bf16x3=int(os.environ.get("OBJNERF_MFMA") == "bf16x3"))
+    l = _lib.lib()
+    assert l.objnerf_render_workspace_bytes(C.byref(cfg), n) == l.objnerf_render_workspace_bytes(C.byref(cfg), 1 << 20)
