@@ -810,7 +810,7 @@ __device__ __forceinline__ float blob_weight_b3(const void* blob, bool vox, int 
               lo = __uint_as_float((uint32_t)p[1024] << 16);
   return (hi + mid) + lo;
 }
-// Step 1 (one workgroup): the hoisted weight columns as a compact matrix wm[group][c][16] + bias[group][16], group = 16
+// Step 1 (one workgroup per input column): the hoisted weight columns as a compact matrix wm[group][c][16] + bias[group][16], group = 16
 // consecutive floats of the per-ray vector (one (layer, out tile, lane half) of the MLP kernel's D layout), c = input
 // column (64 code columns or 27 direction columns) -- read from the packed stream by the packer's own layout arithmetic.
 constexpr int kRbGroups = kRayBiasFloats / 16;                  // 28: O1 8 | O3 8 | SD 8 | OD 4
@@ -818,33 +818,35 @@ constexpr int kRbMatFloats = kRbGroups * 64 * 16 + kRbGroups * 16;
 template <bool B3>
 __global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs a, float* __restrict__ wm) {
   const int o = threadIdx.x;                  // position in the per-ray vector
+  const int c = blockIdx.x;                   // input column (0..63 of the code, 0..26 of the direction embedding)
   const bool vox = a.use_voxel != 0;
   const int l = o < 128 ? L_O1 : (o < 256 ? L_O3 : (o < 384 ? L_SD : L_OD));
   const int off = o < 128 ? 0 : (o < 256 ? 128 : (o < 384 ? 256 : 384));
   const int q = o - off, m = q >> 5, half = (q >> 4) & 1, r = q & 15;
   const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;   // D layout
   const int g = o >> 4, j = o & 15;
-  float* wrow = wm + (long)g * 64 * 16 + j;
-  for (int c = 0; c < 64; ++c) wrow[c * 16] = 0.f;
+  float w = 0.f;
   if (o < 256) {
     const int ks0 = ks_emb(vox) + (vox ? kKsObjVox : 0);        // first code k-step of the object input list (layout.h)
-    for (int c = 0; c < 64; ++c)
-      wrow[c * 16] = B3 ? blob_weight_b3(a.blob, vox, l, ks0 + (c & 31), c >> 5, row) : blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
-  } else {
+    w = B3 ? blob_weight_b3(a.blob, vox, l, ks0 + (c & 31), c >> 5, row) : blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
+  } else if (c < kDirC) {
     const int nh = l == L_SD ? 128 : 64;
+    // slot (i, h) of the direction list that holds column c (layout.h::dir_slot_col)
     for (int i = 0; i < kKsDir; ++i)
-      for (int h = 0; h < 2; ++h) {
-        const int c = dir_slot_col(i, h);
-        if (c >= 0) wrow[c * 16] = B3 ? blob_weight_b3(a.blob, vox, l, nh + i, h, row) : blob_weight(a.blob, vox, l, nh + i, h, row);
-      }
+      for (int h = 0; h < 2; ++h)
+        if (dir_slot_col(i, h) == c) w = B3 ? blob_weight_b3(a.blob, vox, l, nh + i, h, row) : blob_weight(a.blob, vox, l, nh + i, h, row);
   }
-  wm[kRbGroups * 64 * 16 + o] = a.aux[aux_bias_off(l) + q];
+  wm[((long)g * 64 + c) * 16 + j] = w;
+  if (c == 0) wm[kRbGroups * 64 * 16 + o] = a.aux[aux_bias_off(l) + q];
 }
 // Step 2: lane = ray (its code and direction embedding in registers), the weights of 16 outputs at a time as wave-uniform
-// (scalar) operands; every lane stores the 16 outputs as one 64-byte piece of its ray's vector.
-__global__ void __launch_bounds__(256) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ wm) {
-  const long ray = (long)blockIdx.x * 256 + threadIdx.x;
+// (scalar) operands; every lane stores the 16 outputs as one 64-byte piece of its ray's vector.  One wave per workgroup and
+// the 28 groups in 7 parts (blockIdx.y): a 1,024-ray chunk of the editor still spreads over 112 workgroups.
+constexpr int kRbParts = 7;                                     // 28 groups of 16 outputs in 7 parts of 4 (blockIdx.y)
+__global__ void __launch_bounds__(64) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ wm) {
+  const long ray = (long)blockIdx.x * 64 + threadIdx.x;
   if (ray >= a.n_rays) return;
+  const int g0 = blockIdx.y * (kRbGroups / kRbParts);
   float x[64], pe[28];
   if (a.do_object) {
     const float* cp = a.codes + ray * a.code_stride;
@@ -871,7 +873,7 @@ __global__ void __launch_bounds__(256) ray_bias_kernel(const RayBiasArgs a, cons
   float* out = a.out + ray * kRayBiasFloats;
   const float* bias = wm + kRbGroups * 64 * 16;
 #pragma unroll 1
-  for (int g = 0; g < kRbGroups; ++g) {
+  for (int g = g0; g < g0 + kRbGroups / kRbParts; ++g) {
     const bool is_code = g < 16;
     const bool live = is_code ? a.do_object != 0 : (g < 24 ? a.do_scene != 0 : a.do_object != 0);
     if (!live) continue;                       // uniform
@@ -1169,9 +1171,9 @@ int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   if (m->n_rays == 0) return 0;
   RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out};
   float* wm = out + m->n_rays * kRayBiasFloats;          // the compact weight matrix lives behind the vectors
-  if (m->mfma_bf16x3) hipLaunchKernelGGL(ray_bias_weights_kernel<true>, dim3(1), dim3(448), 0, (hipStream_t)stream, a, wm);   // blob = the split-bf16 stream
-  else hipLaunchKernelGGL(ray_bias_weights_kernel<false>, dim3(1), dim3(448), 0, (hipStream_t)stream, a, wm);
-  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (const float*)wm);
+  if (m->mfma_bf16x3) hipLaunchKernelGGL(ray_bias_weights_kernel<true>, dim3(64), dim3(448), 0, (hipStream_t)stream, a, wm);   // blob = the split-bf16 stream
+  else hipLaunchKernelGGL(ray_bias_weights_kernel<false>, dim3(64), dim3(448), 0, (hipStream_t)stream, a, wm);
+  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 63) / 64), kRbParts), dim3(64), 0, (hipStream_t)stream, a, (const float*)wm);
   return check_launch("ray_bias");
 }
 
