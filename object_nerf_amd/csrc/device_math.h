@@ -11,6 +11,23 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef f32x4 f32x4u __attribute__((aligned(4)));
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Accesses through a pointer the compiler cannot prove global (one read out of a device-memory argument list, wgrad.h)
+// compile to flat_* instructions, which count on lgkmcnt as well as vmcnt: every later LDS wait then also waits for the
+// prefetch in flight.  These say "global memory" explicitly (global_load / global_store, vmcnt only).
+#define OBJ_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 gload4(const float* p) { return *(const OBJ_GLOBAL f32x4*)p; }
+__device__ __forceinline__ f32x4 gload4u(const float* p) { return *(const OBJ_GLOBAL f32x4u*)p; }
+__device__ __forceinline__ float gload(const float* p) { return *(const OBJ_GLOBAL float*)p; }
+__device__ __forceinline__ void gstore(float* p, float v) { *(OBJ_GLOBAL float*)p = v; }
+// "this value is the same in every lane": moves it to scalar registers, so that what is computed from it (loop counters,
+// base addresses) runs on the SALU and global addresses take the scalar-base form
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long uni(long x) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)x >> 32));
+  return (long)(((unsigned long)hi << 32) | lo);
+}
+template <class T> __device__ __forceinline__ T* uni(T* p) { return reinterpret_cast<T*>(uni(reinterpret_cast<long>(p))); }
+
 // sin / cos with 3-term Cody-Waite reduction by pi/2 and the classic degree-7/8 minimax
 // polynomials on [-pi/4, pi/4] (abs error ~1e-7 for |x| < 2^15, i.e. f32-roundoff class;
 // the reference calls torch.sin/torch.cos, embedding_helper.py:69-74).

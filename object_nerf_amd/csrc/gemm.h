@@ -131,23 +131,23 @@ struct GemmOperand {
     if (fast && k0 + GBK <= kend) {            // uniform branches
       if (aligned) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)p[i];
+        for (int i = 0; i < 4; ++i) v[i] = gload4(p[i]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *(const f32x4u*)p[i];
+        for (int i = 0; i < 4; ++i) v[i] = gload4u(p[i]);
       }
     } else if (K_CONTIG) {
       const long gk = k0 + 4 * (tid & 7);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[i][j] = (gk + j < kend) ? p[i][j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[i][j] = (gk + j < kend) ? gload(p[i] + j) : 0.f;
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool kin = k0 + (tid >> 5) + 8 * i < kend;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[i][j] = (kin && j < rows_left) ? p[i][j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[i][j] = (kin && j < rows_left) ? gload(p[i] + j) : 0.f;
       }
     }
 #pragma unroll

@@ -1,20 +1,22 @@
 // wgrad.hip -- grouped, stream-K, deterministic weight gradients of one backward pass (wgrad.h).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <type_traits>
 #include "wgrad.h"
 #include "host_api.h"
 
 namespace objnerf {
 
-template <bool TAIL>
-__device__ __forceinline__ void wgrad_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend,
-                                            float* slot, float* lds, int tid) {
-  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+// ---- ragged tiles (1..3 live 32-column sub-tiles): 4 x 1 waves, gemm.h's operand staging, single LDS buffer ----------------
+__device__ __forceinline__ void wgrad_tail_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend,
+                                                 float* slot, float* lds, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
   const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
-  const int ncol = TAIL ? tl.ncol : 4;
-  f32x16 acc[TAIL ? 3 : 4];
+  const int ncol = tl.ncol;
+  f32x16 acc[3];
 #pragma unroll
-  for (int i = 0; i < (TAIL ? 3 : 4); ++i)
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float rsum = 0.f;
@@ -41,71 +43,248 @@ __device__ __forceinline__ void wgrad_piece(const WgProduct& pr, const WgTile& t
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) rsum += As[((tid >> 7) * 16 + kk) * GLDR + (tid & 127)];
     }
-    if constexpr (TAIL) {
-      if (m0 + wave * 32 < pr.M) {       // wave-uniform: this wave's row sub-tile exists
+    if (m0 + wave * 32 < pr.M) {         // wave-uniform: this wave's row sub-tile exists
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const f32x4 a = GemmOperand<false>::frag(As, wave * 32 + rl, half, s4);
-          f32x4 b[3];
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 a = GemmOperand<false>::frag(As, wave * 32 + rl, half, s4);
+        f32x4 b[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < ncol) b[j] = GemmOperand<false>::frag(Bs, j * 32 + rl, half, s4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int j = 0; j < 3; ++j)
-            if (j < ncol) b[j] = GemmOperand<false>::frag(Bs, j * 32 + rl, half, s4);
+            if (j < ncol) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j][s], acc[j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                       // the row-sum exchange below reuses the LDS buffers
+  // row sums: the two 16-k halves of a row live in threads tid and tid + 128: combine through LDS (fixed order)
+  if (want_rowsum) {
+    if (tid >= 128) lds[tid - 128] = rsum;
+    __syncthreads();
+    if (tid < 128) gstore(slot + 128 * 128 + tid, rsum + lds[tid]);
+  }
+  // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); the partial tile goes to the unit's slot
+  // as a dense 128 x 128 block (rows / columns past the product's extent are never read back)
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+  for (int t = 0; t < 3; ++t) {
+    if (t >= ncol) continue;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-              if (j < ncol) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[j][s], acc[j], 0, 0, 0);
+    for (int r = 0; r < 16; ++r) gstore(slot + (wave * 32 + (r & 3) + 8 * (r >> 2) + rbase) * 128 + t * 32 + col, acc[t][r]);
+  }
+}
+
+// ---- full tiles: 2 x 2 waves of 2 x 2 MFMA tiles ------------------------------------------------------------------------------
+// The loop gemm.h runs per k tile (barrier, registers -> LDS, barrier, fetch, 64 MFMAs with ~50 VALU instructions of
+// pointer / LDS-address arithmetic) kept the matrix pipe 0.76 busy at three workgroups per CU; timing ablations
+// (profiles/r03_wgrad_ablations.md): operands from cache -4 %, no barriers -6 %, both -7 %: not memory, not the
+// barriers alone -- on gfx950 the fp32 MFMA shares the SIMD's ALUs with the VALU, so every address instruction is matrix
+// time.  This loop has none: global addresses are a scalar base (advanced on the SALU) + a constant per-lane offset, the LDS
+// tile keeps a wave's two 32-column sub-tiles 64 floats apart so that one ds_read2st64_b32 with immediate offsets fetches both
+// operands of a k step, and the tile is double-buffered: ONE barrier per k tile, the next tile's registers -> LDS copy and the
+// fetch after next issue at the head of the MFMA burst.  64 KB of LDS: two workgroups per CU.
+// Timing ablations (tools/, results are wrong when set): OBJ_ABL bits: 1 no global loads, 2 no registers -> LDS copy, 4 no
+// barrier, 8 no fragment reads, 16 no MFMAs, 32 every k tile re-reads the first one (operands from cache)
+#ifndef OBJ_ABL
+#define OBJ_ABL 0
+#endif
+constexpr int WTILE = GBK * GLDR;                // floats per staged operand tile (16 KB), [k][128] with permuted columns
+#ifndef OBJ_WG_WAVES
+#define OBJ_WG_WAVES 2
+#endif
+// position of column c of an operand tile inside its k row: 32-column group g = (wave coordinate w, sub-tile i) = (g >> 1, g & 1)
+// sits at 32 (2 i + w)
+__device__ __forceinline__ int wg_pos(int c) { const int g = c >> 5; return (((g & 1) << 1) + (g >> 1)) * 32 + (c & 31); }
+
+struct WgOperand {             // one operand of a full tile: 128 columns ("rows" of the staged tile) x 32 k per tile
+  const char* base;            // uniform: element (k0, row0) of the k tile to fetch next
+  long step;                   // uniform: bytes per k tile
+  unsigned off[4];             // this thread's four 16-byte pieces (k = tid / 32 + 8 i, columns 4 (tid % 32) .. + 3): bytes from base
+  int cols_left;               // columns of the operand from this thread's first one on (<= 0: none)
+  bool fast, aligned;          // uniform: all 128 columns exist; 16-byte aligned pieces
+  f32x4 v[4];
+  __device__ __forceinline__ void init(const float* src, long ld, long row0, long rows, long kbeg, int tid) {
+    base = (const char*)(src + kbeg * ld + row0);
+    step = GBK * ld * 4;
+    cols_left = (int)(rows - row0) - 4 * (tid & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) off[i] = 4u * (unsigned)(((tid >> 5) + 8 * i) * ld + 4 * (tid & 31));
+    fast = row0 + GBN <= rows;
+    aligned = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+  }
+  // the contraction range must be zero-filled in BOTH operands (0 x garbage could be NaN): only a ragged last tile needs it
+  // Piece i of the k tile that starts krem points before the end of the slice (32-bit counters: the SALU has no 64-bit ordered
+  // compare).  The contraction range must be zero-filled in BOTH operands (0 x garbage could be NaN): a ragged last tile only.
+  __device__ __forceinline__ void fetch_piece(int i, int krem, int tid) {
+    if (OBJ_ABL & 1) return;
+    if (fast && krem >= GBK) {                 // uniform
+      v[i] = aligned ? gload4((const float*)(base + off[i])) : gload4u((const float*)(base + off[i]));
+    } else {
+      const bool kin = (tid >> 5) + 8 * i < krem;
+      if (kin && cols_left >= 4) {
+        v[i] = gload4u((const float*)(base + off[i]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (kin && j < cols_left) ? gload((const float*)(base + off[i]) + j) : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void advance() { if (!(OBJ_ABL & 32)) base += step; }       // after the four pieces of a k tile
+  __device__ __forceinline__ void fetch(int krem, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_piece(i, krem, tid);
+    advance();
+  }
+  __device__ __forceinline__ void put_piece(int i, float* tile, int tid) const {
+    if (OBJ_ABL & 2) return;
+    *(f32x4*)&tile[((tid >> 5) + 8 * i) * GLDR + wg_pos(4 * (tid & 31))] = v[i];
+  }
+  __device__ __forceinline__ void put(float* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put_piece(i, tile, tid);
+  }
+};
+#define OBJ_WG_SYNC() do { if (!(OBJ_ABL & 4)) __syncthreads(); } while (0)
+
+__device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgTile& tl, long kbeg, long kend,
+                                                 float* slot, float* lds, int tid) {
+  // the lists are read with vector loads (the compiler cannot know they are constant): say that they are uniform
+  const WgProduct pr{uni(prv.A), uni(prv.lda), uni(prv.B), uni(prv.ldb), prv.C, prv.ldc, uni(prv.rowsum), uni(prv.M), uni(prv.N)};
+  kbeg = uni(kbeg); kend = uni(kend); slot = uni(slot);
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)uni((int)tl.by) * GBM, n0 = (long)uni((int)tl.bx) * GBN;
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float rsum = 0.f;
+  const bool want_rowsum = pr.rowsum != nullptr && tl.bx == 0;
+  WgOperand opa, opb;
+  opa.init(pr.A, pr.lda, m0, pr.M, kbeg, tid);
+  opb.init(pr.B, pr.ldb, n0, pr.N, kbeg, tid);
+  const int klen = (int)(kend - kbeg);   // a slice is at most 2^31 points long
+  opa.fetch(klen, tid);
+  opb.fetch(klen, tid);
+  opa.put(lds, tid);
+  opb.put(lds + WTILE, tid);
+  if (klen > GBK) {
+    opa.fetch(klen - GBK, tid);
+    opb.fetch(klen - GBK, tid);
+  }
+  const int half = lane >> 5, rl = lane & 31;
+  const int aoff = 16 * half * GLDR + wm * 32 + rl, boff = 16 * half * GLDR + wn * 32 + rl;
+  const int roff = (tid >> 7) * 16 * GLDR + wg_pos(tid & 127);
+  int buf = 0;
+  // One k tile.  STEADY: both operands are full-width panels and at least two more full k tiles follow -- the body has no
+  // branch, so the compiler's wait counts stay exact (a load waits for its own piece only: vmcnt(6), not vmcnt(0)).
+  auto k_tile = [&](auto steady, int krem) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady)::value;
+    OBJ_WG_SYNC();                       // this tile is complete in LDS; every wave is done reading the other buffer
+    const float* As = lds + buf * 2 * WTILE;
+    const float* Bs = As + WTILE;
+    float* An = lds + (buf ^ 1) * 2 * WTILE;
+    float* Bn = An + WTILE;
+    if (want_rowsum && !(OBJ_ABL & 8)) { // thread -> row tid % 128, 16 of the 32 k
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) rsum += As[roff + kk * GLDR];
+    }
+    // MFMA step (s4, s) of lane half h contracts k = 16 h + 4 s4 + s; the fragments of group s4 + 1 are read before the 16
+    // MFMAs of group s4 issue
+    float fa[2][2][4], fb[2][2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (OBJ_ABL & 8) { fa[0][0][s] = fa[0][1][s] = fb[0][0][s] = fb[0][1][s] = (float)(tid + s); continue; }
+      fa[0][0][s] = As[aoff + s * GLDR]; fa[0][1][s] = As[aoff + s * GLDR + 64];
+      fb[0][0][s] = Bs[boff + s * GLDR]; fb[0][1][s] = Bs[boff + s * GLDR + 64];
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      // a quarter of the staging per MFMA group: piece s4 of the next tile goes registers -> the other LDS buffer, then piece
+      // s4 of the tile after it global -> the same registers (one k tile = 64 MFMAs per wave to arrive).  Issued as one burst
+      // at the head of the k tile, the workgroups' 32 KiB each queue at the CU's 64 B/clk vector-memory path and the issuing
+      // waves stall behind it: +17 % kernel time even with every load hitting in cache (profiles/r03_wgrad_ablations.md)
+      if constexpr (STEADY) {
+        // the loads are opaque to the compiler (its wait-count pass would make the first copy of a k tile wait for ALL eight
+        // loads in flight, vmcnt(0), the youngest of them one MFMA group old); loads return in order, so with eight in flight
+        // "at most six outstanding" = the two issued for this piece one k tile ago have landed
+        if (!(OBJ_ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        opa.put_piece(s4, An, tid);
+        opb.put_piece(s4, Bn, tid);
+        if (!(OBJ_ABL & 1)) {
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opa.v[s4]) : "v"(opa.off[s4]), "s"(opa.base) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opb.v[s4]) : "v"(opb.off[s4]), "s"(opb.base) : "memory");
+        }
+      } else if (krem > GBK) {           // uniform
+        opa.put_piece(s4, An, tid);
+        opb.put_piece(s4, Bn, tid);
+        if (krem > 2 * GBK) {
+          opa.fetch_piece(s4, krem - 2 * GBK, tid);
+          opb.fetch_piece(s4, krem - 2 * GBK, tid);
         }
       }
-    } else {
+      if (s4 < 3 && !(OBJ_ABL & 8)) {
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {   // 4 MFMA steps per fragment read
-        f32x4 a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = GemmOperand<false>::frag(As, wm * 64 + i * 32 + rl, half, s4);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = GemmOperand<false>::frag(Bs, wn * 64 + j * 32 + rl, half, s4);
+        for (int s = 0; s < 4; ++s) {
+          const int kk = 4 * (s4 + 1) + s;
+          fa[(s4 + 1) & 1][0][s] = As[aoff + kk * GLDR]; fa[(s4 + 1) & 1][1][s] = As[aoff + kk * GLDR + 64];
+          fb[(s4 + 1) & 1][0][s] = Bs[boff + kk * GLDR]; fb[(s4 + 1) & 1][1][s] = Bs[boff + kk * GLDR + 64];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(OBJ_ABL & 16)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[2 * i + j], 0, 0, 0);
+              acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[(OBJ_ABL & 8) ? 0 : (s4 & 1)][i][s], fb[(OBJ_ABL & 8) ? 0 : (s4 & 1)][j][s], acc[2 * i + j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s][0] += fa[s4 & 1][0][s] + fa[s4 & 1][1][s] + fb[s4 & 1][0][s] + fb[s4 & 1][1][s];
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (STEADY || krem > 2 * GBK) { opa.advance(); opb.advance(); }
+    buf ^= 1;
+  };
+  int krem = klen;
+  if (opa.fast && opb.fast && krem >= 3 * GBK) {       // uniform
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the second tile is in registers (and the compiler knows it)
+    for (; krem >= 3 * GBK; krem -= GBK) k_tile(std::true_type{}, krem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  __syncthreads();                       // the next piece's first tile overwrites the LDS buffers
-  // row sums: the two 16-k halves of a row live in threads tid and tid + 128: combine through LDS (fixed order)
-  if (want_rowsum) {
+  for (; krem > 0; krem -= GBK) k_tile(std::false_type{}, krem);
+  __syncthreads();                       // the row-sum exchange below reuses the LDS buffers
+  if (want_rowsum) {                     // the two 16-k halves of a row live in threads tid and tid + 128 (fixed order)
     if (tid >= 128) lds[tid - 128] = rsum;
     __syncthreads();
-    if (tid < 128) slot[128 * 128 + tid] = rsum + lds[tid];
-    __syncthreads();
+    if (tid < 128) gstore(slot + 128 * 128 + tid, rsum + lds[tid]);
   }
   // D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); the partial tile goes to the unit's slot
   // as a dense 128 x 128 block (rows / columns past the product's extent are never read back)
   const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
-  for (int t = 0; t < (TAIL ? 3 : 4); ++t) {
+  for (int t = 0; t < 4; ++t) {
     const int i = t >> 1, j = t & 1;
-    if (TAIL && t >= ncol) continue;
-    const int nl = TAIL ? t * 32 + col : wn * 64 + j * 32 + col;           // column inside the tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (TAIL ? wave * 32 : wm * 64 + i * 32) + (r & 3) + 8 * (r >> 2) + rbase;
-      slot[ml * 128 + nl] = acc[t][r];
-    }
+    for (int r = 0; r < 16; ++r)
+      gstore(slot + (wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase) * 128 + wn * 64 + j * 32 + col, acc[t][r]);
   }
 }
 
 // The lists travel as kernel arguments (no device copy to enqueue, no allocation) and are parked in device memory by this
 // one-workgroup kernel: indexing a by-value argument struct with a run-time index would make every kernel that does it
 // keep a private copy of the 2.5 KB struct in scratch memory.
-__global__ void __launch_bounds__(256) wgrad_list_kernel(const WgradArgs a, WgradArgs* __restrict__ out) {
+__global__ void __launch_bounds__(256) wgrad_list_kernel(const WgradArgs a, WgradArgs* __restrict__ out, unsigned long long* probe) {
   const unsigned* src = (const unsigned*)&a;
   unsigned* dst = (unsigned*)out;
   for (unsigned i = threadIdx.x; i < sizeof(WgradArgs) / 4; i += 256) dst[i] = src[i];
+  if (threadIdx.x == 0) *(unsigned long long**)(dst + kWgradListFloats - 2) = probe;      // OBJNERF_WGRAD_PROBE's sums
 }
 
 // One workgroup per UNIT = (tile, k slice).  TAIL = false: the full tiles of the list ([0, nfull)), TAIL = true: the
@@ -115,19 +294,36 @@ __global__ void __launch_bounds__(256) wgrad_list_kernel(const WgradArgs a, Wgra
 // fetched from HBM once and re-read from L2 (a tile-major order -- every workgroup a different k range of one tile --
 // streamed the operands 4-6 times: measured HBM-bound).  Every unit leaves its partial tile in its own slot.
 template <bool TAIL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) wgrad_units_kernel(const WgradArgs* __restrict__ ap) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * GTILE];
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ? 3 : OBJ_WG_WAVES, TAIL ? 3 : OBJ_WG_WAVES))) wgrad_units_kernel(const WgradArgs* __restrict__ ap) {
+  __shared__ __attribute__((aligned(16))) float lds[TAIL ? 2 * GTILE : 4 * WTILE];
   const WgradArgs& a = *ap;
   const int tid = threadIdx.x;
-  const long KT = (a.P + GBK - 1) / GBK;
-  const int nz = a.nz;
+  const long P = uni(a.P);
+  const long KT = (P + GBK - 1) / GBK;
+  const int nz = uni(a.nz);
   const long L = (KT + nz - 1) / nz;                       // k iterations per slice
   const int t0 = TAIL ? a.nfull : 0, t1 = TAIL ? a.ntile : a.nfull;
   // unit -> (tile, slice): walk the runs of tiles that belong to one product.  Workgroups are dealt round-robin to the 8
   // XCDs; with a.xcd every XCD takes one contiguous eighth of the units, so the tiles of one slice (which read the same
   // operand panels) run on ONE XCD and share its L2
   long u = blockIdx.x;
-  if (a.xcd) {
+  // Issue priority (OBJNERF_WGRAD_PRIO, a.xcd >> 1): the three workgroups of a CU run the same loop with the same period; with
+  // equal priority they share the matrix pipe round-robin, reach their barriers together and leave the pipe idle through the
+  // staging phase (a convoy).  Distinct priorities order them: the first never waits for the pipe, the others fill its gaps.
+  // 1: priority = hardware wave slot (HW_ID.wave_id: the co-resident waves of a SIMD have distinct slots), 2: a hash of the unit
+  // developer probe (OBJNERF_WGRAD_PROBE=1): every full-tile workgroup adds its lifetime in shader-clock cycles and in
+  // 100 MHz ticks to two process-wide sums; their ratio (printed at exit) is the clock the kernel really ran at
+  const bool probe = !TAIL && (a.xcd & 16) && tid == 0;
+  unsigned long long c0 = 0, r0 = 0;
+  if (probe) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  const int prio_mode = (a.xcd >> 1) & 3;
+  if (prio_mode) {
+    const unsigned slot = (prio_mode == 1 ? __builtin_amdgcn_s_getreg(6148) : ((blockIdx.x * 2654435761u) >> 16)) % 3u;
+    if (slot == 0) __builtin_amdgcn_s_setprio(2);
+    else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+  if (a.xcd & 1) {
     const long per = (gridDim.x + 7) / 8;
     u = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (u >= gridDim.x) return;
@@ -141,12 +337,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     t += run;
   }
   if (t >= t1) return;
+  t = uni(t); z = uni(z);
   const WgTile tl = a.tile[t];
   const long kbeg = (long)z * L * GBK;
   long kend = kbeg + L * GBK;
-  if (kend > a.P) kend = a.P;
+  if (kend > P) kend = P;
   float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
-  wgrad_piece<TAIL>(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);      // an empty slice writes zeros
+  if constexpr (TAIL) wgrad_tail_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);      // an empty slice writes zeros
+  else wgrad_full_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);
+  if (probe) {
+    unsigned long long* sums = *(unsigned long long* const*)((const unsigned*)ap + kWgradListFloats - 2);
+    atomicAdd(sums, (unsigned long long)__builtin_readcyclecounter() - c0);
+    atomicAdd(sums + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - r0);
+  }
 }
 
 // Adds a tile's slices to dW in ascending slice order (= ascending points): every bit of the result is reproducible.
@@ -165,16 +368,19 @@ __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __res
   for (int z = 0; z < nz; ++z) {
     const float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += slot[(part * 8 + i) * 256 + tid];
-    if (want_rs) rs += slot[128 * 128 + tid];
+    for (int i = 0; i < 8; ++i) acc[i] += gload(slot + (part * 8 + i) * 256 + tid);
+    if (want_rs) rs += gload(slot + 128 * 128 + tid);
   }
   const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int e = (part * 8 + i) * 256 + tid, ml = e >> 7, nl = e & 127;
-    if (m0 + ml < pr.M && n0 + nl < pr.N && nl < 32 * (int)tl.ncol) pr.C[(m0 + ml) * pr.ldc + n0 + nl] += acc[i];
+    if (m0 + ml < pr.M && n0 + nl < pr.N && nl < 32 * (int)tl.ncol) {
+      float* c = pr.C + (m0 + ml) * pr.ldc + n0 + nl;
+      gstore(c, gload(c) + acc[i]);
+    }
   }
-  if (want_rs && m0 + tid < pr.M) pr.rowsum[m0 + tid] += rs;
+  if (want_rs && m0 + tid < pr.M) gstore(pr.rowsum + m0 + tid, gload(pr.rowsum + m0 + tid) + rs);
 }
 
 // ---- the 1- and 3-row heads on the VALU ---------------------------------------------------------------------------
@@ -225,7 +431,7 @@ __global__ void __launch_bounds__(256) heads_fixup_kernel(const HeadArgs a) {
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
-int wgrad_slices(long P) {
+static long wgrad_base_slices(long P) {
   static const long iters = [] {
     const char* e = getenv("OBJNERF_WGRAD_KITERS");
     const long v = e ? atol(e) : 0;
@@ -233,7 +439,34 @@ int wgrad_slices(long P) {
   }();
   const long KT = (P + GBK - 1) / GBK;
   const long nz = (KT + iters - 1) / iters;
-  return (int)(nz < 1 ? 1 : (nz > kWgradMaxSlices ? kWgradMaxSlices : nz));
+  return nz < 1 ? 1 : nz;
+}
+// upper bound (scratch sizing): the launch may cut up to a quarter more slices than the base count, see wgrad_pick_slices
+int wgrad_slices(long P) {
+  const long nz = wgrad_base_slices(P) * 5 / 4 + 1;
+  return (int)(nz > kWgradMaxSlices ? kWgradMaxSlices : nz);
+}
+// Slices per tile for a pass with `nfull` full tiles: the full-tile workgroups run two per CU, all resident slots busy until
+// the last round -- the base count (64 k tiles per slice) leaves e.g. 53 x 128 units = 13.25 rounds of 512 slots, the last
+// round three quarters empty.  Take the count in [base, 1.25 base] whose last round is fullest (a function of P, the model's
+// tile list and the device only: the sums stay reproducible run to run).
+static int wgrad_pick_slices(long P, int nfull) {
+  static const int slots = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2 * (cus > 0 ? cus : 256);
+  }();
+  static const bool fixed = getenv("OBJNERF_WGRAD_KITERS") != nullptr;       // tuning runs keep the count they ask for
+  const long base = wgrad_base_slices(P), cap = wgrad_slices(P);
+  if (fixed || nfull <= 0) return (int)(base > cap ? cap : base);
+  long best = base > cap ? cap : base;
+  double best_eff = 0.0;
+  for (long nz = best; nz <= cap; ++nz) {
+    const long units = nz * nfull, rounds = (units + slots - 1) / slots;
+    const double eff = (double)units / (double)(rounds * slots);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = nz; }
+  }
+  return (int)best;
 }
 
 void WgradBatch::add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db) {
@@ -260,6 +493,22 @@ void WgradBatch::add_head(const float* dY, int no, const float* X, long ldx, int
   if (h.nheads >= kMaxHeads || no > 3 || ni > 256) { overflow = true; return; }
   h.h[h.nheads++] = HeadItem{dY, X, dW, db, ldx, ldw, no, ni};
 }
+// OBJNERF_WGRAD_PROBE: two device counters for the life of the process, read and printed at exit
+static unsigned long long* g_probe = nullptr;
+static void probe_report() {
+  unsigned long long sums[2] = {0, 0};
+  if (g_probe && hipMemcpy(sums, g_probe, sizeof(sums), hipMemcpyDeviceToHost) == hipSuccess && sums[1])
+    fprintf(stderr, "wgrad probe: full-tile workgroups ran at %.3f GHz (shader cycles / 100 MHz ticks, %.3e ticks)\n",
+            (double)sums[0] / (double)sums[1] * 0.1, (double)sums[1]);
+}
+static unsigned long long* probe_sums() {
+  if (!g_probe && hipMalloc((void**)&g_probe, 16) == hipSuccess) {
+    (void)hipMemset(g_probe, 0, 16);
+    atexit(probe_report);
+  }
+  return g_probe;
+}
+
 int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
   if (overflow) return set_error(-3, "wgrad: work list overflow");
   if (P <= 0) return 0;
@@ -268,10 +517,13 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
   if (a.ntile > 0) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
-    const int nz = a.nz = wgrad_slices(P);
+    const int nz = a.nz = wgrad_pick_slices(P, a.nfull);
     static const int xcd = [] { const char* e = getenv("OBJNERF_WGRAD_XCD"); return e ? atoi(e) : 0; }();
-    a.xcd = xcd;
-    hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
+    static const int prio = [] { const char* e = getenv("OBJNERF_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
+    static const int probe = [] { const char* e = getenv("OBJNERF_WGRAD_PROBE"); return e ? atoi(e) : 0; }();
+    a.xcd = (xcd & 1) | ((prio & 3) << 1) | (probe ? 16 : 0);
+    hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev, probe ? probe_sums() : nullptr);
+    if (probe) { static int launches = 0; if (++launches % 64 == 0) probe_report(); }   // (synchronises once in 64 launches)
     if (a.nfull > 0) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3(a.nfull * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);

@@ -32,7 +32,7 @@ def main(n_rays=2048, steps=5):
     g = torch.Generator(device=dev).manual_seed(rank)
     target = torch.rand(n_rays, 3, device=dev, generator=g)
 
-    def step():
+    def step(timed=True):
         idx = torch.randint(0, rays_all.shape[0], (n_rays,), device=dev, generator=g)
         rays = rays_all[idx].contiguous()
         ids = synth.per_ray_ids(n_rays).to(dev)
@@ -42,6 +42,11 @@ def main(n_rays=2048, steps=5):
                           embedding_instance=codes, frustum_bound_th=0.025, pass_through_mask=(ids == 1).view(-1, 1))
         loss = sum(((r["rgb_%s" % t] - target) ** 2).mean() + ((r["rgb_instance_%s" % t] - target) ** 2).mean()
                    + 0.1 * (r["depth_%s" % t] ** 2).mean() + (r["opacity_instance_%s" % t] ** 2).mean() for t in ("coarse", "fine"))
+        if not timed:                       # a training loop as it runs: nothing waits for the device inside a step
+            loss.backward()
+            sync.sync()
+            opt.step()
+            return loss
         torch.cuda.synchronize(); t1 = time.perf_counter()
         loss.backward()
         sync.sync()
@@ -57,6 +62,19 @@ def main(n_rays=2048, steps=5):
         loss, t1, t2, t3 = step()
         rows.append((t1 - t0, t2 - t1, t3 - t2, loss))
     fw, bw, op = (sorted(r[i] for r in rows)[len(rows) // 2] for i in range(3))
+    # steady state: 8 steps in flight at most (the launch queue is bounded by a synchronisation every 8 steps), as a loop
+    # that reads its loss for logging every few steps does; the three per-phase figures above each end in a host
+    # synchronisation and an idle device, which costs the step ~2-3 ms of launch latency and clock ramp
+    n_free = 48
+    for _ in range(8):
+        step(False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n_free):
+        step(False)
+        if i % 8 == 7:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    free = (time.perf_counter() - t0) / n_free
     evals = n_rays * 192 * world
     flop = evals * 1776128 * 3.0          # forward + dgrad + wgrad
     if rank == 0:
@@ -64,6 +82,8 @@ def main(n_rays=2048, steps=5):
               "%.1f TFLOP/s (3x forward FLOP), loss %.4f -> %.4f"
               % (n_rays, world, fw * 1e3, bw * 1e3, op * 1e3, evals / (fw + bw + op) / 1e6, flop / (fw + bw) / 1e12,
                  rows[0][3], rows[-1][3]))
+        print("steady state (no host synchronisation inside a step, %d steps): %.2f ms per step incl. Adam -> %.2f M ray-samples/s, "
+              "%.1f TFLOP/s (3x forward FLOP over the whole step)" % (n_free, free * 1e3, evals / free / 1e6, flop / free / 1e12))
     if dist.is_initialized():
         dist.destroy_process_group()
 
