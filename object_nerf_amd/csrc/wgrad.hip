@@ -385,45 +385,65 @@ __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __res
 
 // ---- the 1- and 3-row heads on the VALU ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) heads_wgrad_kernel(const HeadArgs a) {
+  // the chunk's dY rows (<= 12 KB) are staged in LDS once: every thread needs every one of them (uniform reads = LDS
+  // broadcasts), and the bias sums walk them without a global-memory round trip per point (1024 dependent-latency loads by
+  // three threads were most of this kernel's 0.25 ms)
+  __shared__ float dys[kHeadChunk * 3];
   const HeadItem h = a.h[blockIdx.y];
   const int tid = threadIdx.x;
   const long p0 = (long)blockIdx.x * kHeadChunk, p1 = p0 + kHeadChunk < a.P ? p0 + kHeadChunk : a.P;
+  const int np = (int)(p1 - p0), no = h.no;
+  for (int i = tid; i < np * no; i += 256) dys[i] = gload(h.dY + p0 * no + i);
+  __syncthreads();
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, b = 0.f;
-  // thread = input column; 8 points per trip so that 8 row loads are in flight (the loop is latency-bound otherwise);
+  // thread = input column; 16 points per trip so that 16 row loads are in flight (the loop is latency-bound otherwise);
   // the sums stay sequential in p: fixed order
   if (tid < h.ni) {
-    const float* x = h.X + tid;
-    long p = p0;
-    for (; p + 8 <= p1; p += 8) {
-      float xv[8];
+    const float* x = h.X + p0 * h.ldx + tid;
+    int p = 0;
+    for (; p + 16 <= np; p += 16) {
+      float xv[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) xv[u] = x[(p + u) * h.ldx];
+      for (int u = 0; u < 16; ++u) xv[u] = gload(x + (long)(p + u) * h.ldx);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float* dy = h.dY + (p + u) * h.no;
+      for (int u = 0; u < 16; ++u) {
+        const float* dy = dys + (p + u) * no;
         s0 += dy[0] * xv[u];
-        if (h.no > 1) { s1 += dy[1] * xv[u]; s2 += dy[2] * xv[u]; }
+        if (no > 1) { s1 += dy[1] * xv[u]; s2 += dy[2] * xv[u]; }
       }
     }
-    for (; p < p1; ++p) {
-      const float xv = x[p * h.ldx];
-      s0 += h.dY[p * h.no] * xv;
-      if (h.no > 1) { s1 += h.dY[p * h.no + 1] * xv; s2 += h.dY[p * h.no + 2] * xv; }
+    for (; p < np; ++p) {
+      const float xv = gload(x + (long)p * h.ldx);
+      s0 += dys[p * no] * xv;
+      if (no > 1) { s1 += dys[p * no + 1] * xv; s2 += dys[p * no + 2] * xv; }
     }
   }
-  if (tid < h.no) for (long p = p0; p < p1; ++p) b += h.dY[p * h.no + tid];
+  if (tid < no) for (int p = 0; p < np; ++p) b += dys[p * no + tid];
   float* slot = a.partials + ((long)blockIdx.y * a.nchunks + blockIdx.x) * kHeadSlotFloats;
-  slot[tid] = s0; slot[256 + tid] = s1; slot[512 + tid] = s2;
-  if (tid < 3) slot[768 + tid] = b;
+  gstore(slot + tid, s0); gstore(slot + 256 + tid, s1); gstore(slot + 512 + tid, s2);
+  if (tid < 3) gstore(slot + 768 + tid, b);
 }
 __global__ void __launch_bounds__(256) heads_fixup_kernel(const HeadArgs a) {
   const HeadItem h = a.h[blockIdx.x];
   const int tid = threadIdx.x;
   float s[3] = {0.f, 0.f, 0.f}, b = 0.f;
-  for (int c = 0; c < a.nchunks; ++c) {
+  // ascending chunks = ascending points; eight chunks' partial sums are fetched before they are added (same order of additions)
+  int c = 0;
+  for (; c + 8 <= a.nchunks; c += 8) {
+    float v[8][3], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* slot = a.partials + ((long)blockIdx.x * a.nchunks + c + u) * kHeadSlotFloats;
+      v[u][0] = gload(slot + tid); v[u][1] = gload(slot + 256 + tid); v[u][2] = gload(slot + 512 + tid);
+      bv[u] = tid < 3 ? gload(slot + 768 + tid) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; b += bv[u]; }
+  }
+  for (; c < a.nchunks; ++c) {
     const float* slot = a.partials + ((long)blockIdx.x * a.nchunks + c) * kHeadSlotFloats;
-    s[0] += slot[tid]; s[1] += slot[256 + tid]; s[2] += slot[512 + tid];
-    if (tid < 3) b += slot[768 + tid];
+    s[0] += gload(slot + tid); s[1] += gload(slot + 256 + tid); s[2] += gload(slot + 512 + tid);
+    if (tid < 3) b += gload(slot + 768 + tid);
   }
   if (tid < h.ni)
     for (int o = 0; o < h.no; ++o) h.dW[o * h.ldw + tid] += s[o];
