@@ -56,19 +56,25 @@ open(os.path.join(P, "r03_kernel_stats_config4.md"), "w").write(
     "Per frame (3 steps traced): scene-branch MLP launches (background set) and object-branch launches (two object sets, culled rays skipped), both "
     "HOIST instantiations, `ray_bias` kernels per ray set and pass, joint compositing `composite_multi_kernel`.\n\n" + head(os.path.join(O, "trace_c4_kernel_stats.md"), 14))
 
-tk = os.path.join(O, "trace_train_kernel_stats.md")
-tb = open(os.path.join(O, "train_bench.txt")).read().strip().splitlines()[-1]
+# training artefacts: the closing session after the weight-gradient rewrite (tools/gpu_session_r03zz.sh) when it exists
+OT = os.path.join(os.path.dirname(O), "r03zz")
+OT = OT if os.path.exists(os.path.join(OT, "trace_train_kernel_stats.md")) else O
+tk = os.path.join(OT, "trace_train_kernel_stats.md")
+tlines = [l for l in open(os.path.join(OT, "train_bench.txt")).read().strip().splitlines() if l.startswith(("train step", "steady state"))]
+tb = "\n\n".join(tlines)
+open(os.path.join(P, "r03_train_bench.txt"), "w").write("\n".join(tlines) + "\n")
 wf, wt, fx, hw, hf = (row(tk, n) for n in ("wgrad_units_kernel<false>", "wgrad_units_kernel<true>", "wgrad_fixup_kernel", "heads_wgrad_kernel", "heads_fixup_kernel"))
-steps = 6.0
+steps = wf["calls"] / 2.0        # two passes (coarse, fine) per step
 open(os.path.join(P, "r03_train_kernel_stats.md"), "w").write(
-    "# Round 3 — training step (row f1): rocprofv3 --kernel-trace --stats of `python tools/train_bench.py` (1x MI355X; 6 steps = 1 warm-up + 5 timed; "
-    "2048 rays x (64 + 128), scene + object, voxel embedding, perturb / noise on, Adam)\n\n"
+    "# Round 3 — training step (row f1): rocprofv3 --kernel-trace --stats of `python tools/train_bench.py` (1x MI355X; %d steps: 6 with a host "
+    "synchronisation after every phase + 56 back to back; 2048 rays x (64 + 128), scene + object, voxel embedding, perturb / noise on, Adam)\n\n" % steps +
     "Wall clock of the same library, un-profiled (`profiles/r03_train_bench.txt`): " + tb + "\n\n"
-    "Round 3: all weight-gradient products of a backward pass in `wgrad_units_kernel<false|true>` (full / ragged tiles; work unit = tile x 2048-point slice, "
+    "Round 3: all weight-gradient products of a backward pass in `wgrad_units_kernel<false|true>` (full / ragged tiles; work unit = tile x ~1950-point slice, "
     "ordered product / slice / tile) + `wgrad_fixup_kernel` (ordered sum of the slices: bit-reproducible) + `heads_wgrad_kernel` / `heads_fixup_kernel` "
-    "(1- and 3-row heads on the VALU) instead of ~35 atomic split-K `gemm_kernel<false, false, *>` launches per pass (round 2: 8.2 + 1.2 ms per step; now "
-    "%.1f full tiles + %.1f ragged tiles + %.2f fix-up + %.2f heads = %.1f ms); the remaining `gemm_kernel<true, false, *>` launches are the gradients w.r.t. "
-    "the embeddings (1.9 ms per step as in round 2).\n\n"
+    "(1- and 3-row heads on the VALU) instead of ~35 atomic split-K `gemm_kernel<false, false, *>` launches per pass (round 2: 8.2 + 1.2 ms per step; "
+    "first grouped version of this round: 6.2 + 0.7 + 0.17 + 0.68 = 7.7 ms; after the full-tile loop rewrite and the heads rewrite, "
+    "`profiles/r03_wgrad_ablations.md`: %.1f full tiles + %.1f ragged tiles + %.2f fix-up + %.2f heads = %.1f ms); the remaining "
+    "`gemm_kernel<true, false, *>` launches are the gradients w.r.t. the embeddings (1.9 ms per step as in round 2).\n\n"
     % (wf["total"] / steps, wt["total"] / steps, fx["total"] / steps, (hw["total"] + hf["total"]) / steps,
        (wf["total"] + wt["total"] + fx["total"] + hw["total"] + hf["total"]) / steps) + head(tk, 26))
 

@@ -5,7 +5,6 @@ O=$R/gpurun_out/r03h; mkdir -p $O
 cd $R
 timeout 600 python -m pytest tests/test_gpu_train.py -x -q -m gpu > $O/test_train.txt 2>&1; echo "train tests rc=$?"; tail -3 $O/test_train.txt
 timeout 200 python tools/train_bench.py > $O/train_bench.txt 2>&1; echo "bench rc=$?"; tail -2 $O/train_bench.txt
-OBJNERF_WGRAD_XCD=1 timeout 200 python tools/train_bench.py > $O/train_bench_xcd.txt 2>&1; tail -2 $O/train_bench_xcd.txt
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_train -o tr -- python $R/tools/train_bench.py > $O/trace_train.log 2>&1; echo "trace rc=$?"
 cd $R
