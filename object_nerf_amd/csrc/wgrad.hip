@@ -1,7 +1,6 @@
 // wgrad.hip -- grouped, stream-K, deterministic weight gradients of one backward pass (wgrad.h).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
-#include <stdio.h>
 #include <type_traits>
 #include "wgrad.h"
 #include "host_api.h"
@@ -280,11 +279,10 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
 // The lists travel as kernel arguments (no device copy to enqueue, no allocation) and are parked in device memory by this
 // one-workgroup kernel: indexing a by-value argument struct with a run-time index would make every kernel that does it
 // keep a private copy of the 2.5 KB struct in scratch memory.
-__global__ void __launch_bounds__(256) wgrad_list_kernel(const WgradArgs a, WgradArgs* __restrict__ out, unsigned long long* probe) {
+__global__ void __launch_bounds__(256) wgrad_list_kernel(const WgradArgs a, WgradArgs* __restrict__ out) {
   const unsigned* src = (const unsigned*)&a;
   unsigned* dst = (unsigned*)out;
   for (unsigned i = threadIdx.x; i < sizeof(WgradArgs) / 4; i += 256) dst[i] = src[i];
-  if (threadIdx.x == 0) *(unsigned long long**)(dst + kWgradListFloats - 2) = probe;      // OBJNERF_WGRAD_PROBE's sums
 }
 
 // One workgroup per UNIT = (tile, k slice).  TAIL = false: the full tiles of the list ([0, nfull)), TAIL = true: the
@@ -311,11 +309,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
   // equal priority they share the matrix pipe round-robin, reach their barriers together and leave the pipe idle through the
   // staging phase (a convoy).  Distinct priorities order them: the first never waits for the pipe, the others fill its gaps.
   // 1: priority = hardware wave slot (HW_ID.wave_id: the co-resident waves of a SIMD have distinct slots), 2: a hash of the unit
-  // developer probe (OBJNERF_WGRAD_PROBE=1): every full-tile workgroup adds its lifetime in shader-clock cycles and in
-  // 100 MHz ticks to two process-wide sums; their ratio (printed at exit) is the clock the kernel really ran at
-  const bool probe = !TAIL && (a.xcd & 16) && tid == 0;
-  unsigned long long c0 = 0, r0 = 0;
-  if (probe) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
   const int prio_mode = (a.xcd >> 1) & 3;
   if (prio_mode) {
     const unsigned slot = (prio_mode == 1 ? __builtin_amdgcn_s_getreg(6148) : ((blockIdx.x * 2654435761u) >> 16)) % 3u;
@@ -345,11 +338,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
   float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
   if constexpr (TAIL) wgrad_tail_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);      // an empty slice writes zeros
   else wgrad_full_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);
-  if (probe) {
-    unsigned long long* sums = *(unsigned long long* const*)((const unsigned*)ap + kWgradListFloats - 2);
-    atomicAdd(sums, (unsigned long long)__builtin_readcyclecounter() - c0);
-    atomicAdd(sums + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - r0);
-  }
 }
 
 // Adds a tile's slices to dW in ascending slice order (= ascending points): every bit of the result is reproducible.
@@ -513,22 +501,6 @@ void WgradBatch::add_head(const float* dY, int no, const float* X, long ldx, int
   if (h.nheads >= kMaxHeads || no > 3 || ni > 256) { overflow = true; return; }
   h.h[h.nheads++] = HeadItem{dY, X, dW, db, ldx, ldw, no, ni};
 }
-// OBJNERF_WGRAD_PROBE: two device counters for the life of the process, read and printed at exit
-static unsigned long long* g_probe = nullptr;
-static void probe_report() {
-  unsigned long long sums[2] = {0, 0};
-  if (g_probe && hipMemcpy(sums, g_probe, sizeof(sums), hipMemcpyDeviceToHost) == hipSuccess && sums[1])
-    fprintf(stderr, "wgrad probe: full-tile workgroups ran at %.3f GHz (shader cycles / 100 MHz ticks, %.3e ticks)\n",
-            (double)sums[0] / (double)sums[1] * 0.1, (double)sums[1]);
-}
-static unsigned long long* probe_sums() {
-  if (!g_probe && hipMalloc((void**)&g_probe, 16) == hipSuccess) {
-    (void)hipMemset(g_probe, 0, 16);
-    atexit(probe_report);
-  }
-  return g_probe;
-}
-
 int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
   if (overflow) return set_error(-3, "wgrad: work list overflow");
   if (P <= 0) return 0;
@@ -540,10 +512,8 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
     const int nz = a.nz = wgrad_pick_slices(P, a.nfull);
     static const int xcd = [] { const char* e = getenv("OBJNERF_WGRAD_XCD"); return e ? atoi(e) : 0; }();
     static const int prio = [] { const char* e = getenv("OBJNERF_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
-    static const int probe = [] { const char* e = getenv("OBJNERF_WGRAD_PROBE"); return e ? atoi(e) : 0; }();
-    a.xcd = (xcd & 1) | ((prio & 3) << 1) | (probe ? 16 : 0);
-    hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev, probe ? probe_sums() : nullptr);
-    if (probe) { static int launches = 0; if (++launches % 64 == 0) probe_report(); }   // (synchronises once in 64 launches)
+    a.xcd = (xcd & 1) | ((prio & 3) << 1);
+    hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
     if (a.nfull > 0) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3(a.nfull * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);
