@@ -65,8 +65,8 @@ def main(n_rays=2048, steps=5):
     # steady state: 8 steps in flight at most (the launch queue is bounded by a synchronisation every 8 steps), as a loop
     # that reads its loss for logging every few steps does; the three per-phase figures above each end in a host
     # synchronisation and an idle device, which costs the step ~2-3 ms of launch latency and clock ramp
-    n_free = 48
-    for _ in range(8):
+    n_free = int(os.environ.get("TRAIN_BENCH_FREE_STEPS", "48"))      # 0: skip (counter-collection runs serialise every kernel)
+    for _ in range(8 if n_free else 0):
         step(False)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n_free):
@@ -74,7 +74,7 @@ def main(n_rays=2048, steps=5):
         if i % 8 == 7:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
-    free = (time.perf_counter() - t0) / n_free
+    free = (time.perf_counter() - t0) / max(n_free, 1)
     evals = n_rays * 192 * world
     flop = evals * 1776128 * 3.0          # forward + dgrad + wgrad
     if rank == 0:
@@ -82,7 +82,8 @@ def main(n_rays=2048, steps=5):
               "%.1f TFLOP/s (3x forward FLOP), loss %.4f -> %.4f"
               % (n_rays, world, fw * 1e3, bw * 1e3, op * 1e3, evals / (fw + bw + op) / 1e6, flop / (fw + bw) / 1e12,
                  rows[0][3], rows[-1][3]))
-        print("steady state (no host synchronisation inside a step, %d steps): %.2f ms per step incl. Adam -> %.2f M ray-samples/s, "
+        if n_free:
+            print("steady state (no host synchronisation inside a step, %d steps): %.2f ms per step incl. Adam -> %.2f M ray-samples/s, "
               "%.1f TFLOP/s (3x forward FLOP over the whole step)" % (n_free, free * 1e3, evals / free / 1e6, flop / free / 1e12))
     if dist.is_initialized():
         dist.destroy_process_group()
