@@ -62,7 +62,8 @@ OT = OT if os.path.exists(os.path.join(OT, "trace_train_kernel_stats.md")) else 
 tk = os.path.join(OT, "trace_train_kernel_stats.md")
 tlines = [l for l in open(os.path.join(OT, "train_bench.txt")).read().strip().splitlines() if l.startswith(("train step", "steady state"))]
 tb = "\n\n".join(tlines)
-open(os.path.join(P, "r03_train_bench.txt"), "w").write("\n".join(tlines) + "\n")
+extra = [l for l in open(os.path.join(P, "r03_train_bench.txt")).read().splitlines() if l.startswith("OBJNERF_MFMA=bf16x3")] if os.path.exists(os.path.join(P, "r03_train_bench.txt")) else []
+open(os.path.join(P, "r03_train_bench.txt"), "w").write("\n".join(tlines + extra) + "\n")   # (the split-bf16 line is added by hand from its own session)
 wf, wt, fx, hw, hf = (row(tk, n) for n in ("wgrad_units_kernel<false>", "wgrad_units_kernel<true>", "wgrad_fixup_kernel", "heads_wgrad_kernel", "heads_fixup_kernel"))
 steps = wf["calls"] / 2.0        # two passes (coarse, fine) per step
 open(os.path.join(P, "r03_train_kernel_stats.md"), "w").write(
