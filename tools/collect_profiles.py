@@ -31,7 +31,7 @@ def row(path, name):
 for src, dst in [("bench.json", "r03_bench.json"), ("bench_c0.json", "r03_bench_c0.json"), ("bench_c2.json", "r03_bench_c2.json"),
                  ("bench_c4.json", "r03_bench_c4.json"), ("bench_c3_dist.json", "r03_bench_c3_dist.json"), ("r03_pmc.json", "r03_pmc.json"),
                  ("r03_parity.md", "r03_parity.md"), ("r03_frame_parity.md", "r03_frame_parity.md"), ("big_frame.md", "r03_big_frame.md"),
-                 ("small_batch.md", "r03_small_batch.md"), ("train_bench.txt", "r03_train_bench.txt"), ("r03_band_replay.md", "r03_band_replay.md")]:
+                 ("small_batch.md", "r03_small_batch.md"), ("r03_band_replay.md", "r03_band_replay.md")]:
     shutil.copy(os.path.join(O, src), os.path.join(P, dst))
 
 b = line(os.path.join(O, "bench.json"))
