@@ -39,6 +39,8 @@ struct WgradArgs {             // passed by value (2.5 KB of kernel arguments: n
   WgProduct prod[kWgradMaxProducts];
   WgTile tile[kWgradMaxTiles];
   int nprod, ntile, nfull;     // tile[0 .. nfull) are full tiles, tile[nfull .. ntile) ragged ones
+  int nbig;                    // tile[0 .. nbig) (a multiple of 4): the quadrants (0,0) (0,1) (1,0) (1,1) of 256 x 256 tiles, one
+                               // workgroup each (wgrad_big_kernel); wgrad_units_kernel<false> takes tile[nbig .. nfull)
   int nz;                      // k slices per tile
   int xcd;                     // XCD-aware unit map (tuning switch OBJNERF_WGRAD_XCD)
   long P;
@@ -75,7 +77,7 @@ struct WgradBatch {
   WgradArgs a;
   HeadArgs h;
   bool overflow = false;
-  WgradBatch() { a.nprod = a.ntile = a.nfull = 0; h.nheads = 0; }
+  WgradBatch() { a.nprod = a.ntile = a.nfull = a.nbig = 0; h.nheads = 0; }
   void add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db);
   void add_head(const float* dY, int no, const float* X, long ldx, int ni, float* dW, long ldw, float* db);
   int launch(long P, float* scratch, hipStream_t s);

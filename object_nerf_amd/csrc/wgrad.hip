@@ -276,6 +276,165 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
   }
 }
 
+// ---- 256 x 256 tiles: one workgroup per CU, 2 x 2 waves of 4 x 4 MFMA tiles ------------------------------------------------
+// The full-tile kernel above is held by the part's power management, not by its instruction stream (profiles/r03_train_pmc.md:
+// busy x clock did not move when its issue overhead halved): ~3.5 TB/s of operand panels stream in next to the MFMAs.  A
+// 256 x 256 output tile moves HALF the bytes per MFMA -- from memory (each panel of a 256 x 256 product is fetched once instead
+// of twice), into LDS, and out of it (8 fragment reads per 16 MFMAs instead of 8 per 8... the wave tile is 128 x 128: 4 + 4
+// operand registers per 16 MFMAs) -- at the price of the inference kernel's structure: 256 accumulator registers per lane, one
+// wave per SIMD, 128 KB of LDS.  Same staging scheme as wgrad_full_piece: scalar base + constant lane offsets, a [k][256] tile
+// with a wave's four 32-column sub-tiles 64 floats apart (ds_read2st64_b32 with immediate offsets), double-buffered LDS with one
+// barrier per k tile, one of the sixteen 16-byte pieces per MFMA step (registers -> other buffer, then global -> the same
+// registers, waited for with vmcnt(15) one k tile later).  The partial tile goes to the slots of its four 128 x 128 quadrants
+// (each wave owns one), so wgrad_fixup_kernel does not know the difference.
+constexpr int BTILE = GBK * 256;                 // floats per staged operand tile (32 KB)
+__device__ __forceinline__ int big_pos(int c) { const int g = c >> 5; return (((g & 3) << 1) + (g >> 2)) * 32 + (c & 31); }
+
+struct BigOperand {            // one operand of a 256 x 256 tile: 256 columns x 32 k per tile, all columns exist
+  const char* base;            // uniform: element (k0, row0) of the k tile to fetch next
+  long step;                   // uniform: bytes per k tile
+  unsigned off[8];             // piece i: k = tid / 64 + 4 i, columns 4 (tid % 64) .. + 3: bytes from base
+  f32x4 v[8];
+  __device__ __forceinline__ void init(const float* src, long ld, long row0, long kbeg, int tid) {
+    base = (const char*)(src + kbeg * ld + row0);
+    step = GBK * ld * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) off[i] = 4u * (unsigned)(((tid >> 6) + 4 * i) * ld + 4 * (tid & 63));
+  }
+  // compiler-tracked form (prologue and the last tiles of a slice); rows of the k tile past the slice end are zero-filled
+  __device__ __forceinline__ void fetch_piece(int i, int krem, int tid) {
+    const bool kin = (tid >> 6) + 4 * i < krem;            // wave-uniform
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    v[i] = kin ? gload4u((const float*)(base + off[i])) : z;
+  }
+  __device__ __forceinline__ void fetch(int krem, int tid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fetch_piece(i, krem, tid);
+    base += step;
+  }
+  __device__ __forceinline__ void put_piece(int i, float* tile, int tid) const {
+    *(f32x4*)&tile[((tid >> 6) + 4 * i) * 256 + big_pos(4 * (tid & 63))] = v[i];
+  }
+  __device__ __forceinline__ void put(float* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) put_piece(i, tile, tid);
+  }
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) wgrad_big_kernel(const WgradArgs* __restrict__ ap) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * BTILE];
+  const WgradArgs& a = *ap;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const long P = uni(a.P);
+  const long KT = (P + GBK - 1) / GBK;
+  const int nz = uni(a.nz);
+  const long L = (KT + nz - 1) / nz;                       // k iterations per slice
+  const int b = uni((int)(blockIdx.x / (unsigned)nz)), z = uni((int)(blockIdx.x % (unsigned)nz));   // product by product, slice by slice
+  const int t0 = 4 * b;                                    // first quadrant's tile
+  const WgProduct& prv = a.prod[a.tile[t0].prod];
+  const float* A = uni(prv.A); const float* B = uni(prv.B);
+  const long lda = uni(prv.lda), ldb = uni(prv.ldb);
+  const bool want_rowsum = uni(prv.rowsum) != nullptr;
+  const long kbeg = (long)z * L * GBK;
+  long kend = kbeg + L * GBK;
+  if (kend > P) kend = P;
+  const int klen = (int)(kend - kbeg);
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float rsum = 0.f;
+  BigOperand opa, opb;
+  opa.init(A, lda, 0, kbeg, tid);
+  opb.init(B, ldb, 0, kbeg, tid);
+  opa.fetch(klen, tid);
+  opb.fetch(klen, tid);
+  opa.put(lds, tid);
+  opb.put(lds + BTILE, tid);
+  if (klen > GBK) {
+    opa.fetch(klen - GBK, tid);
+    opb.fetch(klen - GBK, tid);
+  }
+  const int half = lane >> 5, rl = lane & 31;
+  const int aoff = 16 * half * 256 + wm * 32 + rl, boff = 16 * half * 256 + wn * 32 + rl;
+  const int roff = big_pos(tid);                           // row sums: thread = row, all 32 k of a tile in ascending order
+  int buf = 0;
+  auto k_tile = [&](auto steady, int krem) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady)::value;
+    __syncthreads();                     // this tile is complete in LDS; every wave is done reading the other buffer
+    const float* As = lds + buf * 2 * BTILE;
+    const float* Bs = As + BTILE;
+    float* An = lds + (buf ^ 1) * 2 * BTILE;
+    float* Bn = An + BTILE;
+    if (want_rowsum) {
+#pragma unroll
+      for (int kk = 0; kk < GBK; ++kk) rsum += As[roff + kk * 256];
+    }
+    float fa[2][4], fb[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fa[0][i] = As[aoff + i * 64]; fb[0][i] = Bs[boff + i * 64]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {       // MFMA step q = 4 s4 + s of lane half h contracts k = 16 h + q
+      // staging piece q (A pieces 0..7 on the even steps, B pieces on the odd ones)
+      if constexpr (STEADY) {
+        asm volatile("s_waitcnt vmcnt(15)" ::: "memory");      // sixteen loads in flight, in-order return: this piece's has landed
+        if ((q & 1) == 0) {
+          opa.put_piece(q >> 1, An, tid);
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opa.v[q >> 1]) : "v"(opa.off[q >> 1]), "s"(opa.base) : "memory");
+        } else {
+          opb.put_piece(q >> 1, Bn, tid);
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opb.v[q >> 1]) : "v"(opb.off[q >> 1]), "s"(opb.base) : "memory");
+        }
+      } else if (krem > GBK) {           // uniform
+        if ((q & 1) == 0) {
+          opa.put_piece(q >> 1, An, tid);
+          if (krem > 2 * GBK) opa.fetch_piece(q >> 1, krem - 2 * GBK, tid);
+        } else {
+          opb.put_piece(q >> 1, Bn, tid);
+          if (krem > 2 * GBK) opb.fetch_piece(q >> 1, krem - 2 * GBK, tid);
+        }
+      }
+      if (q < 15) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[(q + 1) & 1][i] = As[aoff + (q + 1) * 256 + i * 64];
+          fb[(q + 1) & 1][i] = Bs[boff + (q + 1) * 256 + i * 64];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[4 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i], fb[q & 1][j], acc[4 * i + j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (STEADY || krem > 2 * GBK) { opa.base += opa.step; opb.base += opb.step; }
+    buf ^= 1;
+  };
+  int krem = klen;
+  if (krem >= 3 * GBK) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the second tile is in registers (and the compiler knows it)
+    for (; krem >= 3 * GBK; krem -= GBK) k_tile(std::true_type{}, krem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  for (; krem > 0; krem -= GBK) k_tile(std::false_type{}, krem);
+
+  // every wave owns one quadrant = one 128 x 128 tile of the list; its partial tile goes to that tile's slot of this slice
+  float* slot = uni(a.partials) + ((long)(t0 + wm * 2 + wn) * nz + z) * kWgradSlotFloats;
+  if (want_rowsum)                       // thread = row: rows 0..127 belong to quadrant (0,0)'s tile, rows 128..255 to (1,0)'s
+    gstore(uni(a.partials) + ((long)(t0 + 2 * (tid >> 7)) * nz + z) * kWgradSlotFloats + 128 * 128 + (tid & 127), rsum);
+  const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = t >> 2, j = t & 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gstore(slot + (i * 32 + (r & 3) + 8 * (r >> 2) + rbase) * 128 + j * 32 + col, acc[t][r]);
+  }
+}
+
 // The lists travel as kernel arguments (no device copy to enqueue, no allocation) and are parked in device memory by this
 // one-workgroup kernel: indexing a by-value argument struct with a run-time index would make every kernel that does it
 // keep a private copy of the 2.5 KB struct in scratch memory.
@@ -300,7 +459,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
   const long KT = (P + GBK - 1) / GBK;
   const int nz = uni(a.nz);
   const long L = (KT + nz - 1) / nz;                       // k iterations per slice
-  const int t0 = TAIL ? a.nfull : 0, t1 = TAIL ? a.ntile : a.nfull;
+  const int t0 = TAIL ? a.nfull : a.nbig, t1 = TAIL ? a.ntile : a.nfull;
   // unit -> (tile, slice): walk the runs of tiles that belong to one product.  Workgroups are dealt round-robin to the 8
   // XCDs; with a.xcd every XCD takes one contiguous eighth of the units, so the tiles of one slice (which read the same
   // operand panels) run on ONE XCD and share its L2
@@ -454,31 +613,36 @@ int wgrad_slices(long P) {
   const long nz = wgrad_base_slices(P) * 5 / 4 + 1;
   return (int)(nz > kWgradMaxSlices ? kWgradMaxSlices : nz);
 }
-// Slices per tile for a pass with `nfull` full tiles: the full-tile workgroups run two per CU, all resident slots busy until
-// the last round -- the base count (64 k tiles per slice) leaves e.g. 53 x 128 units = 13.25 rounds of 512 slots, the last
-// round three quarters empty.  Take the count in [base, 1.25 base] whose last round is fullest (a function of P, the model's
-// tile list and the device only: the sums stay reproducible run to run).
-static int wgrad_pick_slices(long P, int nfull) {
-  static const int slots = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return 2 * (cus > 0 ? cus : 256);
+// Slices per tile for a pass with `nbig` 256 x 256 tiles and `nfull` ordinary full tiles: the big-tile workgroups run one per CU
+// (a unit = four tiles' work on a whole CU), the ordinary ones two per CU (a unit = one tile on half a CU: half the time), both
+// with every resident slot busy until their last round -- the base count (64 k tiles per slice) leaves e.g. 53 x 128 units =
+// 13.25 rounds of 512 slots, the last round three quarters empty.  Take the count in [base, 1.25 base] that costs the fewest
+// rounds per unit of work (a function of P, the model's tile list and the device only: the sums stay reproducible run to run).
+static int wgrad_pick_slices(long P, int nbig, int nfull) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
   }();
   static const bool fixed = getenv("OBJNERF_WGRAD_KITERS") != nullptr;       // tuning runs keep the count they ask for
   const long base = wgrad_base_slices(P), cap = wgrad_slices(P);
-  if (fixed || nfull <= 0) return (int)(base > cap ? cap : base);
+  if (fixed || nbig + nfull <= 0) return (int)(base > cap ? cap : base);
   long best = base > cap ? cap : base;
-  double best_eff = 0.0;
+  double best_cost = 1e300;
   for (long nz = best; nz <= cap; ++nz) {
-    const long units = nz * nfull, rounds = (units + slots - 1) / slots;
-    const double eff = (double)units / (double)(rounds * slots);
-    if (eff > best_eff + 1e-9) { best_eff = eff; best = nz; }
+    const long rb = (nz * nbig + cus - 1) / cus, rf = (nz * nfull + 2 * cus - 1) / (2 * cus);
+    const double cost = (2.0 * (double)rb + (double)rf) / (double)nz;
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = nz; }
   }
   return (int)best;
 }
 
 void WgradBatch::add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db) {
   if (a.nprod >= kWgradMaxProducts) { overflow = true; return; }
+  // 256 x 256 tiles (wgrad_big_kernel) for the products with exactly two row tiles and at least two full column tiles:
+  // OBJNERF_WGRAD_BIG=0 keeps every full tile in the 128 x 128 kernel (developer A/B switch)
+  static const bool big_on = [] { const char* e = getenv("OBJNERF_WGRAD_BIG"); return !e || atoi(e) != 0; }();
+  const bool big = big_on && out == 2 * GBM && in >= 2 * GBN;
   const int pi = a.nprod++;
   a.prod[pi] = WgProduct{dY, lddy, X, ldx, dW, ldw, db, out, in};
   const int ny = (out + GBM - 1) / GBM, nx = (in + GBN - 1) / GBN;
@@ -488,13 +652,14 @@ void WgradBatch::add(const float* dY, long lddy, const float* X, long ldx, int o
       const int cols = in - bx * GBN < GBN ? in - bx * GBN : GBN;
       const int sub = (cols + 31) / 32;                          // live 32-column sub-tiles
       const WgTile tl{(unsigned char)pi, (unsigned char)by, (unsigned char)bx, (unsigned char)(sub >= 4 ? 4 : sub)};
-      if (tl.ncol == 4) {                                        // full tiles first, ragged ones behind them
-        for (int i = a.ntile; i > a.nfull; --i) a.tile[i] = a.tile[i - 1];
-        a.tile[a.nfull++] = tl;
-        ++a.ntile;
-      } else {
-        a.tile[a.ntile++] = tl;
-      }
+      // list order: quadrants of the 256 x 256 tiles | other full tiles | ragged tiles; insertion keeps each part in call order,
+      // so the quadrants of one product sit together as (0,0) (0,1) (1,0) (1,1)
+      int at = a.ntile;
+      if (tl.ncol == 4) at = (big && bx < 2) ? a.nbig : a.nfull;
+      for (int i = a.ntile; i > at; --i) a.tile[i] = a.tile[i - 1];
+      a.tile[at] = tl;
+      ++a.ntile;
+      if (tl.ncol == 4) { ++a.nfull; if (big && bx < 2) ++a.nbig; }
     }
 }
 void WgradBatch::add_head(const float* dY, int no, const float* X, long ldx, int ni, float* dW, long ldw, float* db) {
@@ -509,12 +674,13 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
   if (a.ntile > 0) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
-    const int nz = a.nz = wgrad_pick_slices(P, a.nfull);
+    const int nz = a.nz = wgrad_pick_slices(P, a.nbig / 4, a.nfull - a.nbig);
     static const int xcd = [] { const char* e = getenv("OBJNERF_WGRAD_XCD"); return e ? atoi(e) : 0; }();
     static const int prio = [] { const char* e = getenv("OBJNERF_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
     a.xcd = (xcd & 1) | ((prio & 3) << 1);
     hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
-    if (a.nfull > 0) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3(a.nfull * nz), dim3(256), 0, s, (const WgradArgs*)dev);
+    if (a.nbig > 0) hipLaunchKernelGGL(wgrad_big_kernel, dim3((a.nbig / 4) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
+    if (a.nfull > a.nbig) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3((a.nfull - a.nbig) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);
   }

@@ -57,14 +57,17 @@ open(os.path.join(P, "r03_kernel_stats_config4.md"), "w").write(
     "HOIST instantiations, `ray_bias` kernels per ray set and pass, joint compositing `composite_multi_kernel`.\n\n" + head(os.path.join(O, "trace_c4_kernel_stats.md"), 14))
 
 # training artefacts: the closing session after the weight-gradient rewrite (tools/gpu_session_r03zz.sh) when it exists
-OT = os.path.join(os.path.dirname(O), "r03zz")
-OT = OT if os.path.exists(os.path.join(OT, "trace_train_kernel_stats.md")) else O
+OT = O
+for cand in ("r03zz", "r03zn"):          # the latest one that exists (r03zn: after the 256 x 256 tiles, tools/gpu_session_r03n.sh)
+    if os.path.exists(os.path.join(os.path.dirname(O), cand, "trace_train_kernel_stats.md")):
+        OT = os.path.join(os.path.dirname(O), cand)
 tk = os.path.join(OT, "trace_train_kernel_stats.md")
 tlines = [l for l in open(os.path.join(OT, "train_bench.txt")).read().strip().splitlines() if l.startswith(("train step", "steady state"))]
 tb = "\n\n".join(tlines)
 extra = [l for l in open(os.path.join(P, "r03_train_bench.txt")).read().splitlines() if l.startswith("OBJNERF_MFMA=bf16x3")] if os.path.exists(os.path.join(P, "r03_train_bench.txt")) else []
 open(os.path.join(P, "r03_train_bench.txt"), "w").write("\n".join(tlines + extra) + "\n")   # (the split-bf16 line is added by hand from its own session)
 wf, wt, fx, hw, hf = (row(tk, n) for n in ("wgrad_units_kernel<false>", "wgrad_units_kernel<true>", "wgrad_fixup_kernel", "heads_wgrad_kernel", "heads_fixup_kernel"))
+wb = row(tk, "wgrad_big_kernel") or dict(calls=0, total=0.0, avg=0.0)
 steps = wf["calls"] / 2.0        # two passes (coarse, fine) per step
 open(os.path.join(P, "r03_train_kernel_stats.md"), "w").write(
     "# Round 3 — training step (row f1): rocprofv3 --kernel-trace --stats of `python tools/train_bench.py` (1x MI355X; %d steps: 6 with a host "
@@ -74,10 +77,11 @@ open(os.path.join(P, "r03_train_kernel_stats.md"), "w").write(
     "ordered product / slice / tile) + `wgrad_fixup_kernel` (ordered sum of the slices: bit-reproducible) + `heads_wgrad_kernel` / `heads_fixup_kernel` "
     "(1- and 3-row heads on the VALU) instead of ~35 atomic split-K `gemm_kernel<false, false, *>` launches per pass (round 2: 8.2 + 1.2 ms per step; "
     "first grouped version of this round: 6.2 + 0.7 + 0.17 + 0.68 = 7.7 ms; after the full-tile loop rewrite and the heads rewrite, "
-    "`profiles/r03_wgrad_ablations.md`: %.1f full tiles + %.1f ragged tiles + %.2f fix-up + %.2f heads = %.1f ms); the remaining "
+    "`profiles/r03_wgrad_ablations.md`: 5.9 + 0.7 + 0.18 + 0.29 = 7.1 ms; with the 256 x 256 tiles of `wgrad_big_kernel`: %.1f big tiles + %.1f other full tiles "
+    "+ %.1f ragged tiles + %.2f fix-up + %.2f heads = %.1f ms); the remaining "
     "`gemm_kernel<true, false, *>` launches are the gradients w.r.t. the embeddings (1.9 ms per step as in round 2).\n\n"
-    % (wf["total"] / steps, wt["total"] / steps, fx["total"] / steps, (hw["total"] + hf["total"]) / steps,
-       (wf["total"] + wt["total"] + fx["total"] + hw["total"] + hf["total"]) / steps) + head(tk, 26))
+    % (wb["total"] / steps, wf["total"] / steps, wt["total"] / steps, fx["total"] / steps, (hw["total"] + hf["total"]) / steps,
+       (wb["total"] + wf["total"] + wt["total"] + fx["total"] + hw["total"] + hf["total"]) / steps) + head(tk, 26))
 
 pm = json.load(open(os.path.join(O, "r03_pmc.json")))
 d = pm["derived"]
