@@ -280,13 +280,14 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
 // The full-tile kernel above is held by the part's power management, not by its instruction stream (profiles/r03_train_pmc.md:
 // busy x clock did not move when its issue overhead halved): ~3.5 TB/s of operand panels stream in next to the MFMAs.  A
 // 256 x 256 output tile moves HALF the bytes per MFMA -- from memory (each panel of a 256 x 256 product is fetched once instead
-// of twice), into LDS, and out of it (8 fragment reads per 16 MFMAs instead of 8 per 8... the wave tile is 128 x 128: 4 + 4
-// operand registers per 16 MFMAs) -- at the price of the inference kernel's structure: 256 accumulator registers per lane, one
-// wave per SIMD, 128 KB of LDS.  Same staging scheme as wgrad_full_piece: scalar base + constant lane offsets, a [k][256] tile
-// with a wave's four 32-column sub-tiles 64 floats apart (ds_read2st64_b32 with immediate offsets), double-buffered LDS with one
-// barrier per k tile, one of the sixteen 16-byte pieces per MFMA step (registers -> other buffer, then global -> the same
-// registers, waited for with vmcnt(15) one k tile later).  The partial tile goes to the slots of its four 128 x 128 quadrants
-// (each wave owns one), so wgrad_fixup_kernel does not know the difference.
+// of twice), into LDS, and out of it (the wave tile is 128 x 128: 4 + 4 operand registers feed 16 MFMAs, against 2 + 2 for 4) --
+// at the price of the inference kernel's structure: 256 accumulator registers per lane, one wave per SIMD, 128 KB of LDS.
+// Same staging scheme as wgrad_full_piece: scalar base + constant lane offsets, a [k][256] tile with a wave's four 32-column
+// sub-tiles 64 floats apart (ds_read2st64_b32 with immediate offsets), double-buffered LDS with one barrier per k tile, one of
+// the sixteen 16-byte pieces per MFMA step (registers -> other buffer, then global -> the same registers, waited for with
+// vmcnt(15) one k tile later).  The partial tile goes to the slots of its four 128 x 128 quadrants (each wave owns one), so
+// wgrad_fixup_kernel does not know the difference.  Measured: 0.050 ms per launch and 128 x 128 tile against 0.065 for the
+// kernel above, 0.90 of the MFMA-only ceiling at the clock the part holds (profiles/r03_wgrad_ablations.md, section 4).
 constexpr int BTILE = GBK * 256;                 // floats per staged operand tile (32 KB)
 __device__ __forceinline__ int big_pos(int c) { const int g = c >> 5; return (((g & 3) << 1) + (g >> 2)) * 32 + (c & 31); }
 
