@@ -56,6 +56,27 @@ open(os.path.join(P, "r03_kernel_stats_config4.md"), "w").write(
     "Per frame (3 steps traced): scene-branch MLP launches (background set) and object-branch launches (two object sets, culled rays skipped), both "
     "HOIST instantiations, `ray_bias` kernels per ray set and pass, joint compositing `composite_multi_kernel`.\n\n" + head(os.path.join(O, "trace_c4_kernel_stats.md"), 14))
 
+def budget(path, steps):
+    """per-step kernel time by group, from the kernel table"""
+    rows = []
+    for ln in open(path):
+        c = [x.strip() for x in ln.split("|")]
+        if len(c) > 5 and c[2].isdigit():
+            rows.append((c[1], float(c[3])))
+    tot = sum(v for _, v in rows)
+
+    def grp(*keys):
+        return sum(v for n, v in rows if any(k in n for k in keys)) / steps
+    g = [("fused forward with saved activations (`mlp_kernel<..., SAVE>`)", grp("mlp_kernel")), ("dgrad chain (`mlp_bwd_kernel`)", grp("mlp_bwd_kernel")),
+         ("weight gradients, 256 x 256 tiles (`wgrad_big_kernel`)", grp("wgrad_big")), ("weight gradients, 128 x 128 tiles (`wgrad_units_kernel<false>`)", grp("wgrad_units_kernel<false>")),
+         ("weight gradients, ragged tiles (`wgrad_units_kernel<true>`)", grp("wgrad_units_kernel<true>")), ("weight gradients, fix-up + heads", grp("fixup", "heads_wgrad")),
+         ("gradients w.r.t. the embeddings (`gemm_kernel<true, false, *>`)", grp("gemm_kernel")), ("voxel embedding forward + table scatter", grp("voxel_embed"))]
+    g.append(("everything else (compositing / sampling forward + backward, sigmoid, per-ray sums, Adam, fills, torch element-wise)", tot / steps - sum(v for _, v in g)))
+    out = "Kernel time per step by group (the table below, / %d steps):\n\n| group | ms per step |\n|---|---|\n" % steps
+    out += "".join("| %s | %.2f |\n" % x for x in g) + "| sum of kernel time | %.2f |\n\n" % (tot / steps)
+    return out
+
+
 # training artefacts: the closing session after the weight-gradient rewrite (tools/gpu_session_r03zz.sh) when it exists
 OT = O
 for cand in ("r03zz", "r03zn"):          # the latest one that exists (r03zn: after the 256 x 256 tiles, tools/gpu_session_r03n.sh)
@@ -81,7 +102,7 @@ open(os.path.join(P, "r03_train_kernel_stats.md"), "w").write(
     "+ %.1f ragged tiles + %.2f fix-up + %.2f heads = %.1f ms); the remaining "
     "`gemm_kernel<true, false, *>` launches are the gradients w.r.t. the embeddings (1.9 ms per step as in round 2).\n\n"
     % (wb["total"] / steps, wf["total"] / steps, wt["total"] / steps, fx["total"] / steps, (hw["total"] + hf["total"]) / steps,
-       (wb["total"] + wf["total"] + wt["total"] + fx["total"] + hw["total"] + hf["total"]) / steps) + head(tk, 26))
+       (wb["total"] + wf["total"] + wt["total"] + fx["total"] + hw["total"] + hf["total"]) / steps) + budget(tk, steps) + head(tk, 26))
 
 pm = json.load(open(os.path.join(O, "r03_pmc.json")))
 d = pm["derived"]
