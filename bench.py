@@ -9,10 +9,14 @@ region.  `--config` selects the BASELINE.json configuration (index into its `con
 
   0  ToyDesk-2 frame, scene branch only, 64 coarse samples (the reference's CPU plumbing case, here on the GPU)
   1  ToyDesk-2 frame, scene + object branches, 64 + 64                  <- the configuration the metric is quoted on;
-                                                                           DEFAULT at --gpus 1
+                                                                           DEFAULT at EVERY --gpus N: one frame per rank
+                                                                           per step (weak scaling), all frames' pixels
+                                                                           all-gathered -- the N = 1, 2, 4, 8 lines are
+                                                                           one workload
   2  ScanNet-0113-multi frame, 5 object codes (per ray), 64 + 128, frustum bound 0.025, rays_in_bbox
   3  configs[2]'s frame cut into contiguous ray bands over the N ranks + ONE RCCL all-gather of the rendered pixels
-     (rgb, depth, opacity packed in one message)                        <- DEFAULT at --gpus N > 1 (strong scaling)
+     (rgb, depth, opacity packed in one message): strong scaling.  Every default N > 1 line also carries this frame as
+     `strong_scaling` -- its time on the N ranks next to the time rank 0 needs for the SAME frame alone in the same run
   4  the editing demo (duplicating + moving): ray sets [background, object 4, object 4'] generated on the device,
      render_rays_multi 64 + 64 with the removed-object box, pixels sharded like 3
 
@@ -29,7 +33,15 @@ Prints ONE JSON line on rank 0 (contract in the task description) with
                   committed profile when rocprofv3 is unavailable;
   cpu_baseline -- the oracle (port of the reference's PyTorch path, oracle/objnerf_oracle.py) timed on the host cores
                   on a bounded sample of the same workload (N = 1 only), and PSNR of the GPU pixels against it;
-  multi_gpu    -- (N > 1 or --dist) RCCL world size, per-rank render ms, gather ms.
+  multi_gpu    -- (N > 1 or --dist) RCCL world size, per-rank render ms, gather ms;
+  strong_scaling -- (N > 1, configs 0-2) BASELINE configs[3]: one frame sharded over the N ranks, with its same-run N = 1 anchor;
+  train_step   -- the reference's training step (train.py:147-180: 2048 rays, 64 + 64, perturb, noise, both branches) on the
+                  differentiable HIP path: forward + backward + gradient exchange + Adam, free-running, ms per step and the
+                  fraction of the fp32-MFMA peak on 3 x forward FLOP (never part of `value`).
+
+--one-gpu: all N ranks share cuda:0 and the collectives run over gloo with host-staged messages (RCCL refuses two ranks on one
+device).  Not a performance mode: it executes the N > 1 code path -- self-launch, RayShards, the HIP renderer in N processes,
+a real inter-process gather -- on a box with one GPU (tests/test_gpu_dist.py).
 """
 import argparse
 import ctypes as C
@@ -64,7 +76,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=None, choices=[0, 1, 2, 3, 4],
-                    help="BASELINE.json configs[] index (default: 1 at --gpus 1, 3 at --gpus N > 1)")
+                    help="BASELINE.json configs[] index (default: 1 at every --gpus N)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None,
                     help="N > 1: strong = one frame shared by all ranks (default for configs 3, 4), weak = one frame per rank")
     ap.add_argument("--width", type=int, default=640)
@@ -85,6 +97,13 @@ def parse(argv=None):
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("RANK", "WORLD"), default=None,
                     help="single process: render only the share that rank RANK of WORLD would render (tools/band_replay.py)")
     ap.add_argument("--dist", action="store_true", help="initialise the RCCL process group even at N = 1")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="N > 1 on a one-GPU box: every rank uses cuda:0, collectives over gloo with host-staged messages")
+    ap.add_argument("--strong-steps", type=int, default=2,
+                    help="N > 1, configs 0-2: extra frames of BASELINE configs[3] (one frame sharded over the N ranks) reported as "
+                         "`strong_scaling` together with rank 0 rendering the same frame alone (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=24,
+                    help="extra, separately reported free-running training steps of the reference batch (`train_step`; 0 = skip)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -104,15 +123,16 @@ def self_launch(args, argv, cmd=None):
     """Starts ranks 0..N-1 of this script (cmd: the test suite substitutes a stand-in child), waits for all of them and
     returns the first non-zero exit code (stopping the remaining ranks) or 0."""
     n = args.gpus
+    one_gpu = bool(getattr(args, "one_gpu", False))
     if cmd is None:
         have = torch.cuda.device_count()
-        if have < n:
+        if have < (1 if one_gpu else n):
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
         cmd = [sys.executable, os.path.abspath(__file__)]
     port = _free_port()
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if one_gpu else r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OBJNERF_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(list(cmd) + list(argv), env=env))
@@ -327,6 +347,8 @@ def run(args, renderer=None, backend="nccl", argv=None):
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.as_rank is not None and (world != 1 or not 0 <= args.as_rank[0] < args.as_rank[1]):
         raise SystemExit("bench.py --as-rank RANK WORLD is a single-process replay (0 <= RANK < WORLD, --gpus 1)")
+    if args.one_gpu:
+        local_rank, backend = 0, "gloo"
     if renderer is None:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -345,8 +367,11 @@ def run(args, renderer=None, backend="nccl", argv=None):
             dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
 
-    cfg_id = args.config if args.config is not None else (1 if world == 1 else 3)
+    # ONE default workload at every N (configs[1], the configuration the metric is quoted on; one frame per rank per step),
+    # so that the driver's N = 1, 2, 4, 8 series is same-workload and its N = 1 point is the BENCH line
+    cfg_id = args.config if args.config is not None else 1
     scaling = args.scaling or ("strong" if (cfg_id in (3, 4) or world == 1) else "weak")
+    cdev = torch.device("cpu") if backend == "gloo" else dev        # where the bookkeeping collectives' scalars live
     # what the JSON line says: configs 3 / 4 are the sharded-frame (strong-scaling) modes at any N; a plain N = 1 run of
     # the other configs is the one-frame-per-rank series, i.e. "weak"
     scaling_label = scaling if (world > 1 or cfg_id in (3, 4)) else "weak"
@@ -390,7 +415,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
         return None
 
     def allreduce(x, op):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         if dist is not None:
             dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
         return t.item()
@@ -398,8 +423,8 @@ def run(args, renderer=None, backend="nccl", argv=None):
     def allgather_list(x):
         if dist is None:
             return [x]
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        o = torch.empty(world, dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        o = torch.empty(world, dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(o, t)
         return o.tolist()
 
@@ -427,6 +452,15 @@ def run(args, renderer=None, backend="nccl", argv=None):
     extra = None
     if on_gpu and args.split_bf16_steps > 0:
         extra = split_bf16_leg(wl, args, lib, fence, allreduce, evals_job)
+
+    # ---- BASELINE configs[3] beside a default N > 1 line: one frame over the N ranks + its same-run N = 1 anchor ----
+    strong = None
+    if dist is not None and world > 1 and cfg_id in (0, 1, 2) and args.strong_steps > 0 and args.as_rank is None:
+        strong = strong_scaling_leg(args, R, rank, world, dist, fence, allreduce, allgather_list, backend)
+    # ---- the reference's training step on the differentiable HIP path (row f1), reported beside the headline ----
+    train = None
+    if on_gpu and args.train_steps > 0 and args.as_rank is None:
+        train = train_step_leg(args, dev, rank, world, dist, fence, allreduce)
 
     res = None
     if rank == 0:
@@ -482,6 +516,13 @@ def run(args, renderer=None, backend="nccl", argv=None):
                                         "wait for the slowest rank's render; gather_alone_ms = the same collective after a barrier"}
         if extra is not None:
             res["split_bf16_mode"] = extra
+        if strong is not None:
+            res["strong_scaling"] = strong
+        if train is not None:
+            res["train_step"] = train
+        if args.one_gpu:
+            res["config"]["one_gpu"] = ("all %d ranks share cuda:0, collectives over gloo with host-staged messages: a run of the "
+                                        "N > 1 code path on a one-GPU box, not a scaling measurement" % world)
     if rank == 0 and lib is not None:
         want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and args.as_rank is None)     # every config at N = 1
         res["roofline"].update(pmc_traffic(args, cfg_id, live=want_pmc and dist is None))
@@ -492,6 +533,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
         res["psnr_vs_cpu_oracle_db"], res["psnr_delta_vs_reference_db"] = psnr
     if rank == 0:
         res["config"]["mean_" + wl.gather_keys[0]] = float(out[wl.gather_keys[0]].double().mean().item())   # float64: independent of layout / reduction order
+        res["config"]["bits_" + wl.gather_keys[0]] = bit_sum(out[wl.gather_keys[0]])
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -502,6 +544,119 @@ def run(args, renderer=None, backend="nccl", argv=None):
 
 def backend_name(backend):
     return "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
+
+
+def bit_sum(t):
+    """sum of the fp32 bit patterns of a map (mod 2^63): equal for bit-equal maps whatever the reduction order, and a one-ulp
+    change anywhere changes it"""
+    return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+
+
+def strong_scaling_leg(args, R, rank, world, dist, fence, allreduce, allgather_list, backend):
+    """BASELINE configs[3]: ONE ScanNet-multi frame (5 codes, 64 + 128) cut into ray bands over the N ranks, pixels
+    all-gathered -- and, as its same-workload anchor, rank 0 rendering that whole frame alone while the others wait at a
+    barrier.  `value`-independent: runs after the timed region."""
+    wl = Workload(3, args, R, rank, world, "strong", dist)
+    out = wl.step()
+    fence()
+    wl.marks.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.strong_steps):
+        out = wl.step()
+    fence()
+    t_n = allreduce(time.perf_counter() - t0, "MAX") / args.strong_steps
+    render_ms, gather_ms = wl.phase_ms()
+    per_rank_render = allgather_list(render_ms)
+    bits_n = bit_sum(out[wl.gather_keys[0]]) if rank == 0 else 0
+    t_1, bits_1 = 0.0, 0
+    if rank == 0:
+        alone = Workload(3, args, R, 0, 1, "strong", None, as_rank=True, scene=wl.sc)
+        alone.step()
+        R.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.strong_steps):
+            o1 = alone.step()
+        R.sync()
+        t_1 = (time.perf_counter() - t0) / args.strong_steps
+        bits_1 = bit_sum(o1[wl.gather_keys[0]])
+    fence()
+    if rank != 0:
+        return None
+    evals = float(wl.n_pixels) * wl.evals_per_ray
+    return {"workload": CONFIG_TEXT[3] % (args.width, args.height, wl.S, wl.I), "baseline_config_index": 3, "n_gpus": world,
+            "steps": args.strong_steps, "sharding": wl.shard_mode, "ms_per_frame": 1e3 * t_n, "value": evals / t_n,
+            "unit": "ray-samples/s", "per_rank_render_ms": per_rank_render, "rank0_gather_ms_incl_wait": gather_ms,
+            "anchor_n1_ms_per_frame": 1e3 * t_1, "anchor_n1_value": evals / t_1,
+            "anchor": "rank 0 renders the same frame alone (no shards, no collective) in this run while the other ranks wait",
+            "speedup_vs_anchor": t_1 / t_n, "efficiency_vs_anchor": t_1 / t_n / world,
+            "frame_bit_equal_to_anchor": bits_n == bits_1, "collective": backend_name(backend)}
+
+
+def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
+    """The reference's training step (train.py:147-180, config/default_conf.yml: 2048 rays per batch, 64 coarse + 64 fine,
+    perturb = 1, noise_std = 1, scene + object branches, occlusion mask, voxel embedding) through the differentiable HIP
+    render_rays: forward, backward, gradient exchange (N > 1: broadcast_parameters once, GradientSync per step), Adam.
+    Free-running: nothing waits for the device inside a step, the launch queue is bounded by one synchronisation every 8
+    steps (a loop that logs its loss now and then).  FLOP convention: 3 x forward GEMM FLOP per evaluated sample point."""
+    try:
+        import object_nerf_amd as A
+        from object_nerf_amd import synth
+        from object_nerf_amd.distributed import GradientSync, broadcast_parameters
+        sc = synth.build_scene(A, True, preset=synth.SCANNET_LIKE, max_voxels=args.max_voxels, device=dev)
+        mods = (sc.models["coarse"], sc.models["fine"], sc.code_library, sc.embeddings["xyz"])
+        params = [p for m in mods for p in m.parameters()]
+        if dist is not None and world > 1:
+            broadcast_parameters(params + [b for m in mods for b in m.buffers()], src=0)
+        rays_all = synth.camera_rays(args.width, args.height).to(dev)
+        opt = torch.optim.Adam(params, lr=1e-3)
+        table = sc.embeddings["xyz"].embedding_space_ftr.weight
+        sync = GradientSync(params, active_rows={table: sc.embeddings["xyz"].active_rows()})
+        g = torch.Generator(device=dev).manual_seed(rank)
+        target = torch.rand(n_rays, 3, device=dev, generator=g)
+        ids = synth.per_ray_ids(n_rays).to(dev)
+        ptm = (ids == 1).view(-1, 1)
+
+        def step():
+            idx = torch.randint(0, rays_all.shape[0], (n_rays,), device=dev, generator=g)
+            rays = rays_all[idx].contiguous()
+            opt.zero_grad(set_to_none=True)
+            codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+            r = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                              embedding_instance=codes, frustum_bound_th=0.025, pass_through_mask=ptm)
+            loss = sum(((r["rgb_%s" % t] - target) ** 2).mean() + ((r["rgb_instance_%s" % t] - target) ** 2).mean()
+                       + 0.1 * (r["depth_%s" % t] ** 2).mean() + (r["opacity_instance_%s" % t] ** 2).mean() for t in ("coarse", "fine"))
+            loss.backward()
+            sync.sync()
+            opt.step()
+            return loss
+        l0 = step().item()
+        for _ in range(7):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.train_steps):
+            loss = step()
+            if i % 8 == 7:
+                torch.cuda.synchronize()
+        fence()
+        dt = allreduce(time.perf_counter() - t0, "MAX") / args.train_steps
+        l1 = loss.item()
+        evals = float(n_rays) * 192 * world
+        tflops = evals * FLOP_BOTH * 3.0 / dt / 1e12
+        return {"ms_per_step": 1e3 * dt, "steps": args.train_steps, "rays_per_rank": n_rays, "n_gpus": world,
+                "value": evals / dt, "unit": "ray-samples/s (forward + backward + Adam)",
+                "workload": "train.py:147-180 batch: %d rays x (64 coarse + 64 fine), perturb 1, noise_std 1, scene + object "
+                            "branches, occlusion mask, voxel embedding, ScanNet-like scene, Adam on both MLPs + codes + voxel table"
+                            % n_rays,
+                "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+                             "frac": tflops / (PEAK_FP32_MFMA_TFLOPS * world),
+                             "flop_convention": "3 x forward GEMM FLOP (forward + dgrad + wgrad) per evaluated sample point, whole "
+                                                "step incl. sampling, compositing, gradient exchange and Adam"},
+                "gradient_exchange": ("GradientSync: %d flat all-reduce(s) of %s bytes" % (len(sync.buckets), sync.message_bytes()))
+                                     if (dist is not None and world > 1) else "none (1 rank)",
+                "loss_first": l0, "loss_last": l1}
+    except Exception as e:      # an optional leg must never cost the headline line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def split_bf16_leg(wl, args, lib, fence, allreduce, evals_job):

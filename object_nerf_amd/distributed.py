@@ -12,7 +12,9 @@ Training (SURVEY.md §8 row f1 on N GPUs) is plain data parallelism like the ref
 `GradientSync` averages the gradients with a few large flat all-reduces.
 
 Backend: torch.distributed "nccl" (= RCCL on ROCm) for GPU tensors; the same functions work on
-"gloo" with CPU tensors, which is how tests/test_distributed_gloo.py covers world_size 2.
+"gloo" with CPU tensors, which is how tests/test_distributed_gloo.py covers world_size 2 and 8.  A gloo group
+handed DEVICE tensors (several ranks sharing one GPU, where RCCL refuses duplicate devices: `bench.py --one-gpu`,
+tests/test_gpu_dist.py) stages the message through host memory -- gloo has no device all-gather.
 """
 from typing import Dict, Iterable, List, Sequence, Tuple
 
@@ -130,6 +132,20 @@ def default_block(n: int, world: int) -> int:
     return b
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """device tensor on a gloo group: the collective runs on a host copy"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(out: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    if _host_staged(send, group):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, send.cpu(), group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, send, group=group)
+
+
 def gather_pixels(local: torch.Tensor, n_total: int = None, shards: RayShards = None) -> torch.Tensor:
     """All-gathers per-ray pixel rows.  `local` is (n_local, C) (or (n_local,)); short / empty shards are padded to the
     longest one for the collective and the padding dropped afterwards.  Returns (n_total, C) in frame order."""
@@ -150,7 +166,7 @@ def gather_pixels(local: torch.Tensor, n_total: int = None, shards: RayShards = 
         send = x.new_zeros(per, cols)
         send[: x.shape[0]].copy_(x)
     out = x.new_empty(world * per, cols)
-    dist.all_gather_into_tensor(out, send)
+    _all_gather_into(out, send)
     if shards is not None:
         out = shards.restore(out)
     return out.reshape(-1) if squeeze else out
@@ -169,6 +185,11 @@ def gather_pixel_maps(local: Dict[str, torch.Tensor], n_total: int = None, shard
     cols = [int(torch.Size(local[k].shape[1:]).numel()) for k in keys]          # 1 for (n_local,) maps
     first = local[keys[0]]
     n_local = first.shape[0]
+    for k in keys:          # one packed message: a map of another dtype / device would be cast or copied silently
+        if local[k].dtype != first.dtype or local[k].device != first.device or local[k].shape[0] != n_local:
+            raise RuntimeError("gather_pixel_maps: map %r is %s on %s with %d rows, %r is %s on %s with %d rows -- the maps of "
+                               "one message share dtype, device and row count (gather other dtypes in a call of their own)"
+                               % (k, local[k].dtype, local[k].device, local[k].shape[0], keys[0], first.dtype, first.device, n_local))
     if shards is None and n_total is not None:
         shards = RayShards(n_total, world)
     per = n_local if shards is None else shards.per
@@ -180,7 +201,7 @@ def gather_pixel_maps(local: Dict[str, torch.Tensor], n_total: int = None, shard
     if n_local < per:
         packed[n_local:].zero_()
     full = first.new_empty(world * per, packed.shape[1])
-    dist.all_gather_into_tensor(full, packed)
+    _all_gather_into(full, packed)
     if shards is not None:
         full = shards.restore(full)
     out, off = {}, 0
@@ -246,6 +267,65 @@ def render_rays_multi_sharded(render_fn, rays_list, gather_keys: Iterable[str] =
         on_rendered(res)
     maps = {k: res[k] for k in gather_keys if k in res}
     return maps if as_rank is not None else gather_pixel_maps(maps, n, sh)
+
+
+@torch.no_grad()
+def broadcast_parameters(tensors: Iterable[torch.Tensor], src: int = 0, group=None, bucket_bytes: int = 64 << 20) -> int:
+    """Every rank's tensors become rank `src`'s, in place: the initial synchronisation of data-parallel training (what
+    Lightning's DDP does when it wraps the module, train.py:261-262 -- `GradientSync` keeps replicas equal only if they
+    START equal).  Pass parameters AND buffers (`list(m.parameters()) + list(m.buffers())`: the voxel index map and the
+    grid geometry are buffers).  Like the gradient exchange: few large messages -- tensors are packed per dtype into flat
+    buckets of up to `bucket_bytes`, one broadcast each, all in flight before the first wait.  Every rank must pass
+    tensors of the same shapes and dtypes in the same order (checked: a one-number digest of the layout is compared
+    first).  No-op without a process group or in a 1-rank group.  Returns the number of bytes that travelled."""
+    ts = [t for t in tensors]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not ts:
+        return 0
+    # layout digest: ranks that disagree on the list would otherwise exchange garbage (or hang on message sizes)
+    import zlib
+    desc = ";".join("%s:%s" % (str(t.dtype), "x".join(str(int(d)) for d in t.shape)) for t in ts).encode()
+    ddev = "cpu" if dist.get_backend(group) == "gloo" else ts[0].device       # RCCL moves device tensors only
+    mine = torch.tensor([zlib.crc32(desc), len(ts)], dtype=torch.int64, device=ddev)
+    ref = mine.clone()
+    dist.broadcast(ref, src=src, group=group)
+    agree = (ref == mine).all().to(torch.int64).reshape(1)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
+    if int(agree.item()) != 1:
+        raise RuntimeError("broadcast_parameters: the ranks pass different tensor lists (count / shapes / dtypes)")
+    by_dtype: Dict[torch.dtype, List[int]] = {}
+    for i, t in enumerate(ts):
+        by_dtype.setdefault(t.dtype, []).append(i)
+    pending, total = [], 0
+    for dt, idx in by_dtype.items():
+        cur, cur_bytes, buckets = [], 0, []
+        for i in idx:
+            nb = ts[i].numel() * ts[i].element_size()
+            if cur and cur_bytes + nb > bucket_bytes:
+                buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(i)
+            cur_bytes += nb
+        if cur:
+            buckets.append(cur)
+        for b in buckets:
+            dev = ts[b[0]].device
+            staged = _host_staged(ts[b[0]], group)
+            flat = torch.empty(sum(ts[i].numel() for i in b), dtype=dt, device="cpu" if staged else dev)
+            off = 0
+            for i in b:
+                n = ts[i].numel()
+                flat[off:off + n].copy_(ts[i].reshape(-1))
+                off += n
+            total += flat.numel() * flat.element_size()
+            pending.append((dist.broadcast(flat, src=src, group=group, async_op=True), flat, b))
+    for work, flat, b in pending:
+        work.wait()
+        off = 0
+        for i in b:
+            n = ts[i].numel()
+            ts[i].copy_(flat[off:off + n].view(ts[i].shape))
+            off += n
+    return total
 
 
 class GradientSync:
@@ -317,6 +397,8 @@ class GradientSync:
         idx = self.buckets[b]
         n = sum(self._numel(i) for i in idx)
         dev = self.params[idx[0]].device
+        if _host_staged(self.params[idx[0]], self.group):      # several ranks on one GPU over gloo: the message lives on the host
+            dev = torch.device("cpu")
         if self._flat[b] is None or self._flat[b].device != dev or self._flat[b].numel() != n:
             self._flat[b] = torch.empty(n, dtype=torch.float32, device=dev)
         return self._flat[b]
@@ -359,6 +441,8 @@ class GradientSync:
                 p = self.params[i]
                 n = self._numel(i)
                 g = flat[off:off + n]
+                if g.device != p.device:
+                    g = g.to(p.device)
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 if p.grad.is_contiguous():

@@ -114,19 +114,34 @@ def test_as_rank_replay_renders_one_ranks_share():
     assert abs(sum(s["config"]["evals_per_step_all_ranks"] for s in shares) - whole["config"]["evals_per_step_all_ranks"]) < 1e-6
 
 
-def test_weak_scaling_world2_renders_two_frames():
-    two = _run(2, ["--config", "1"])
-    assert two["scaling"] == "weak" and two["config"]["frames_per_step"] == 2
-    assert two["config"]["evals_per_step_all_ranks"] == 2 * 12 * 9 * 192
-    assert two["config"]["rays_per_step_rank0"] == 12 * 9
-
-
-def test_default_config_follows_world_size():
+def test_default_line_is_one_workload_at_every_world_size():
+    """the driver's N = 1, 2, 4, 8 series: `--gpus N` without --config is BASELINE configs[1] at EVERY N (one frame per rank
+    per step, weak scaling), so the series' N = 1 point is the BENCH line; the N > 1 line additionally carries configs[3]
+    (one frame sharded over the ranks) with rank 0's same-run, same-frame anchor"""
     import bench
     a = bench.parse(["--gpus", "8"])
-    assert a.config is None and a.scaling is None      # resolved in run(): 3 / strong at N > 1, 1 at N = 1
+    assert a.config is None and a.scaling is None      # resolved in run(): configs[1] at every N
     one = _run(1, [])
-    assert one["config"]["baseline_config_index"] == 1 and "multi_gpu" not in one
+    two = _run(2, [])
+    check_contract(one, 1)
+    check_contract(two, 2)
+    assert one["config"]["baseline_config_index"] == two["config"]["baseline_config_index"] == 1
+    assert one["scaling"] == two["scaling"] == "weak" and "multi_gpu" not in one and "strong_scaling" not in one
+    assert one["config"]["workload"] == two["config"]["workload"] and one["metric"] == two["metric"]
+    assert two["config"]["frames_per_step"] == 2 and two["config"]["rays_per_step_rank0"] == 12 * 9
+    assert two["config"]["evals_per_step_all_ranks"] == 2 * one["config"]["evals_per_step_all_ranks"] == 2 * 12 * 9 * 192
+    ss = two["strong_scaling"]
+    assert ss["baseline_config_index"] == 3 and ss["n_gpus"] == 2 and ss["sharding"] == "contiguous"
+    assert len(ss["per_rank_render_ms"]) == 2 and ss["ms_per_frame"] > 0 and ss["anchor_n1_ms_per_frame"] > 0
+    assert ss["frame_bit_equal_to_anchor"] is True                      # the sharded frame IS the unsharded frame
+    assert abs(ss["speedup_vs_anchor"] - ss["anchor_n1_ms_per_frame"] / ss["ms_per_frame"]) < 1e-9
+    assert abs(ss["value"] * ss["ms_per_frame"] / 1e3 - 12 * 9 * 256) < 1e-6 * 12 * 9 * 256
+    assert "train_step" not in two                                      # the training leg needs the HIP path
+
+
+def test_strong_leg_can_be_switched_off():
+    two = _run(2, ["--config", "1", "--strong-steps", "0"])
+    assert two["scaling"] == "weak" and "strong_scaling" not in two and two["config"]["frames_per_step"] == 2
 
 
 def test_self_launch_starts_every_rank_and_propagates_failures(tmp_path):

@@ -202,6 +202,63 @@ def test_gradient_sync(world):
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
+def _bcast_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from object_nerf_amd.distributed import broadcast_parameters, gather_pixel_maps
+        g = torch.Generator().manual_seed(100 + rank)                  # every rank starts from DIFFERENT values
+        shapes = [(256, 271), (256,), (64, 64), (1000, 24), (3, 128), (1,)]
+        params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+        idx_map = torch.randint(-1, 1000, (6, 7, 5), generator=g, dtype=torch.int64)      # a buffer of another dtype
+        flag = torch.tensor(rank == 0)                                                   # 0-d bool buffer
+        g1 = torch.Generator().manual_seed(101)                         # what rank 1 holds
+        want = [torch.randn(*s, generator=g1) for s in shapes]
+        want_idx = torch.randint(-1, 1000, (6, 7, 5), generator=g1, dtype=torch.int64)
+        moved = broadcast_parameters(params + [idx_map, flag], src=1, bucket_bytes=64 << 10)   # several buckets per dtype
+        ok = moved == 4 * sum(p.numel() for p in params) + 8 * idx_map.numel() + 1
+        ok = ok and all(torch.equal(p.detach(), w) for p, w in zip(params, want)) and torch.equal(idx_map, want_idx)
+        ok = ok and bool(flag.item()) is False and all(p.requires_grad for p in params)
+        # a rank that passes another list is told so instead of exchanging garbage
+        try:
+            broadcast_parameters(params[: (3 if rank == 0 else 2)], src=0)
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "different tensor lists" in str(e)
+        # one packed pixel message carries one dtype: a mixed request is refused, not cast
+        try:
+            gather_pixel_maps({"rgb": torch.zeros(4, 3), "ids": torch.zeros(4, dtype=torch.int64)}, 4 * world)
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "share dtype" in str(e)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_broadcast_parameters(world):
+    """the initial synchronisation of data-parallel training (Lightning DDP broadcasts the wrapped module's state from rank 0,
+    train.py:261-262): parameters and buffers of every dtype, bucketed, from any source rank"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_broadcast_parameters_without_process_group_is_a_noop():
+    from object_nerf_amd.distributed import broadcast_parameters
+    p = torch.nn.Parameter(torch.ones(3))
+    assert broadcast_parameters([p]) == 0 and torch.equal(p.detach(), torch.ones(3))
+
+
 def test_gradient_sync_without_process_group_is_a_noop():
     p = torch.nn.Parameter(torch.ones(3))
     p.grad = torch.full((3,), 2.0)

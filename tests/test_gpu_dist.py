@@ -17,7 +17,7 @@ from object_nerf_amd.distributed import GradientSync
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "3", "--warmup", "1", "--width", "320", "--height", "240", "--max-voxels", "120000", "--cpu-rays", "0",
-         "--split-bf16-steps", "0", "--pmc", "off"]
+         "--split-bf16-steps", "0", "--pmc", "off", "--train-steps", "0"]
 
 
 def _bench(extra, env=None):
@@ -70,6 +70,7 @@ def test_bench_default_line_carries_cpu_baseline():
     small = [a for a in SMALL]
     i = small.index("--cpu-rays")
     small[i + 1] = "96"
+    small[small.index("--train-steps") + 1] = "8"
     e = dict(os.environ)
     e.pop("OBJNERF_MFMA", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, env=e, capture_output=True, text=True, timeout=600)
@@ -81,6 +82,54 @@ def test_bench_default_line_carries_cpu_baseline():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["unit"] == r["unit"] and 0 < cb["value"] < r["value"]
     assert r["psnr_vs_cpu_oracle_db"] > 60.0
+    # the training step of the reference batch rides on the same line (never part of `value`)
+    ts = r["train_step"]
+    assert "error" not in ts, ts
+    assert ts["steps"] == 8 and ts["rays_per_rank"] == 2048 and 0 < ts["ms_per_step"] < 200
+    assert 0 < ts["roofline"]["frac"] < 1 and ts["roofline"]["peak"] == 157.3 and ts["loss_last"] < ts["loss_first"]
+
+
+def test_two_ranks_on_one_gpu_render_the_sharded_frame_bit_equal():
+    """The N > 1 code path EXECUTED on the HIP renderer (the box has one GPU; RCCL refuses two ranks on one device, so the
+    pixel all-gather runs over gloo with a host-staged message): bench.py's self-launch, RayShards bands, two renderer
+    processes, one inter-process gather -- the gathered configs[3] frame is bit-equal to configs[2]'s unsharded frame."""
+    plain = _bench(["--config", "2"])
+    two = _bench(["--gpus", "2", "--one-gpu", "--config", "3"])
+    assert two["n_gpus"] == 2 and two["multi_gpu"]["world_size"] == 2 and two["multi_gpu"]["backend"] == "gloo"
+    assert two["scaling"] == "strong" and two["config"]["rays_per_step_rank0"] == 120 * 320
+    assert len(two["multi_gpu"]["per_rank_render_ms"]) == 2 and all(v > 0 for v in two["multi_gpu"]["per_rank_render_ms"])
+    assert two["config"]["bits_rgb_fine"] == plain["config"]["bits_rgb_fine"]
+    assert two["config"]["mean_rgb_fine"] == plain["config"]["mean_rgb_fine"]
+    assert two["config"]["evals_per_step_all_ranks"] == plain["config"]["evals_per_step_all_ranks"]
+    assert "one_gpu" in two["config"]
+    # the editing demo's block-cyclic split through render_rays_multi_sharded, three ranks (ragged: 240 rows in 4-row blocks)
+    whole = _bench(["--config", "4"])
+    three = _bench(["--gpus", "3", "--one-gpu", "--config", "4"])
+    assert three["multi_gpu"]["world_size"] == 3 and three["config"]["sharding"] == "cyclic"
+    assert three["config"]["bits_rgb_fine"] == whole["config"]["bits_rgb_fine"]
+    assert abs(three["config"]["evals_per_step_all_ranks"] - whole["config"]["evals_per_step_all_ranks"]) < 1e-6
+
+
+def test_default_two_rank_line_on_one_gpu():
+    """`bench.py --gpus 2` as the driver issues it (no --config): configs[1] at every N, one frame per rank, plus the
+    configs[3] frame with its same-run anchor and the data-parallel training step (broadcast_parameters + GradientSync)"""
+    one = _bench([])
+    small = [a for a in SMALL]
+    small[small.index("--train-steps") + 1] = "8"
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small + ["--gpus", "2", "--one-gpu"], env=e,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    two = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert one["config"]["baseline_config_index"] == two["config"]["baseline_config_index"] == 1
+    assert one["config"]["workload"] == two["config"]["workload"] and one["scaling"] == two["scaling"] == "weak"
+    assert two["config"]["frames_per_step"] == 2
+    assert two["config"]["evals_per_step_all_ranks"] == 2 * one["config"]["evals_per_step_all_ranks"]
+    ss = two["strong_scaling"]
+    assert ss["baseline_config_index"] == 3 and ss["frame_bit_equal_to_anchor"] is True and ss["n_gpus"] == 2
+    ts = two["train_step"]
+    assert "error" not in ts, ts
+    assert ts["n_gpus"] == 2 and "all-reduce" in ts["gradient_exchange"] and ts["loss_last"] < ts["loss_first"]
 
 
 def test_gradient_sync_over_rccl_world1():
