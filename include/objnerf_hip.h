@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 6
+#define OBJNERF_ABI_VERSION 7
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -87,6 +87,9 @@ int objnerf_sample_coarse(const float* rays, const float* z_steps, const float* 
 
 /* Embedding.forward (embedding_helper.py:57-74): x (n, C) -> (n, C*(2F+1)) */
 int objnerf_pos_encode(const float* x, int64_t n, int C, int n_freqs, float* out, void* stream);
+/* the same with explicit frequency bands (n_freqs device floats): `logscale=False`, torch.linspace(1, 2^(F-1), F)
+ * (embedding_helper.py:54-55); freqs == NULL is objnerf_pos_encode */
+int objnerf_pos_encode_freqs(const float* x, int64_t n, int C, int n_freqs, const float* freqs, float* out, void* stream);
 
 /* EmbeddingVoxel.forward (embedding_helper.py:325-411): xyz (n,3) -> scene_ftr (n,271), obj_ftr (n,104) */
 int objnerf_voxel_embed(const objnerf_voxel_grid* grid, const float* xyz, int64_t n,
@@ -130,9 +133,9 @@ typedef struct {
   float* rgb;
   float* inst_sigma;
   float* inst_rgb;
-  /* memory form only: evaluate just the density head of the selected branch (nerf_model.py:111-112,
-   * 142-143 `sigma_only=True`, used by tools/extract_mesh.py:85-108): the final / direction / rgb
-   * layers are skipped (scene branch: 597,760 instead of 699,904 MAC per point) */
+  /* evaluate just the density head of the selected branch (nerf_model.py:111-112, 142-143 `sigma_only=True`, used by
+   * tools/extract_mesh.py:85-108): the final / direction / rgb layers are skipped (scene branch: 597,760 instead of
+   * 699,904 MAC per point).  Memory form: as ObjectNeRF.forward gets its inputs; fused form: see `points` below */
   int32_t sigma_only;
   /* fused form only: `blob` is an objnerf_pack_weights_b3() stream and the MLP runs in the split-bf16 mode above */
   int32_t mfma_bf16x3;
@@ -163,6 +166,20 @@ typedef struct {
    * inst_dir_encoding: the reference repeats both over the samples (rendering.py:89-94) -- are then taken from there
    * instead of being contracted per sample point: 2.45 % fewer MFMAs, same sums in another association. */
   const float* ray_bias;
+  /* fused form with sigma_only (ABI 7): the density query of tools/extract_mesh.py:63-113 in ONE enqueue -- the kernel
+   * takes the n_points sample POINTS themselves instead of rays x depths (rays / z_vals NULL, no direction, one branch:
+   * do_scene xor do_object; an object query reads ONE code at `codes`), embeds them in registers (voxel grid or
+   * Embedding(3,10), exactly as the render path does) and stops after the density head: sigma / inst_sigma (n_points).
+   * The script's per-chunk embedding_xyz(...) -> forward(..., sigma_only=True) loop materialises 271 (+104) floats per
+   * point and reads them back; here nothing but the 4-byte result reaches memory.  Either
+   *   points   (n_points, 3) explicit positions, or
+   *   lat_x / lat_y / lat_z  the axes of a lattice in np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3) order
+   *            (extract_mesh.py:62-66; fp32 values as torch.FloatTensor(...) rounds them): point ((j * nx + i) * nz + k)
+   *            = (x[i], y[j], z[k]), lat_n = {nx, ny, nz}, n_points = nx * ny * nz -- the 1.6 GB coordinate array of a
+   *            512^3 grid is never built. */
+  const float* points;
+  const float* lat_x; const float* lat_y; const float* lat_z;
+  int32_t lat_n[3];
 } objnerf_mlp_args;
 #define OBJNERF_RAY_BIAS_FLOATS 448
 /* out: objnerf_ray_bias_floats(n_rays) floats -- the (n_rays, OBJNERF_RAY_BIAS_FLOATS) vectors for

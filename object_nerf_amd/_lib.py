@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 6     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 7     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -50,6 +50,7 @@ class MlpArgs(C.Structure):
         ("ray_index", C.c_void_p), ("n_active", C.c_void_p),
         ("comp_w", C.c_void_p), ("comp_rec", C.c_void_p), ("comp_last_delta", C.c_float), ("comp_inst_weights", C.c_int32),
         ("ray_bias", C.c_void_p),
+        ("points", C.c_void_p), ("lat_x", C.c_void_p), ("lat_y", C.c_void_p), ("lat_z", C.c_void_p), ("lat_n", C.c_int32 * 3),
     ]
 
 
@@ -172,6 +173,7 @@ SIGNATURES = {
     "objnerf_pack_weights_bwd_b3": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),
     "objnerf_sample_coarse": (C.c_int, [_VP, _VP, _VP, C.c_float, C.c_int, C.c_int64, C.c_int, _VP, _VP]),
     "objnerf_pos_encode": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
+    "objnerf_pos_encode_freqs": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP, _VP]),
     "objnerf_voxel_embed": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP]),
     "objnerf_mlp_eval": (C.c_int, [C.POINTER(MlpArgs), _VP]),
     "objnerf_ray_bias": (C.c_int, [C.POINTER(MlpArgs), _VP, _VP]),

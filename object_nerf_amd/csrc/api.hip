@@ -219,9 +219,11 @@ int objnerf_pack_index_bwd_b3(int use_voxel, uint32_t* blob_idx) {
 
 int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if (!a || !a->blob || !a->aux) return set_error(-1, "mlp_eval: null weights");
-  if ((a->emb_xyz == nullptr ? a->n_rays * (int64_t)a->S : a->n_points) == 0) return 0;   // nothing to do
-  if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
   const bool fused = a->emb_xyz == nullptr;
+  // the density query on points / a lattice (tools/extract_mesh.py:63-113): fused form + sigma_only
+  const bool query = fused && a->sigma_only;
+  if ((fused && !query ? a->n_rays * (int64_t)a->S : a->n_points) == 0) return 0;   // nothing to do
+  if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
   const bool comp = a->comp_w != nullptr;      // compositing in the epilogue: sigma / rgb need not be written
   if (a->ray_bias && (!fused || a->sigma_only)) return set_error(-1, "mlp_eval: ray_bias needs the fused form");
   if (comp) {
@@ -235,9 +237,22 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   // n_rays slots of a list whose tail is uninitialised; a count without a list would silently evaluate the first rays
   if ((a->ray_index == nullptr) != (a->n_active == nullptr))
     return set_error(-1, "mlp_eval: ray_index and n_active go together (both or neither)");
-  if (a->ray_index && !fused) return set_error(-1, "mlp_eval: ray_index / n_active need the fused form (rays + z_vals)");
+  if (a->ray_index && (!fused || query)) return set_error(-1, "mlp_eval: ray_index / n_active need the fused form (rays + z_vals)");
   long P;
-  if (fused) {
+  if (query) {
+    if (a->do_scene && a->do_object) return set_error(-1, "mlp_eval(points, sigma_only): one branch per call (contiguous stream window)");
+    if (a->mfma_bf16x3) return set_error(-1, "mlp_eval(points, sigma_only): the split-bf16 mode evaluates every layer");
+    if (a->n_points < 0) return set_error(-1, "mlp_eval(points, sigma_only): negative n_points");
+    if (!a->points) {
+      if (!a->lat_x || !a->lat_y || !a->lat_z) return set_error(-1, "mlp_eval(sigma_only, fused): needs points or the three lattice axes");
+      if (a->lat_n[0] < 1 || a->lat_n[1] < 1 || a->lat_n[2] < 1 || (int64_t)a->lat_n[0] * a->lat_n[1] * a->lat_n[2] != a->n_points)
+        return set_error(-1, "mlp_eval(lattice): n_points must equal lat_n[0] * lat_n[1] * lat_n[2]");
+    }
+    if (a->do_object && !a->codes) return set_error(-1, "mlp_eval(points, sigma_only): the object query needs its code");
+    if (a->use_voxel && (!a->grid.idx_map || !a->grid.table || a->grid.n_rows < 1))
+      return set_error(-1, "mlp_eval: voxel mode needs a voxel grid");
+    P = a->n_points;
+  } else if (fused) {
     if (!a->rays || !a->z_vals || a->S < 1 || a->n_rays < 0) return set_error(-1, "mlp_eval: bad fused inputs");
     if (a->do_object && !a->codes) return set_error(-1, "mlp_eval: object branch needs codes");
     if (a->use_voxel && (!a->grid.idx_map || !a->grid.table || a->grid.n_rows < 1))

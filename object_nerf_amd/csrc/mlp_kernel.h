@@ -52,6 +52,9 @@
 #ifndef OBJ_PREFETCH_TILE
 #define OBJ_PREFETCH_TILE 1  // gather prologue of the NEXT tile staged between the object-branch layers
 #endif
+#ifndef OBJ_PREFETCH_SCENE
+#define OBJ_PREFETCH_SCENE 1 // density query, scene branch: gather prologue of the NEXT tile staged on the chunk barriers of xyz_encoding_1
+#endif
 #ifndef OBJ_XCD_TILES
 #define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers)
 #endif
@@ -790,7 +793,10 @@ template <class S, int NH, int NT> struct HidThenDir {
 // MFMAs to land (the chain cost 1.5 % of the kernel when it ran at the top of every pass).
 // Arithmetic and its order are identical in both placements.
 // ---------------------------------------------------------------------------------------------
-template <bool VOXEL>
+// POINTS (the fused sigma-only form, objnerf_mlp_args.points / lat_*): the tile's 128 points are given directly -- an
+// explicit (n, 3) array or the nodes of a lattice in np.meshgrid(x, y, z) order -- instead of rays x depths; there is no
+// direction and no per-ray quantity.
+template <bool VOXEL, bool POINTS = false>
 struct TilePrologue {
   long p, ray;
   int sidx;            // the point's sample index inside its ray
@@ -807,6 +813,23 @@ struct TilePrologue {
     const long p_raw = tile * 128 + wave * 32 + (lane & 31);
     valid = p_raw < P;
     const long pc = valid ? p_raw : P - 1;
+    if constexpr (POINTS) {
+      p = pc; ray = 0; sidx = 0; zv = 0.f;
+      if (a.points) {
+        const float* q = a.points + pc * 3;
+        rw[0] = q[0]; rw[1] = q[1]; rw[2] = q[2];
+      } else {
+        // np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3) (tools/extract_mesh.py:62-66, indexing 'xy'):
+        // point ((j * nx + i) * nz + k) = (x[i], y[j], z[k])
+        const long t = pc / a.lat_n[2];
+        const int k = (int)(pc - t * a.lat_n[2]);
+        const long j = t / a.lat_n[0];
+        const int i = (int)(t - j * a.lat_n[0]);
+        rw[0] = a.lat_x[i]; rw[1] = a.lat_y[j]; rw[2] = a.lat_z[k];
+      }
+      rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = 0.f;
+      return;
+    }
     const long slot = pc / a.S;
     // ray subset (objnerf_mlp_args.ray_index): tiles walk the listed rays only; p stays the point's index in the
     // full (n_rays, S) arrays, so depths are read and results written in place
@@ -823,7 +846,7 @@ struct TilePrologue {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       dir[c] = rw[3 + c];
-      pos[c] = rw[c] + dir[c] * zv;
+      pos[c] = POINTS ? rw[c] : rw[c] + dir[c] * zv;
     }
     if constexpr (VOXEL) {
       const float sx = __fdiv_rn(pos[0] + g.offset[0], g.voxel_size);
@@ -877,6 +900,40 @@ struct TilePrologue {
       }
     }
   }
+  // the same two corners at a time (rows[0..5]: 24 registers in flight instead of 48) for the scene-only variants, whose
+  // next-tile prologue rides on the chunk barriers of xyz_encoding_1 (PrefetchHook)
+  template <int Q>
+  __device__ __forceinline__ void stage_rows2(const objnerf_voxel_grid& g, int half) {
+    if constexpr (VOXEL) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = idx[2 * Q + j];
+        const int row = (r < 0 || r >= g.n_rows) ? -1 : r;
+        idx[2 * Q + j] = row;
+        const float* t = g.table + (size_t)(row < 0 ? 0 : row) * kVoxC;
+        rows[3 * j + 0] = *(const f32x4*)(t + half * 8);
+        rows[3 * j + 1] = *(const f32x4*)(t + half * 8 + 4);
+        rows[3 * j + 2] = *(const f32x4*)(t + kScnVoxC + half * 4);
+      }
+    }
+  }
+  template <int Q>
+  __device__ __forceinline__ void stage_acc2() {
+    if constexpr (VOXEL) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = 2 * Q + j;
+        const bool bad = idx[k] < 0;
+        const float wk = w[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float f0 = bad ? 0.f : rows[3 * j][i], f1 = bad ? 0.f : rows[3 * j + 1][i], f2 = bad ? 0.f : rows[3 * j + 2][i];
+          if (k == 0) { vf[i] = f0 * wk; vf[4 + i] = f1 * wk; vf[8 + i] = f2 * wk; }
+          else { vf[i] = vf[i] + f0 * wk; vf[4 + i] = vf[4 + i] + f1 * wk; vf[8 + i] = vf[8 + i] + f2 * wk; }
+        }
+      }
+    }
+  }
   __device__ __forceinline__ void run_all(const objnerf_mlp_args& a, long tile, long P, int wave, int lane, int half) {
     stage_a(a, tile, P, wave, lane);
     stage_b(a.grid);
@@ -885,6 +942,31 @@ struct TilePrologue {
     stage_rows<1>(a.grid, half);
     stage_acc<1>();
   }
+};
+
+// layer_mac hook of xyz_encoding_1 in the scene-only variants (no object branch to stage the next tile's prologue under):
+// one level of the dependent chain per chunk barrier -- ray row / point, 8 index-map reads, then the feature rows two
+// corners at a time -- each consumed behind the NEXT barrier (3.4 us of MFMAs later; the barrier's vmcnt(0) drains them
+// anyway).  xyz_encoding_1 is the one layer during which no hidden vector is live: 128 registers to spare.
+template <bool VOXEL, bool POINTS>
+struct PrefetchHook {
+  TilePrologue<VOXEL, POINTS>& pre;
+  const objnerf_mlp_args& a;
+  long tile, P;
+  int wave, lane, half;
+  template <int C>
+  __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {
+    if constexpr (C == 0) pre.stage_a(a, tile, P, wave, lane);
+    if constexpr (C == 1) pre.stage_b(a.grid);
+    if constexpr (VOXEL) {
+      if constexpr (C == 2) pre.template stage_rows2<0>(a.grid, half);
+      if constexpr (C == 3) { pre.template stage_acc2<0>(); pre.template stage_rows2<1>(a.grid, half); }
+      if constexpr (C == 4) { pre.template stage_acc2<1>(); pre.template stage_rows2<2>(a.grid, half); }
+      if constexpr (C == 5) { pre.template stage_acc2<2>(); pre.template stage_rows2<3>(a.grid, half); }
+      if constexpr (C == 6) pre.template stage_acc2<3>();
+    }
+  }
+  template <int GI> __device__ __forceinline__ void group() const {}
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1004,7 +1086,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
                                   : (DO_OBJ ? total_chunks(VOXEL) : scene_chunks(VOXEL));
   // ray subset: the number of listed rays lives in device memory (written by objnerf_compact_rays earlier on the
   // stream), so a caller can cull rays without a host round trip; the grid was sized for all n_rays
-  long P = FUSED ? a.n_rays * (long)a.S : a.n_points;
+  constexpr bool POINTS = FUSED && SIGMA_ONLY;       // the density query on explicit points / a lattice
+  long P = (FUSED && !POINTS) ? a.n_rays * (long)a.S : a.n_points;
   long ntiles = ntiles_arg;
   if constexpr (FUSED && !SAVE) {
     if (a.n_active) {
@@ -1051,7 +1134,14 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   constexpr int NO = ks_objin(VOXEL);
 
   constexpr bool PREFETCH = OBJ_PREFETCH_TILE && FUSED && DO_OBJ;
-  TilePrologue<VOXEL> pre;
+  // scene-branch density query: there is no object branch to hide the next tile's gather chain under -- it rides on the
+  // chunk barriers of xyz_encoding_1 (PrefetchHook).  Not for the other scene-only variants (BASELINE configs[0], the
+  // background set of render_rays_multi): the next tile's 24 values would be live across the direction / colour layers
+  // too, and those variants sit at the 256 architectural registers already (measured at compile time: 48 spills).
+  static_assert(ks_emb(VOXEL) / (kChunkTiles / 8) + (ks_emb(VOXEL) % (kChunkTiles / 8) != 0) >= (VOXEL ? 7 : 2),
+                "xyz_encoding_1 must have a chunk per prologue stage");
+  constexpr bool PREFETCH_S = OBJ_PREFETCH_TILE && OBJ_PREFETCH_SCENE && POINTS && DO_SCENE && !DO_OBJ;
+  TilePrologue<VOXEL, POINTS> pre;
   if constexpr (FUSED) {
 #ifdef OBJ_ABL_PROLOGUE     // timing ablation only: no voxel gather
     pre.stage_a(a, tile_first, P, wave, lane);
@@ -1073,7 +1163,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
     Src src;
     src.half = half;
     if constexpr (FUSED) {
-      if constexpr (!PREFETCH) {
+      if constexpr (!PREFETCH && !PREFETCH_S) {
         if (tile != tile_first) {
 #ifdef OBJ_ABL_PROLOGUE
           pre.stage_a(a, tile, P, wave, lane);
@@ -1121,7 +1211,13 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       // xyz_encoding_1
       src.launder();
       load_bias<8>(acc, aux, L_S1, half);
-      { EmbOnly<Src> s{src}; layer_mac<8, NE>(acc, st, s); }
+      if constexpr (PREFETCH_S) {
+        EmbOnly<Src> s{src};
+        layer_mac<8, NE>(acc, st, s, PrefetchHook<VOXEL, POINTS>{pre, a, tile_next, P, wave, lane, half});
+      } else {
+        EmbOnly<Src> s{src};
+        layer_mac<8, NE>(acc, st, s);
+      }
       finish<8, true>(acc, h);
       // SAVE: a layer's output is written by the NEXT layer's after-barrier hook (see layer_mac); h is that layer's
       // input and stays live anyway

@@ -139,7 +139,10 @@ __global__ void sample_coarse4_kernel(const float* __restrict__ rays, const floa
 // ------------------------------------------------------------------------------------------
 // Embedding.forward (embedding_helper.py:57-74)
 // ------------------------------------------------------------------------------------------
-__global__ void pos_encode_kernel(const float* __restrict__ x, long n, int C, int F, float* __restrict__ out) {
+// freqs == nullptr: frequency bands 2^k (logscale=True, embedding_helper.py:52-53); else the F bands read from memory
+// (logscale=False: torch.linspace(1, 2^(F-1), F), embedding_helper.py:54-55) -- `freq * x` is one fp32 multiply either way
+__global__ void pos_encode_kernel(const float* __restrict__ x, long n, int C, int F, const float* __restrict__ freqs,
+                                  float* __restrict__ out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * C) return;
   const long row = idx / C;
@@ -149,7 +152,7 @@ __global__ void pos_encode_kernel(const float* __restrict__ x, long n, int C, in
   o[c] = v;
   float f = 1.f;
   for (int k = 0; k < F; ++k) {
-    const SinCos sc = psincos<true>(f * v);
+    const SinCos sc = psincos<true>((freqs ? freqs[k] : f) * v);
     o[C * (1 + 2 * k) + c] = sc.s;
     o[C * (2 + 2 * k) + c] = sc.c;
     f *= 2.f;
@@ -1037,10 +1040,13 @@ int objnerf_sample_coarse(const float* rays, const float* z_steps, const float* 
 }
 
 int objnerf_pos_encode(const float* x, int64_t n, int C, int n_freqs, float* out, void* stream) {
+  return objnerf_pos_encode_freqs(x, n, C, n_freqs, nullptr, out, stream);
+}
+int objnerf_pos_encode_freqs(const float* x, int64_t n, int C, int n_freqs, const float* freqs, float* out, void* stream) {
   if (!x || !out || C < 1 || n_freqs < 0) return set_error(-1, "pos_encode: bad arguments");
   if (n == 0) return 0;
   hipLaunchKernelGGL(pos_encode_kernel, dim3(blocks_for(n * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                     x, (long)n, C, n_freqs, out);
+                     x, (long)n, C, n_freqs, freqs, out);
   return check_launch("pos_encode");
 }
 

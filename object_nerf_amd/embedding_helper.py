@@ -27,13 +27,17 @@ class Embedding(nn.Module):
 
     def __init__(self, in_channels, N_freqs, logscale=True):
         super().__init__()
-        if not logscale:
-            raise NotImplementedError("object_nerf_amd.Embedding: only logscale=True (the reference default) is built")
+        self.logscale = bool(logscale)
         self.N_freqs = N_freqs
         self.in_channels = in_channels
         self.funcs = [torch.sin, torch.cos]
         self.out_channels = in_channels * (len(self.funcs) * N_freqs + 1)
-        self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)   # plain attribute, like the reference
+        # plain attribute, like the reference (embedding_helper.py:52-55)
+        if logscale:
+            self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)
+        else:
+            self.freq_bands = torch.linspace(1, 2 ** (N_freqs - 1), N_freqs)
+        self._bands_dev = None
 
     @_lib.on_device_of(lambda self, x: x)
     def forward(self, x):
@@ -44,8 +48,13 @@ class Embedding(nn.Module):
         c = shp[-1]
         xf = _lib.as_f32(x).reshape(-1, c)
         out = torch.empty(xf.shape[0], c * (2 * self.N_freqs + 1), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().objnerf_pos_encode(_lib.ptr(xf), xf.shape[0], c, self.N_freqs, _lib.ptr(out),
-                                                 _lib.stream_ptr()), "pos_encode")
+        bands = None
+        if not self.logscale:        # the bands travel as a device table; 2^k bands are generated in the kernel
+            if self._bands_dev is None or self._bands_dev.device != x.device:
+                self._bands_dev = self.freq_bands.to(torch.float32).to(x.device).contiguous()
+            bands = self._bands_dev
+        _lib.check(_lib.lib().objnerf_pos_encode_freqs(_lib.ptr(xf), xf.shape[0], c, self.N_freqs, _lib.ptr(bands), _lib.ptr(out),
+                                                       _lib.stream_ptr()), "pos_encode")
         return out.reshape(*shp[:-1], out.shape[-1])
 
 
@@ -160,7 +169,8 @@ class EmbeddingVoxel(nn.Module):
         _lib.require_cuda(xyz, "EmbeddingVoxel input")
         if torch.is_grad_enabled() and (xyz.requires_grad or self.embedding_space_ftr.weight.requires_grad):
             raise NotImplementedError(
-                "object_nerf_amd.EmbeddingVoxel is forward-only in this round; call under torch.no_grad()")
+                "object_nerf_amd.EmbeddingVoxel.forward is an inference entry point (the differentiable path is render_rays, "
+                "object_nerf_amd/autograd.py, which embeds inside the kernel); call it under torch.no_grad()")
         x = _lib.as_f32(xyz).reshape(-1, 3)
         n = x.shape[0]
         scene = torch.empty(n, 271, dtype=torch.float32, device=x.device)

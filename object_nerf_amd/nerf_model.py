@@ -241,8 +241,9 @@ class ObjectNeRF(nn.Module):
         if torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
                                         or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
-                "object_nerf_amd: the HIP path is forward-only in this round (backward = SURVEY §8 row f1). "
-                "Call under torch.no_grad(); there is deliberately no PyTorch fallback.")
+                "object_nerf_amd: ObjectNeRF.forward / forward_instance on pre-embedded inputs are inference entry points "
+                "(the differentiable path is render_rays, object_nerf_amd/autograd.py). Call them under torch.no_grad(); "
+                "there is deliberately no PyTorch fallback.")
 
     @_lib.on_device_of(lambda self, inputs, *a, **k: inputs["emb_xyz"])
     def _run(self, inputs, scene, sigma_only=False):
@@ -287,6 +288,69 @@ class ObjectNeRF(nn.Module):
             a.inst_sigma, a.inst_rgb = sig.data_ptr(), rgb.data_ptr()
         _lib.check(_lib.lib().objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval")
         return sig, rgb
+
+    # ---- density query on points / a lattice (tools/extract_mesh.py:63-113) in one enqueue -----------------
+    def query_sigma(self, embedding_xyz, xyz=None, lattice=None, obj_code=None):
+        """sigma at sample POINTS, embedded inside the kernel.
+
+        The reference's mesh tool walks its N^3 grid in chunks, per chunk `embedding_xyz(xyz)` ->
+        `forward({"emb_xyz", "obj_voxel"}, sigma_only=True)["sigma"]` (or `forward_instance(...)["inst_sigma"]` with the
+        code of `obj_id > 0`), tools/extract_mesh.py:80-111 -- 271 (+104) embedded floats per point written and read back.
+        Here the MLP kernel takes the points themselves (fused form, `objnerf_mlp_args.points / lat_*`), embeds them in
+        registers like the render path and stops after the density head: ONE enqueue for the whole grid, 4 bytes per point
+        of memory traffic.
+
+        embedding_xyz: the scene's `EmbeddingVoxel` (voxel mode) or `Embedding(3, 10)` (plain mode; only its type is used)
+        xyz:           (n, 3) points, or
+        lattice:       (x, y, z) 1-D axis tensors/arrays -> the points of `np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3)`
+                       in that order (extract_mesh.py:62-66) without building the coordinate array
+        obj_code:      None -> scene branch (`forward`); a (64,) / (1, 64) code -> object branch (`forward_instance`)
+        Returns (n, 1) like `forward(..., sigma_only=True)["sigma"]`."""
+        if (xyz is None) == (lattice is None):
+            raise ValueError("query_sigma: give either xyz or lattice=(x, y, z)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("object_nerf_amd: query_sigma is an inference entry point: call it under torch.no_grad()")
+        dev = self.sigma.weight.device
+        _lib.require_cuda(self.sigma.weight, "ObjectNeRF parameters")
+        with torch.cuda.device(dev):
+            blob, aux = self.packed()
+            a = _lib.MlpArgs()
+            a.use_voxel = int(self.use_voxel_embedding)
+            a.sigma_only = 1
+            a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
+            keep = []
+            if self.use_voxel_embedding:
+                if not hasattr(embedding_xyz, "grid_struct"):
+                    raise RuntimeError("query_sigma: a voxel-mode model needs the scene's EmbeddingVoxel")
+                a.grid = embedding_xyz.grid_struct()
+            if xyz is not None:
+                pts = _lib.as_f32(torch.as_tensor(xyz).reshape(-1, 3).to(dev))
+                n = pts.shape[0]
+                a.points = pts.data_ptr()
+                keep.append(pts)
+            else:
+                # torch.FloatTensor(np.float64 array) rounds to fp32 (extract_mesh.py:66): so do the axes
+                axes = [torch.as_tensor(v).reshape(-1).to(torch.float32).to(dev).contiguous() for v in lattice]
+                if len(axes) != 3 or any(v.numel() < 1 for v in axes):
+                    raise ValueError("query_sigma: lattice = (x, y, z), three non-empty 1-D axes")
+                a.lat_x, a.lat_y, a.lat_z = (v.data_ptr() for v in axes)
+                a.lat_n[0], a.lat_n[1], a.lat_n[2] = (v.numel() for v in axes)
+                n = axes[0].numel() * axes[1].numel() * axes[2].numel()
+                keep += axes
+            a.n_points = n
+            sig = torch.empty(n, 1, dtype=torch.float32, device=dev)
+            if n == 0:
+                return sig
+            if obj_code is None:
+                a.do_scene, a.sigma = 1, sig.data_ptr()
+            else:
+                code = _lib.as_f32(torch.as_tensor(obj_code).detach().reshape(-1).to(dev))
+                if code.numel() != 64:
+                    raise RuntimeError("query_sigma: obj_code must be ONE 64-d code (the script repeats one id over the chunk)")
+                a.do_object, a.codes, a.code_stride, a.inst_sigma = 1, code.data_ptr(), 0, sig.data_ptr()
+                keep.append(code)
+            _lib.check(_lib.lib().objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval(points, sigma_only)")
+        return sig
 
     def forward(self, inputs, sigma_only=False):
         sig, rgb = self._run(inputs, scene=True, sigma_only=sigma_only)

@@ -135,6 +135,39 @@ def frames(ref, scene):
         save(case, out)
 
 
+def sigma_grids(ref, scene):
+    """tools/extract_mesh.py:62-113 issued on a 32^3 lattice with the REAL reference modules (the script itself is a
+    __main__ with a checkpoint and mcubes; its query loop is the part restated here, line by line): nerf_fine's density
+    for the scene (obj_id 0) and for object 4, voxel and plain embedding."""
+    x, y, z = cases.sigma_grid_axes()
+    xyz_ = torch.FloatTensor(np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3))                  # :66
+    chunk = 32768                                                                                # default_conf.yml:41
+    out = {}
+    for sname in ("voxel", "plain"):
+        sc = scene(sname)
+        emb, fine, lib = sc.embeddings["xyz"], sc.models["fine"], sc.code_library
+        use_voxel = sname == "voxel"
+        for obj_id in (0, cases.SIGMA_GRID["obj_id"]):
+            chunks = []
+            for i in range(0, xyz_.shape[0], chunk):                                             # :80
+                obj_voxel_embedded = None
+                if use_voxel:
+                    xyz_embedded, obj_voxel_embedded = emb(xyz_[i:i + chunk])                    # :84-87
+                else:
+                    xyz_embedded = emb(xyz_[i:i + chunk])                                        # :88-91
+                input_dict = {"emb_xyz": xyz_embedded, "obj_voxel": obj_voxel_embedded}
+                if obj_id > 0:
+                    n_local = xyz_embedded.shape[0]
+                    input_dict["obj_code"] = lib.embedding_instance(torch.ones((n_local)).long() * obj_id)    # :99-101
+                    chunks.append(fine.forward_instance(input_dict, sigma_only=True)["inst_sigma"])      # :102-104
+                else:
+                    chunks.append(fine.forward(input_dict, sigma_only=True)["sigma"])                    # :106-108
+            sigma = torch.cat(chunks, 0)                                                         # :111
+            assert sigma.shape == (xyz_.shape[0], 1)
+            out["%s_obj%d" % (sname, obj_id)] = sigma[:, -1]                                     # :113
+    save("stage_sigma_grid", out)
+
+
 def main():
     torch.set_num_threads(8)
     ref = ref_import.load_reference()
@@ -150,9 +183,14 @@ def main():
         with torch.no_grad():
             frames(ref, scene)
         return
+    if "--sigma-grid" in sys.argv:   # only the density-grid query
+        with torch.no_grad():
+            sigma_grids(ref, scene)
+        return
 
     with torch.no_grad():
         frames(ref, scene)
+        sigma_grids(ref, scene)
         # ---- render_rays end to end ----
         for case, c in cases.RENDER_CASES.items():
             sc = scene(c["scene"])

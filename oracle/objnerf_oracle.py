@@ -205,6 +205,30 @@ def composite(z, sigma, rgb, inst_sigma=None, inst_rgb=None, noise=None, noise_i
 
 
 # ---------------------------------------------------------------------------------------------
+# density-grid query of the mesh tool
+# ---------------------------------------------------------------------------------------------
+def sigma_grid(params, grid, x, y, z, obj_code=None, chunk=32768):
+    """tools/extract_mesh.py:62-113: sigma of `nerf_fine` on the lattice np.meshgrid(x, y, z) (float64 axes rounded to fp32 by
+    torch.FloatTensor, :66), chunk by chunk: embedding_xyz -> forward(..., sigma_only=True) (:85-108), or forward_instance
+    with ONE repeated code when obj_id > 0 (:97-104).  grid None = plain positional encoding.  Returns (nx*ny*nz, 1)."""
+    import numpy as np
+    xyz_ = torch.FloatTensor(np.stack(np.meshgrid(np.asarray(x), np.asarray(y), np.asarray(z)), -1).reshape(-1, 3))   # :66
+    out = []
+    for i in range(0, xyz_.shape[0], chunk):                                                          # :80
+        p = xyz_[i:i + chunk]
+        if grid is not None:
+            e_xyz, e_obj = voxel_embed(p, grid)                                                       # :84-87
+        else:
+            e_xyz, e_obj = pos_encode(p, 10), None                                                    # :88-91
+        if obj_code is not None:
+            code = obj_code.reshape(1, -1).expand(p.shape[0], -1)                                     # :99-101
+            out.append(mlp_object(params, e_xyz, None, e_obj, code, sigma_only=True)[0])              # :102-104
+        else:
+            out.append(mlp_scene(params, e_xyz, None, sigma_only=True)[0])                            # :106-108
+    return torch.cat(out, 0)                                                                          # :111
+
+
+# ---------------------------------------------------------------------------------------------
 # render_rays
 # ---------------------------------------------------------------------------------------------
 def eval_points(params, grid, xyz, rays_d, codes, forward_instance=True, scene=True, chunk=32768):

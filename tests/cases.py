@@ -117,6 +117,18 @@ def mlp_inputs(use_voxel, n=200):
                 obj_voxel=torch.randn(n, 104, generator=g) if use_voxel else None, obj_code=torch.randn(n, 64, generator=g))
 
 
+# ---- density-grid query (tools/extract_mesh.py:53-66) ----------------------------------
+SIGMA_GRID = dict(N=32, x_range=(-1.3, 2.2), y_range=(-1.2, 2.1), z_range=(-0.3, 1.5), obj_id=4)
+
+
+def sigma_grid_axes(n=None):
+    """np.linspace axes as the script builds them (float64; the consumer rounds to fp32): a box around the synthetic room
+    (normalised x, y in [-1, 2], z in [0, 1.25]) that also reaches outside the voxel grid on every side"""
+    g = SIGMA_GRID
+    n = n or (g["N"],) * 3
+    return tuple(np.linspace(r[0], r[1], k) for r, k in zip((g["x_range"], g["y_range"], g["z_range"]), n))
+
+
 def pdf_inputs():
     g = torch.Generator().manual_seed(24)
     n, nb = 37, 63

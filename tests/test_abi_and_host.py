@@ -119,8 +119,8 @@ def test_module_types_and_state_dict_names():
 def test_unsupported_architecture_is_rejected():
     with pytest.raises(NotImplementedError):
         A.ObjectNeRF(A.default_model_config(W=128))
-    with pytest.raises(NotImplementedError):
-        A.Embedding(3, 4, logscale=False)
+    e = A.Embedding(3, 4, logscale=False)           # built (frequency table); only the fused renderer insists on 2^k bands
+    assert torch.equal(e.freq_bands, torch.linspace(1, 8, 4)) and e.out_channels == 27
 
 
 def test_no_silent_cpu_fallback():

@@ -95,6 +95,94 @@ def test_mlp_branches_match_reference(sname, mode, monkeypatch):
         check(a, g[k], 1e-5, "mlp/%s/%s" % (sname, k))
 
 
+@pytest.mark.parametrize("sname", ["voxel", "plain"])
+def test_sigma_query_matches_the_reference_mesh_tool(sname):
+    """SURVEY.md section 8 row f4 as ONE kernel: the density-grid query of tools/extract_mesh.py:62-113 on the 32^3 golden
+    lattice (scene, and object 4 with its code) -- points embedded inside the MLP kernel, nothing but sigma written --
+    against what the reference's embedding_xyz -> forward(sigma_only=True) chunk loop returned; and against the drop-in's
+    own memory form of the same loop (embedding materialised, then the sigma-only kernel)."""
+    g = cases.load_golden("stage_sigma_grid")
+    sc = scene(sname)
+    emb, fine = sc.embeddings["xyz"], sc.models["fine"]
+    oid = cases.SIGMA_GRID["obj_id"]
+    x, y, z = cases.sigma_grid_axes()
+    with torch.no_grad():
+        code = sc.code_library.embedding_instance.weight[oid]
+        s0 = fine.query_sigma(emb, lattice=(x, y, z))
+        s4 = fine.query_sigma(emb, lattice=(x, y, z), obj_code=code)
+        assert s0.shape == s4.shape == (32 ** 3, 1)
+        e0 = check(s0[:, 0], g["%s_obj0" % sname], 2e-5, "sigma query / scene / " + sname)
+        e4 = check(s4[:, 0], g["%s_obj%d" % (sname, oid)], 2e-5, "sigma query / object / " + sname)
+        print("sigma query %s: normwise error scene %.2e, object %.2e" % (sname, e0, e4))
+        # the explicit-points form of the same lattice: bit-equal (same kernel, same tile walk)
+        import numpy as np
+        pts = torch.FloatTensor(np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3)).to(DEV)
+        assert torch.equal(fine.query_sigma(emb, xyz=pts), s0)
+        assert torch.equal(fine.query_sigma(emb, xyz=pts, obj_code=code.view(1, 64)), s4)
+        # the script's own form on the drop-in types: embed, then the memory-form sigma-only kernel
+        if sname == "voxel":
+            ex, ov = emb(pts)
+            m0 = fine({"emb_xyz": ex, "obj_voxel": ov}, sigma_only=True)["sigma"]
+            m4 = fine.forward_instance({"emb_xyz": ex, "obj_voxel": ov, "obj_code": code.expand(pts.shape[0], 64).contiguous()},
+                                       sigma_only=True)["inst_sigma"]
+        else:
+            ex = emb(pts)
+            m0 = fine({"emb_xyz": ex}, sigma_only=True)["sigma"]
+            m4 = fine.forward_instance({"emb_xyz": ex, "obj_code": code.expand(pts.shape[0], 64).contiguous()}, sigma_only=True)["inst_sigma"]
+        check(s0, m0, 2e-5, "fused vs memory form / scene")
+        check(s4, m4, 2e-5, "fused vs memory form / object")
+
+
+def test_sigma_query_lattice_order_tails_and_errors():
+    """np.meshgrid's 'xy' order with nx != ny != nz, point counts that are not multiples of 128 (incl. 1 and 0), the oracle
+    on the same lattice, and the argument checks of the new form"""
+    sc = scene("voxel")
+    emb, fine = sc.embeddings["xyz"], sc.models["fine"]
+    import numpy as np
+    x, y, z = cases.sigma_grid_axes((7, 5, 11))
+    with torch.no_grad():
+        s = fine.query_sigma(emb, lattice=(x, y, z))
+        pts = torch.FloatTensor(np.stack(np.meshgrid(x, y, z), -1).reshape(-1, 3))
+        assert s.shape == (7 * 5 * 11, 1) and torch.equal(fine.query_sigma(emb, xyz=pts.to(DEV)), s)
+        ref = O.sigma_grid(H.state(fine), H.oracle_grid(emb), x, y, z)
+        check(s, ref, 2e-5, "7 x 5 x 11 lattice vs oracle")
+        for n in (1, 31, 129):
+            assert torch.equal(fine.query_sigma(emb, xyz=pts[:n].to(DEV)), s[:n])
+        assert fine.query_sigma(emb, xyz=pts[:0].to(DEV)).shape == (0, 1)
+        with pytest.raises(ValueError):
+            fine.query_sigma(emb)
+        with pytest.raises(RuntimeError, match="ONE 64-d code"):
+            fine.query_sigma(emb, xyz=pts.to(DEV), obj_code=torch.zeros(2, 64))
+    # the C ABI refuses inconsistent lattice sizes and two branches at once
+    a = _lib.MlpArgs()
+    blob, aux = fine.packed()
+    a.use_voxel, a.sigma_only, a.do_scene = 1, 1, 1
+    a.blob, a.aux, a.grid = blob.data_ptr(), aux.data_ptr(), emb.grid_struct()
+    ax = torch.zeros(4, device=DEV)
+    out = torch.zeros(64, device=DEV)
+    a.lat_x = a.lat_y = a.lat_z = ax.data_ptr()
+    a.lat_n[0], a.lat_n[1], a.lat_n[2] = 4, 4, 4
+    a.n_points, a.sigma = 63, out.data_ptr()
+    assert _lib.lib().objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()) != 0
+    assert b"lat_n" in _lib.lib().objnerf_last_error()
+    a.n_points, a.do_object, a.inst_sigma = 64, 1, out.data_ptr()
+    assert _lib.lib().objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()) != 0
+    assert b"one branch" in _lib.lib().objnerf_last_error()
+
+
+def test_embedding_with_linear_frequency_bands():
+    """Embedding(logscale=False): bands torch.linspace(1, 2^(F-1), F) (embedding_helper.py:54-55) against the formula"""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(300, 3, generator=g) * 4 - 2)
+    for nf in (4, 10):
+        e = A.Embedding(3, nf, logscale=False)
+        assert e.out_channels == 3 * (2 * nf + 1) and torch.equal(e.freq_bands, torch.linspace(1, 2 ** (nf - 1), nf))
+        with torch.no_grad():
+            got = e(x.to(DEV)).cpu()
+        want = torch.cat([x] + [f(fr * x) for fr in torch.linspace(1, 2 ** (nf - 1), nf) for f in (torch.sin, torch.cos)], -1)
+        assert got.shape == want.shape and (got - want).abs().max().item() < 2e-6
+
+
 def test_mlp_ragged_point_counts():
     """tile tails: point counts that are not multiples of 32 / 128, including 1"""
     m = scene("plain").models["coarse"]
