@@ -298,7 +298,12 @@ typedef struct {
   float* rgb_map;
   float* depth;
   float* const* h_own_weights;  /* may be NULL */
+  /* K*S samples of 28 bytes are staged per pixel: in LDS up to 152 KiB (K*S <= 5,558), beyond that in this device
+   * buffer of objnerf_composite_multi_scratch_bytes(K, S) bytes (0 when LDS suffices; may then be NULL).  The reference
+   * sorts any K*S (multi_rendering.py:112).  1 <= K <= 64. */
+  void* scratch;
 } objnerf_composite_multi_args;
+int64_t objnerf_composite_multi_scratch_bytes(int K, int S);
 int objnerf_composite_multi(const objnerf_composite_multi_args* args, void* stream);
 
 /* Ray generation for the editor: one kernel replaces get_ray_directions + get_rays

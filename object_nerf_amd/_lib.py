@@ -90,6 +90,7 @@ class CompositeMultiArgs(C.Structure):
         ("z_sorted", C.c_void_p), ("weights", C.c_void_p), ("obj_ids", C.c_void_p),
         ("opacity", C.c_void_p), ("rgb_map", C.c_void_p), ("depth", C.c_void_p),
         ("h_own_weights", C.POINTER(C.c_void_p)),
+        ("scratch", C.c_void_p),
     ]
 
 
@@ -189,6 +190,7 @@ SIGNATURES = {
     "objnerf_compact_rays": (C.c_int, [_VP, C.c_int64, C.c_int, _VP, _VP, _VP, _VP]),
     "objnerf_points_in_boxes": (C.c_int, [_VP, C.c_int64, _VP, C.c_int, _VP, _VP]),
     "objnerf_composite_multi": (C.c_int, [C.POINTER(CompositeMultiArgs), _VP]),
+    "objnerf_composite_multi_scratch_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "objnerf_generate_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, C.c_float, C.c_float, _VP, C.c_double, _VP, _VP]),
     "objnerf_generate_rays_rows": (C.c_int, [C.c_int, C.c_int, C.c_float, _VP, C.c_float, C.c_float, _VP, C.c_double,
                                              C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),

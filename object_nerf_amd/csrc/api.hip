@@ -433,7 +433,8 @@ int objnerf_render_rays(const objnerf_render_cfg* cfg, const objnerf_render_in* 
 
 // ---- whole render_rays_multi (render_tools/multi_rendering.py:160-325) in one enqueue ---------------------------
 // workspace per ray set k: zc (N*S) | zf (N*(S+I)) | sigma (N*Smax) | rgb (3*N*Smax) | own weights (N*S) | ray_index (N int32)
-// then: n_active (K int32, 256-byte slots) | compaction scratch
+// then: n_active (K int32, 256-byte slots) | compaction scratch | staging area of the joint compositing (only when K*(S+I)
+// samples of 28 bytes exceed its LDS limit)
 namespace {
 struct MultiWs {
   int64_t N; int S, I, Smax;
@@ -452,14 +453,17 @@ struct MultiWs {
   int32_t* idx(int k) const { return (int32_t*)(own(k) + N * S); }
   int32_t* count(int K, int k) const { return (int32_t*)((float*)base + set_floats() * K) + 64 * k; }
   int32_t* scratch(int K) const { return count(K, K); }
+  float* stage(int K) const { return (float*)(scratch(K) + (objnerf_compact_scratch_ints(N) + 63) / 64 * 64); }
 };
+constexpr int kMultiMaxSets = 64;
 }  // namespace
 
 int64_t objnerf_render_multi_workspace_bytes(const objnerf_render_multi_cfg* cfg, int32_t K, int64_t n_rays) {
   if (!cfg || K < 1 || n_rays < 0) return -1;
   const int I = cfg->N_importance > 0 ? cfg->N_importance : 0;
   MultiWs w{n_rays, cfg->N_samples, I, cfg->N_samples + I, nullptr, !cfg->no_hoist};
-  return 4 * (w.set_floats() * K + 64LL * K + objnerf_compact_scratch_ints(n_rays)) + 256;
+  return 4 * (w.set_floats() * K + 64LL * K + (objnerf_compact_scratch_ints(n_rays) + 63) / 64 * 64) +
+         objnerf_composite_multi_scratch_bytes(K, cfg->N_samples + I) + 256;
 }
 
 int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf_render_multi_in* in,
@@ -467,12 +471,13 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
   if (!cfg || !in || !coarse) return set_error(-1, "render_rays_multi: null argument");
   const int K = in->K, S = cfg->N_samples, I = cfg->N_importance > 0 ? cfg->N_importance : 0;
   const int64_t N = in->n_rays;
-  if (K < 1 || K > 16 || S < 1 || N < 0) return set_error(-1, "render_rays_multi: bad sizes (1 <= K <= 16)");
-  // limits of the stages further down the enqueue, checked BEFORE the first launch (the joint compositing stages
-  // K*(S+I) samples of 28 bytes in 64 KiB of LDS; the importance sampler needs S - 2 >= 1 interior bins)
-  if ((int64_t)K * (S + I) * 28 > 64 * 1024)
-    return set_error(-1, "render_rays_multi: K*(N_samples+N_importance) too large (28 bytes per sample must fit 64 KiB of LDS: K*(S+I) <= 2340)");
+  if (K < 1 || K > kMultiMaxSets || S < 1 || N < 0) return set_error(-1, "render_rays_multi: bad sizes (1 <= K <= 64)");
+  // limits of the stages further down the enqueue, checked BEFORE the first launch (the importance sampler needs
+  // S - 2 >= 1 interior bins and stages a ray's bins in LDS; the joint compositing has no sample limit: it stages in LDS up
+  // to K*(S+I) = 5,558 samples and in the workspace beyond)
   if (I > 0 && S < 3) return set_error(-1, "render_rays_multi: N_importance > 0 needs N_samples >= 3");
+  if (I > 0 && (S > 1025 || S + I > 2048))
+    return set_error(-1, "render_rays_multi: the importance sampler takes N_samples <= 1025 and N_samples + N_importance <= 2048 per ray set");
   if (N == 0) return 0;
   if (!in->h_rays || !in->h_obj_ids || !in->workspace || !in->blob_coarse || !in->aux_coarse || !in->z_steps)
     return set_error(-1, "render_rays_multi: missing input");
@@ -490,8 +495,8 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
 
   auto one_pass = [&](bool is_fine, const float* blob, const float* aux, const objnerf_render_multi_out* out) -> int {
     const int Sp = is_fine ? S + I : S;
-    const float *hz[16], *hs[16], *hr[16];
-    float* how[16];
+    const float *hz[kMultiMaxSets], *hs[kMultiMaxSets], *hr[kMultiMaxSets];
+    float* how[kMultiMaxSets];
     for (int k = 0; k < K; ++k) {
       float* z = is_fine ? w.zf(k) : w.zc(k);
       int rc;
@@ -541,6 +546,7 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
     c.z_sorted = out->z_vals; c.weights = out->weights; c.obj_ids = out->obj_ids;
     c.opacity = out->opacity; c.rgb_map = out->rgb; c.depth = out->depth;
     c.h_own_weights = (!is_fine && I > 0) ? how : nullptr;
+    c.scratch = objnerf_composite_multi_scratch_bytes(K, Sp) > 0 ? (void*)w.stage(K) : nullptr;
     return objnerf_composite_multi(&c, stream);
   };
 

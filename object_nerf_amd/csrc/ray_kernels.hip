@@ -7,6 +7,7 @@
 //
 // Compiled with -ffp-contract=off; see device_math.h.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <math.h>
 #include "layout.h"
 #include "device_math.h"
@@ -902,7 +903,12 @@ __global__ void __launch_bounds__(64) ray_bias_kernel(const RayBiasArgs a, const
 
 // volume_rendering_multi (multi_rendering.py:96-157): joint stable sort by z of K*S samples,
 // gather, composite with last delta 0.  One wave per ray, everything staged in LDS.
-constexpr int kMaxSets = 16;
+// Staging area per ray = 7 floats per sample (28 B): in LDS up to kMultiLdsMax bytes (M = K*S <= 5,558 samples; beyond the
+// default 64 KiB of dynamic LDS the launch raises the kernel's limit once), in a caller-provided global scratch beyond
+// that (GLOBAL: one slice per workgroup, L2-resident; the reference sorts any K*S, multi_rendering.py:96-157).
+constexpr int kMaxSets = 64;
+constexpr size_t kMultiLdsMax = 152 * 1024;
+constexpr unsigned kMultiGlobalGrid = 1024;      // workgroups (= scratch slices) of the global-staging variant
 struct MultiPtrs {
   const float* z[kMaxSets];
   const float* sigma[kMaxSets];
@@ -910,14 +916,16 @@ struct MultiPtrs {
   float* own_w[kMaxSets];
 };
 
+template <bool GLOBAL>
 __global__ void __launch_bounds__(64) composite_multi_kernel(const MultiPtrs ptrs, long n_rays, int K, int S,
                                                              const float* __restrict__ noise, float noise_std,
                                                              int white_back, float* __restrict__ z_sorted,
                                                              float* __restrict__ weights, float* __restrict__ obj_ids,
                                                              float* __restrict__ opacity, float* __restrict__ rgb_map,
-                                                             float* __restrict__ depth, int has_own) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+                                                             float* __restrict__ depth, int has_own, float* stage) {
+  extern __shared__ __attribute__((aligned(16))) float sm_lds[];
   const int M = K * S;
+  float* sm = GLOBAL ? stage + (size_t)blockIdx.x * 7 * M : sm_lds;
   float* zin = sm;            // M   unsorted z
   float* zs = sm + M;         // M   sorted z
   float* sgs = sm + 2 * M;    // M   sorted sigma
@@ -1239,13 +1247,21 @@ int objnerf_ray_box_near_far(const float* rays_o, const float* rays_d, int64_t n
   return check_launch("ray_box_near_far");
 }
 
+int64_t objnerf_composite_multi_scratch_bytes(int K, int S) {
+  if (K < 1 || S < 1) return -1;
+  const size_t stage = (size_t)K * S * 7 * sizeof(float);
+  return stage <= kMultiLdsMax ? 0 : (int64_t)(stage * kMultiGlobalGrid);
+}
+
 int objnerf_composite_multi(const objnerf_composite_multi_args* a, void* stream) {
   if (!a || a->K < 1 || a->K > kMaxSets || a->S < 1 || !a->h_z || !a->h_sigma || !a->h_rgb || !a->z_sorted ||
       !a->weights || !a->opacity || !a->rgb_map || !a->depth)
-    return set_error(-1, "composite_multi: bad arguments (1 <= K <= 16)");
+    return set_error(-1, "composite_multi: bad arguments (1 <= K <= 64)");
   const long M = (long)a->K * a->S;
   const size_t lds = (size_t)M * 7 * sizeof(float);
-  if (lds > 64 * 1024) return set_error(-1, "composite_multi: K*S too large (K*S*28 bytes must fit 64 KiB of LDS)");
+  const bool global = lds > kMultiLdsMax;
+  if (global && !a->scratch)
+    return set_error(-1, "composite_multi: K*S beyond the LDS staging limit needs `scratch` (objnerf_composite_multi_scratch_bytes)");
   if (a->noise_std != 0.f && !a->noise) return set_error(-1, "composite_multi: noise_std != 0 needs noise draws");
   if (a->n_rays == 0) return 0;
   MultiPtrs p;
@@ -1257,10 +1273,32 @@ int objnerf_composite_multi(const objnerf_composite_multi_args* a, void* stream)
     p.own_w[k] = (on && a->h_own_weights) ? a->h_own_weights[k] : nullptr;
     if (on && (!p.z[k] || !p.sigma[k] || !p.rgb[k])) return set_error(-1, "composite_multi: null set pointer");
   }
+  const float* noise = a->noise_std != 0.f ? a->noise : nullptr;
+  if (global) {
+    const unsigned grid = (unsigned)(a->n_rays < kMultiGlobalGrid ? a->n_rays : kMultiGlobalGrid);
+    hipLaunchKernelGGL(composite_multi_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, p, (long)a->n_rays,
+                       a->K, a->S, noise, a->noise_std, a->white_back, a->z_sorted, a->weights, a->obj_ids, a->opacity,
+                       a->rgb_map, a->depth, a->h_own_weights ? 1 : 0, (float*)a->scratch);
+    return check_launch("composite_multi(global staging)");
+  }
+  if (lds > 64 * 1024) {
+    // beyond the default dynamic-LDS limit: raise this kernel's limit (a host-side attribute; once per process and device)
+    static std::mutex mu;
+    static bool raised[64] = {false};
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+      if (hipFuncSetAttribute((const void*)composite_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kMultiLdsMax) != hipSuccess)
+        return set_error(-2, "composite_multi: could not raise the dynamic LDS limit");
+      raised[dev] = true;
+    }
+  }
   unsigned grid = (unsigned)(a->n_rays < 65536 ? a->n_rays : 65536);
-  hipLaunchKernelGGL(composite_multi_kernel, dim3(grid), dim3(64), lds, (hipStream_t)stream, p, (long)a->n_rays,
-                     a->K, a->S, a->noise_std != 0.f ? a->noise : nullptr, a->noise_std, a->white_back, a->z_sorted,
-                     a->weights, a->obj_ids, a->opacity, a->rgb_map, a->depth, a->h_own_weights ? 1 : 0);
+  hipLaunchKernelGGL(composite_multi_kernel<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p, (long)a->n_rays,
+                     a->K, a->S, noise, a->noise_std, a->white_back, a->z_sorted, a->weights, a->obj_ids, a->opacity,
+                     a->rgb_map, a->depth, a->h_own_weights ? 1 : 0, nullptr);
   return check_launch("composite_multi");
 }
 

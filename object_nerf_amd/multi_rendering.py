@@ -37,7 +37,10 @@ def render_rays_multi(
     chunk: int = 1024 * 32,
     white_back: bool = False,
     background_skip_bbox: Dict[str, Any] = None,
+    _randoms: Dict[str, Any] = None,
 ):
+    # _randoms: test hook (never set by the reference's callers) -- pre-drawn tensors of the training-mode paths,
+    # {"u_rand": K x (N, I) (or one (K, N, I) tensor), "noise": [(N, K*S), (N, K*(S+I))]}, instead of drawing them here
     assert len(rays_list) == len(obj_instance_ids)          # multi_rendering.py:179
     K = len(rays_list)
     l = _lib.lib()
@@ -74,10 +77,13 @@ def render_rays_multi(
             raise RuntimeError("render_rays_multi: object ids must index the (N_max_objs, 64) code table")
     elif any(i < 0 for i in ids):
         raise RuntimeError("render_rays_multi: negative object id")
-    # limits of the joint compositing kernel, raised before anything is enqueued (objnerf_render_rays_multi checks them too)
-    if K > 16 or K * (S + max(I, 0)) * 28 > 64 * 1024:
-        raise RuntimeError("render_rays_multi: %d ray sets x %d samples exceed the joint compositing limits "
-                           "(K <= 16, K * (N_samples + N_importance) <= 2340)" % (K, S + max(I, 0)))
+    # limits, raised before anything is enqueued (objnerf_render_rays_multi checks them too).  The joint compositing itself
+    # has no sample limit since round 4 (LDS staging up to K * (S + I) = 5,558, workspace staging beyond)
+    if K > 64:
+        raise RuntimeError("render_rays_multi: %d ray sets (at most 64 per call)" % K)
+    if I > 0 and (S < 3 or S > 1025 or S + I > 2048):
+        raise RuntimeError("render_rays_multi: the importance sampler takes 3 <= N_samples <= 1025 and N_samples + N_importance "
+                           "<= 2048 per ray set; got %d + %d" % (S, I))
 
     b3 = mfma_mode() == "bf16x3"
     cfg = _lib.RenderMultiCfg(use_voxel=int(use_voxel), N_samples=S, N_importance=I, use_disp=int(bool(use_disp)),
@@ -100,18 +106,25 @@ def render_rays_multi(
         rin.u_det = _linspace(I, dev).data_ptr()
         keep += [bf, af]
         if perturb != 0:                      # sample_pdf(det=False) draws torch.rand per set (rendering.py:40)
-            ur = torch.rand(K, n, I, device=dev)
+            if _randoms and "u_rand" in _randoms:
+                u = _randoms["u_rand"]
+                ur = _lib.as_f32(torch.stack([t.to(dev) for t in u]) if isinstance(u, (list, tuple)) else u.to(dev))
+                if tuple(ur.shape) != (K, n, I):
+                    raise RuntimeError("render_rays_multi: _randoms['u_rand'] must be (K, N, N_importance)")
+            else:
+                ur = torch.rand(K, n, I, device=dev)
             rin.u_rand = ur.data_ptr()
             keep.append(ur)
     if use_voxel:
         rin.grid = emb_xyz.grid_struct()
     rin.z_steps = _linspace(S, dev).data_ptr()
     if noise_std != 0:                        # multi_rendering.py:126: one randn per compositing
-        nzc = torch.randn(n, K * S, device=dev)
+        pre = _randoms.get("noise") if _randoms else None
+        nzc = _lib.as_f32(pre[0].to(dev)) if pre else torch.randn(n, K * S, device=dev)
         rin.noise_coarse = nzc.data_ptr()
         keep.append(nzc)
         if I > 0:
-            nzf = torch.randn(n, K * (S + I), device=dev)
+            nzf = _lib.as_f32(pre[1].to(dev)) if pre else torch.randn(n, K * (S + I), device=dev)
             rin.noise_fine = nzf.data_ptr()
             keep.append(nzf)
     if boxes is not None and boxes.shape[0] > 0:

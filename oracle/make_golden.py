@@ -135,6 +135,45 @@ def frames(ref, scene):
         save(case, out)
 
 
+def full_frame(ref, scene):
+    """BASELINE configs[1] at 640x480: all 307,200 rays of bench.py's ToyDesk-2 frame through the real reference (minutes of
+    CPU).  cases.FULL_FRAME describes what is kept."""
+    rays, ids, kw, sname = cases.full_frame_inputs()
+    sc = scene(sname)
+    out = {}
+    parts = {"rgb_fine": [], "depth_fine": []}
+    step = 32768
+    for lo in range(0, rays.shape[0], step):          # the callers' own ray-chunk loop (train.py:84-98)
+        r_ = rays[lo:lo + step]
+        codes = sc.code_library({"instance_ids": ids[lo:lo + step]})["embedding_instance"]
+        r = ref.render_rays(sc.models, sc.embeddings, r_, embedding_instance=codes, chunk=32768, **kw)
+        for k in parts:
+            parts[k].append(r[k])
+        print("full frame: %d / %d rays" % (min(lo + step, rays.shape[0]), rays.shape[0]), flush=True)
+    rgb = torch.cat(parts["rgb_fine"], 0)
+    assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
+    out["rgb_fine_u16"] = torch.round(rgb.double() * 65535.0).to(torch.int32).numpy().astype(np.uint16)
+    out["depth_fine_sub"] = torch.cat(parts["depth_fine"], 0)[:: cases.FULL_FRAME["sub"]]
+    out["_mean_rgb"] = rgb.double().mean()
+    save("full_frame_toydesk2", out)
+
+
+def multi_training_mode(ref, scene):
+    """render_rays_multi in training mode (perturb != 0, noise_std != 0; multi_rendering.py:186-190, 126, 272-274) with the
+    draws of cases.multi_randoms() injected in call order: randn_like (coarse compositing), rand x K (sample_pdf per set),
+    randn_like (fine compositing)."""
+    sc = scene("voxel")
+    sets, boxes = cases.multi_inputs()
+    m = cases.MULTI
+    rnd = cases.multi_randoms()
+    with ref_import.inject_randoms(rand=list(rnd["u_rand"]), randn_like=list(rnd["noise"])):
+        out = ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets], m["obj_ids"],
+                                    N_samples=m["N_samples"], N_importance=m["N_importance"], perturb=1.0, noise_std=1.0,
+                                    chunk=32768, white_back=False, background_skip_bbox={4: ref_import.make_box(boxes[0])})
+    assert not torch.equal(out["z_vals_fine"], cases.load_golden("multi_scannet_dup")["z_vals_fine"])
+    save("multi_train_random", dict(out))
+
+
 def sigma_grids(ref, scene):
     """tools/extract_mesh.py:62-113 issued on a 32^3 lattice with the REAL reference modules (the script itself is a
     __main__ with a checkpoint and mcubes; its query loop is the part restated here, line by line): nerf_fine's density
@@ -187,9 +226,18 @@ def main():
         with torch.no_grad():
             sigma_grids(ref, scene)
         return
+    if "--multi-train" in sys.argv:
+        with torch.no_grad():
+            multi_training_mode(ref, scene)
+        return
+    if "--full-frame" in sys.argv:   # only the 640x480 frame (about five minutes of CPU)
+        with torch.no_grad():
+            full_frame(ref, scene)
+        return
 
     with torch.no_grad():
         frames(ref, scene)
+        full_frame(ref, scene)
         sigma_grids(ref, scene)
         # ---- render_rays end to end ----
         for case, c in cases.RENDER_CASES.items():
@@ -262,6 +310,7 @@ def main():
                                     chunk=32768, white_back=False, background_skip_bbox=ref_boxes)
         assert not torch.equal(out["z_vals_fine"], cases.load_golden("multi_scannet_dup")["z_vals_fine"])    # the clip bites
         save("multi_scannet_clip10", dict(out))
+        multi_training_mode(ref, scene)
         # ---- bench.py --config 4: the editing demo's ray sets, generated by the reference's own ray / box code ----
         sc = scene("scannet_800k")
         bm = cases.BENCH_MULTI

@@ -379,7 +379,8 @@ def points_in_boxes(xyz, boxes):
 
 
 def composite_multi(z_list, rgb_list, sigma_list, noise_std=0.0, white_back=False, noise=None):
-    """volume_rendering_multi, multi_rendering.py:96-157 (stable joint sort; last delta 0)."""
+    """volume_rendering_multi, multi_rendering.py:96-157 (stable joint sort; last delta 0).  noise: the (N, K*S) draw of
+    `torch.randn_like(sigmas)` (:126) -- it meets the sigmas AFTER the sort, i.e. it is indexed by sorted position."""
     z = torch.cat(z_list, 1)
     rgb = torch.cat(rgb_list, 1)
     sg = torch.cat(sigma_list, 1)
@@ -400,9 +401,11 @@ def composite_multi(z_list, rgb_list, sigma_list, noise_std=0.0, white_back=Fals
 
 def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, obj_instance_ids, N_samples=64,
                       use_disp=False, perturb=0.0, noise_std=0.0, N_importance=0, white_back=False,
-                      skip_boxes=None, chunk=32768):
-    """render_rays_multi, multi_rendering.py:160-325 (eval mode: perturb == 0, noise_std == 0).
-    skip_boxes: list of box dicts for points_in_boxes, applied to the id-0 (background) ray set."""
+                      skip_boxes=None, chunk=32768, randoms=None):
+    """render_rays_multi, multi_rendering.py:160-325.  skip_boxes: list of box dicts for points_in_boxes, applied to the
+    id-0 (background) ray set.  Training-mode draws (perturb != 0: sample_pdf(det=False) draws torch.rand(N, I) once per
+    ray set, :272-274 -> rendering.py:40; noise_std != 0: one torch.randn_like per joint compositing, :126) are taken
+    from randoms = {"u_rand": [K x (N, I)], "noise": [(N, K*S), (N, K*(S+I))]} when given, else drawn here."""
     K = len(rays_list)
 
     def branch(params, rays, z, oid):
@@ -423,7 +426,11 @@ def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, o
     zs = [coarse_depths(r, N_samples, use_disp) for r in rays_list]
     cs, sgs = zip(*[branch(params_coarse, rays_list[i], zs[i], obj_instance_ids[i]) for i in range(K)])
     res = {}
-    r = composite_multi(list(zs), list(cs), list(sgs), noise_std, white_back)
+    rnd = randoms or {}
+    nz = rnd.get("noise", [None, None])
+    if noise_std != 0 and nz[0] is None:
+        nz = [torch.randn(rays_list[0].shape[0], K * N_samples), torch.randn(rays_list[0].shape[0], K * (N_samples + N_importance))]
+    r = composite_multi(list(zs), list(cs), list(sgs), noise_std, white_back, noise=nz[0])
     for k, v in r.items():
         res["%s_coarse" % k] = v
     if N_importance > 0:
@@ -432,7 +439,8 @@ def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, o
             n = rays_list[i].shape[0]
             w_own = res["weights_coarse"][res["obj_ids_coarse"] == i].view(n, N_samples)   # :269-271
             mid = 0.5 * (zs[i][:, :-1] + zs[i][:, 1:])
-            z_new = sample_pdf(mid, w_own[:, 1:-1].detach(), N_importance, det=(perturb == 0))
+            z_new = sample_pdf(mid, w_own[:, 1:-1].detach(), N_importance, det=(perturb == 0),
+                               u=rnd["u_rand"][i] if (perturb != 0 and "u_rand" in rnd) else None)
             z = torch.sort(torch.cat([zs[i], z_new], -1), -1)[0]
             if rays_list[i].shape[1] == 10:                               # :277-285 ray mask (e.g. bbox): clip z values
                 lo, hi = rays_list[i][:, 8:9], rays_list[i][:, 9:10]
@@ -440,7 +448,7 @@ def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, o
                 z = torch.where(inside, hi.expand_as(z), z)
             c, sg = branch(params_fine, rays_list[i], z, obj_instance_ids[i])
             zf.append(z); cf.append(c); sf.append(sg)
-        r = composite_multi(zf, cf, sf, noise_std, white_back)
+        r = composite_multi(zf, cf, sf, noise_std, white_back, noise=nz[1])
         for k, v in r.items():
             if k != "obj_ids":
                 res["%s_fine" % k] = v

@@ -174,6 +174,15 @@ def multi_inputs():
     return sets, [box]
 
 
+def multi_randoms():
+    """injected draws of the training-mode render_rays_multi golden: u of sample_pdf(det=False) per ray set
+    (multi_rendering.py:272-274 -> rendering.py:40) and the randn_like of each joint compositing (:126)"""
+    g = torch.Generator().manual_seed(31)
+    n, S, I, K = MULTI["n_rays"], MULTI["N_samples"], MULTI["N_importance"], len(MULTI["obj_ids"])
+    return dict(u_rand=[torch.rand(n, I, generator=g) for _ in range(K)],
+                noise=[torch.randn(n, K * S, generator=g), torch.randn(n, K * (S + I), generator=g)])
+
+
 def multi_inputs_clip():
     """the same ray sets with the two extra columns of the reference's 10-column variant (multi_rendering.py:277-285):
     object sets carry (bbox_mask_near, bbox_mask_far) strictly inside their (near, far); the background set stays (N, 8)"""
@@ -251,6 +260,20 @@ def frame_inputs(case):
         return rays, ids, kw, c["scene"]
     focal, poses, box = synth.edit_demo_geometry(synth.SCANNET_LIKE, w)
     return focal, poses, box, "scannet_800k"
+
+
+# ---- BASELINE configs[1] at its own size: the whole 640x480 ToyDesk-2 frame rendered by the reference (make_golden.full_frame).
+# Stored: rgb_fine of all 307,200 pixels as uint16 (x / 65535: quantisation rmse 4.4e-6 = 107 dB, far below the 74 dB the
+# renders differ by) and depth_fine of every FULL_FRAME["sub"]-th pixel in fp32.
+FULL_FRAME = dict(W=640, H=480, sub=16, render_case="bench_toydesk2")
+
+
+def full_frame_inputs():
+    c = RENDER_CASES[FULL_FRAME["render_case"]]
+    rays = synth.preset_rays(SCENES[c["scene"]][2], FULL_FRAME["W"], FULL_FRAME["H"])
+    n = rays.shape[0]
+    ids = torch.full((n,), int(c["ids"]), dtype=torch.long)
+    return rays, ids, dict(c["kw"], perturb=0, noise_std=0), c["scene"]
 
 
 def frame_multi_sets(gen, case="frame_edit_demo"):

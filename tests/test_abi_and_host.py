@@ -192,9 +192,17 @@ def test_c_abi_argument_validation():
     assert l.objnerf_sample_pdf_merge_clip(None, None, None, 0, 1, 64, 64, 1e-5, None, None, None, None) < 0
     mc = _lib.RenderMultiCfg(N_samples=64, N_importance=64, no_hoist=1)
     per_set = (1000 * (64 + 128 + 4 * 128 + 64) + 1000 + 15) // 16 * 16       # depths, sigma / rgb, own weights, ray index; 64-byte units
-    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * per_set + 64 * 3 + 2) + 256
+    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * per_set + 64 * 3 + 64) + 256
     mc = _lib.RenderMultiCfg(N_samples=64, N_importance=64)                    # + the per-ray vectors of each set (fp32 passes)
-    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * (per_set + (l.objnerf_ray_bias_floats(1000) + 15) // 16 * 16) + 64 * 3 + 2) + 256
+    assert l.objnerf_render_multi_workspace_bytes(C.byref(mc), 3, 1000) == 4 * (3 * (per_set + (l.objnerf_ray_bias_floats(1000) + 15) // 16 * 16) + 64 * 3 + 64) + 256
+    # the joint compositing stages K * (S + I) samples of 28 bytes: in LDS up to 152 KiB, in the workspace beyond (1024 slices)
+    assert l.objnerf_composite_multi_scratch_bytes(3, 128) == 0 and l.objnerf_composite_multi_scratch_bytes(20, 128) == 0
+    assert l.objnerf_composite_multi_scratch_bytes(3, 2000) == 1024 * 6000 * 28
+    big = _lib.RenderMultiCfg(N_samples=1000, N_importance=1000, no_hoist=1)
+    small = _lib.RenderMultiCfg(N_samples=64, N_importance=64, no_hoist=1)
+    grow = l.objnerf_render_multi_workspace_bytes(C.byref(big), 3, 8) - 1024 * 6000 * 28
+    assert 0 < grow < 4 * 3 * 8 * (1000 + 2000 + 4 * 2000 + 1000 + 1 + 16) + 4 * (64 * 3 + 64) + 256 + 64
+    assert l.objnerf_render_multi_workspace_bytes(C.byref(small), 3, 8) < grow
     rin, out = _lib.RenderMultiIn(), _lib.RenderMultiOut()
     rin.n_rays, rin.K = 8, 0
     assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0
@@ -202,12 +210,15 @@ def test_c_abi_argument_validation():
     rin.K = 2
     assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0
     assert b"missing input" in l.objnerf_last_error()
-    # round 3: the compositing kernel's LDS limit and the sampler's S >= 3 are checked BEFORE the first launch
-    big = _lib.RenderMultiCfg(N_samples=64, N_importance=128)
-    rin.K = 13                                                    # 13 x 192 x 28 B > 64 KiB
-    assert l.objnerf_render_rays_multi(C.byref(big), C.byref(rin), C.byref(out), None, None) < 0
-    assert b"too large" in l.objnerf_last_error()
+    # round 3: the limits of later stages are checked BEFORE the first launch.  Round 4: the joint compositing
+    # has no sample limit any more (13 x 192 samples no longer refused); K <= 64 and the sampler's per-set sizes remain
+    rin.K = 65
+    assert l.objnerf_render_rays_multi(C.byref(mc), C.byref(rin), C.byref(out), None, None) < 0
+    assert b"bad sizes" in l.objnerf_last_error()
     rin.K = 2
+    wide = _lib.RenderMultiCfg(N_samples=1500, N_importance=1000)
+    assert l.objnerf_render_rays_multi(C.byref(wide), C.byref(rin), C.byref(out), None, None) < 0
+    assert b"importance sampler" in l.objnerf_last_error()
     tiny = _lib.RenderMultiCfg(N_samples=2, N_importance=4)
     assert l.objnerf_render_rays_multi(C.byref(tiny), C.byref(rin), C.byref(out), None, None) < 0
     assert b"N_samples >= 3" in l.objnerf_last_error()

@@ -64,7 +64,8 @@ def test_reference_checkpoint_renders_multi_like_the_reference():
                               N_samples=m["N_samples"], N_importance=m["N_importance"], perturb=0, noise_std=0,
                               background_skip_bbox={4: boxes[0]})
     assert sorted(r) == sorted(g)
-    H.grade_multi(r, g, "checkpoint / multi")
+    f64 = H.oracle_multi_f64(sc, sets, m["obj_ids"], boxes=[boxes[0]], N_samples=m["N_samples"], N_importance=m["N_importance"])
+    H.grade_multi(r, g, "checkpoint / multi", f64, sets)
     assert H.psnr(r["rgb_fine"], g["rgb_fine"]) >= 60.0
 
 

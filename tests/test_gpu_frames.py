@@ -48,6 +48,36 @@ def test_frame_matches_reference_frame(case):
     assert rep["moved"] <= rep["moved64"] + max(1, rep["n_sub"] // 1000), (rep["moved"], rep["moved64"])
 
 
+def test_full_size_frame_matches_the_reference_frame():
+    """BASELINE configs[1] at its OWN size: the 640x480 ToyDesk-2 frame bench.py times (same scene, weights, camera, code)
+    against the same 307,200 pixels rendered by the real reference (tests/golden/full_frame_toydesk2.npz: rgb_fine as
+    uint16 / 65535 -- quantisation 107 dB --, depth_fine of every 16th pixel in fp32).  "PSNR within 0.1 dB of the
+    reference" (BASELINE north_star; utils/metrics.py:5-15), literally, at 640x480, in both arithmetic modes."""
+    g = cases.load_golden("full_frame_toydesk2")
+    rays, ids, kw, sname = cases.full_frame_inputs()
+    sc = scene(sname)
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": ids.to(DEV)})["embedding_instance"]
+        out = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, chunk=32768, **kw)
+    ref_rgb = torch.from_numpy(g["rgb_fine_u16"].numpy().astype(np.float64) / 65535.0)
+    assert ref_rgb.shape == (640 * 480, 3)
+    ours = out["rgb_fine"].cpu().double()
+    p = H.psnr(ours, ref_rgb)
+    # a fixed synthetic ground truth T (there are no images on the box): reference render + N(0, 0.05), clamped
+    target = (ref_rgb + 0.05 * torch.randn(ref_rgb.shape, generator=torch.Generator().manual_seed(7), dtype=torch.float64)).clamp(0, 1)
+    dp = abs(H.psnr(ours, target) - H.psnr(ref_rgb, target))
+    derr = H.normwise(out["depth_fine"][:: cases.FULL_FRAME["sub"]], g["depth_fine_sub"])
+    small = cases.load_golden("frame_toydesk2")            # the 160x120 frame of the same camera carries the fp64 floors
+    print("640x480 configs[1]: PSNR(ours, reference) %.1f dB, |dPSNR| vs a fixed target %.5f dB, depth_fine max-norm %.2e "
+          "(160x120 floor %.2e), mean rgb ours %.6f / reference %.6f" % (p, dp, derr, float(small["_floor_depth_fine"]),
+                                                                        float(ours.mean()), float(g["_mean_rgb"])))
+    assert p >= 70.0                                         # 160x120: 74 dB; the reference against its own float64: 68 dB
+    assert dp <= 0.1
+    assert derr <= max(H.FLOOR_FACTOR * float(small["_floor_depth_fine"]), 2e-5)
+    dl2 = H.rel_l2(out["depth_fine"][:: cases.FULL_FRAME["sub"]], g["depth_fine_sub"])
+    assert dl2 <= H.FLOOR_FACTOR * float(small["_floor_l2_depth_fine"]), dl2
+
+
 @pytest.mark.single_mode
 def test_edit_demo_frame_from_device_generated_rays():
     """the same configs[4] frame with the three ray sets written by objnerf_generate_rays (row f2) instead of the

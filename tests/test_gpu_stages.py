@@ -403,6 +403,45 @@ def test_mlp_eval_on_a_ray_subset(branch):
 
 
 @pytest.mark.single_mode
+@pytest.mark.parametrize("K,S,where", [(20, 128, "LDS beyond the default 64 KiB"), (3, 2100, "global staging"), (40, 150, "global staging, 40 sets")])
+def test_composite_multi_has_no_sample_limit(K, S, where):
+    """the reference sorts any K*S (multi_rendering.py:112); until round 3 the kernel refused K*S > 2340 and K > 16.  Now:
+    LDS staging up to 152 KiB (raised per-kernel limit), a scratch slice per workgroup beyond; up to 64 sets."""
+    g = torch.Generator().manual_seed(8)
+    n, M = 1100 if "global" in where else 9, K * S           # > 1024 rays: workgroups of the global variant take several rays
+    zs = [torch.sort(torch.rand(n, S, generator=g) * 3.0, -1)[0] for _ in range(K)]
+    zs[K - 1][::4] = 0.0
+    sg = [torch.randn(n, S, generator=g) * 3.0 for _ in range(K)]
+    cs = [torch.rand(n, S, 3, generator=g) for _ in range(K)]
+    ref = O.composite_multi([z.clone() for z in zs], cs, sg, noise_std=0.0, white_back=False)
+    dz, dsg, dcs = [z.to(DEV).contiguous() for z in zs], [t.to(DEV) for t in sg], [t.to(DEV) for t in cs]
+    out = {k: torch.empty(n, *sh, device=DEV) for k, sh in dict(z=(M,), w=(M,), ids=(M,), opacity=(), rgb=(3,), depth=()).items()}
+    own = [torch.empty(n, S, device=DEV) for _ in range(K)]
+    a = _lib.CompositeMultiArgs()
+    a.n_rays, a.K, a.S = n, K, S
+    arr = C.c_void_p * K
+    hz, hs, hr, ho = (arr(*[t.data_ptr() for t in ts]) for ts in (dz, dsg, dcs, own))
+    a.h_z, a.h_sigma, a.h_rgb, a.h_own_weights = hz, hs, hr, ho
+    a.z_sorted, a.weights, a.obj_ids = out["z"].data_ptr(), out["w"].data_ptr(), out["ids"].data_ptr()
+    a.opacity, a.rgb_map, a.depth = out["opacity"].data_ptr(), out["rgb"].data_ptr(), out["depth"].data_ptr()
+    nbytes = _lib.lib().objnerf_composite_multi_scratch_bytes(K, S)
+    assert (nbytes > 0) == ("global" in where)
+    if nbytes:
+        assert _lib.lib().objnerf_composite_multi(C.byref(a), _lib.stream_ptr()) != 0       # refused without its scratch
+        assert b"scratch" in _lib.lib().objnerf_last_error()
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        a.scratch = scratch.data_ptr()
+    _lib.check(_lib.lib().objnerf_composite_multi(C.byref(a), _lib.stream_ptr()), "composite_multi")
+    torch.cuda.synchronize()
+    nz = ref["z_vals"] != 0          # cross-set ties at z == 0: the oracle's stable sort and the kernel agree by construction
+    assert torch.equal(out["z"].cpu(), ref["z_vals"]) and torch.equal(out["ids"].cpu()[nz], ref["obj_ids"][nz])
+    for k, rk in (("w", "weights"), ("opacity", "opacity"), ("rgb", "rgb"), ("depth", "depth")):
+        check(out[k], ref[rk], 5e-5, "composite_multi %s / %s" % (where, rk))
+    for i in (0, K - 1):
+        check(own[i], ref["weights"][ref["obj_ids"] == i].view(n, S), 5e-5, "own weights %d" % i)
+
+
+@pytest.mark.single_mode
 @pytest.mark.parametrize("variant", ["ascending_with_ties", "one_set_descending", "noise_white"])
 def test_composite_multi_matches_oracle(variant):
     """objnerf_composite_multi (joint stable depth sort + compositing, multi_rendering.py:96-157) against the oracle:
