@@ -224,6 +224,15 @@ class Recorder:
 
 
     # ---- row f2: the device ray generation the shims `dropin/datasets/ray_utils.py`, `dropin/utils/bbox_utils.py` route to ----
+    def get_ray_directions(self, H, W, focal, device="cuda"):
+        """what `get_ray_directions(h, w, focal).cuda()` (editable_renderer.py:191, 215) reaches on the drop-in: the grid
+        WRITTEN on the device (dropin/datasets/ray_utils.py::HostDirections) -- here the oracle's grid, recorded"""
+        from oracle import objnerf_oracle as O
+        inspect.signature(self.product["get_ray_directions"]).bind(H, W, focal, device=device)
+        d = O.get_ray_directions(H, W, focal)
+        self.calls.append((self.scenario, "get_ray_directions", dict(H=int(H), W=int(W), focal=float(focal)), dict(out=d.clone())))
+        return d
+
     def get_rays(self, directions, c2w):
         from oracle import objnerf_oracle as O
         inspect.signature(self.product["get_rays"]).bind(directions, c2w)
@@ -284,8 +293,10 @@ def run_scenarios(flavour, work, rec):
         # ... "tensor is on the GPU" is always true for the stand-in device (as Tensor.cuda() is the identity here) ...
         DRU._on_device = DBU._on_device = lambda t: True
         # ... the product functions the shims call are the recording stand-in ...
-        rec.product = dict(get_rays=hip_rays.get_rays, ray_bbox_intersections=hip_bbox.ray_bbox_intersections)
+        rec.product = dict(get_rays=hip_rays.get_rays, ray_bbox_intersections=hip_bbox.ray_bbox_intersections,
+                           get_ray_directions=hip_rays.get_ray_directions)
         hip_rays.get_rays = rec.get_rays
+        hip_rays.get_ray_directions = rec.get_ray_directions
         hip_bbox.ray_bbox_intersections = rec.ray_bbox_intersections
 
         # ... and the host slab test must never run: datasets/geo_utils.py:111-162 raises from here on

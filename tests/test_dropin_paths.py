@@ -49,6 +49,20 @@ if os.path.isdir(ref):
     REFRU = sys.modules['datasets._reference_ray_utils']
     for a, b in zip(RU.get_rays(d, c2w), REFRU.get_rays(REFRU.get_ray_directions(6, 8, 7.0), c2w)):
         assert torch.equal(a, b)
+    # get_ray_directions: the reference's CPU grid for every CPU consumer, generated on the device when the editor moves it
+    # there (`get_ray_directions(h, w, focal).cuda()`, editable_renderer.py:191): no 3.7 MB host-to-device copy per frame
+    assert isinstance(d, torch.Tensor) and type(d).__name__ == 'HostDirections' and not d.is_cuda
+    assert torch.equal(d.as_subclass(torch.Tensor), REFRU.get_ray_directions(6, 8, 7.0)) and type(d * 2.0) is torch.Tensor
+    assert type(d.to(torch.float64)) is torch.Tensor and d.to(torch.float64).dtype == torch.float64
+    seen = []
+    import object_nerf_amd.ray_utils as HIPRU
+    real = HIPRU.get_ray_directions
+    HIPRU.get_ray_directions = lambda H, W, focal, device='cuda': seen.append((H, W, focal, str(device))) or 'device grid'
+    try:
+        assert d.to('cuda:0') == 'device grid' and d.to(device='cuda') == 'device grid'
+        assert seen == [(6, 8, 7.0, 'cuda:0'), (6, 8, 7.0, 'cuda')]
+    finally:
+        HIPRU.get_ray_directions = real
     from object_nerf_amd import synth
     h = ref_callers._box_helper(synth.oriented_box([2.9, 3.1, 0.5], [1.0, 0.8, 1.0], 20.0, [2.0, 2.0, 0.0], 2.0))
     assert type(h) is BU.BBoxRayHelper

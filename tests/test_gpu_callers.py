@@ -201,11 +201,18 @@ def test_editor_ray_generation_on_the_device(gold):
     ray sets the editor then assembled from them (editable_renderer.py:153-181) reproduce the recorded render inputs."""
     from object_nerf_amd import bbox, ray_utils
     calls = load_calls()
-    n_gr = n_rb = 0
+    n_gr = n_rb = n_dir = 0
     sets = {"render_edit": [], "render_origin": []}          # per scenario: [rays_o, rays_d, box result or None] per ray set
     for c in calls:
         t = c["tens"]
-        if c["fn"] == "get_rays":
+        if c["fn"] == "get_ray_directions":
+            # `get_ray_directions(h, w, focal).cuda()` (editable_renderer.py:191, 215): the shim's tensor type has the grid
+            # written on the device instead of copying the host grid -- bit-equal to the reference's CPU grid
+            k = c["scalars"]
+            d = ray_utils.get_ray_directions(k["H"], k["W"], k["focal"])
+            assert d.is_cuda and d.shape == t["out"].shape and torch.equal(d.cpu(), t["out"])
+            n_dir += 1
+        elif c["fn"] == "get_rays":
             o, d = ray_utils.get_rays(t["directions"].to(DEV), t["c2w"].to(DEV))
             assert o.shape == t["out_rays_o"].shape and torch.equal(o.cpu(), t["out_rays_o"])
             assert H.normwise(d, t["out_rays_d"]) < 2e-6
@@ -221,7 +228,7 @@ def test_editor_ray_generation_on_the_device(gold):
             assert torch.equal(t["rays_o"], cur[0].cpu())      # the call was made with the rays of the preceding get_rays
             cur[2] = (hit, near, far)
             n_rb += 1
-    assert n_gr == 4 and n_rb == 2              # three ray sets of the edit + one of render_origin; two object sets
+    assert n_gr == 4 and n_rb == 2 and n_dir == 2      # three ray sets of the edit + one of render_origin; two object sets; one grid per frame
     # editable_renderer.py:153-181 on the device results -> the (N, 8) ray sets of the recorded render_rays_multi calls
     multi = [c for c in calls if c["scenario"] == "render_edit" and c["fn"] == "render_rays_multi"]
     assert [r[2] is None for r in sets["render_edit"]] == [True, False, False] and len(sets["render_origin"]) == 1
