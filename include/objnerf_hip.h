@@ -526,6 +526,53 @@ int objnerf_sum_over_samples(const float* x, int64_t n_rays, int S, int C, float
 /* xyz[n, s, :] = rays_o + rays_d * z_vals[n, s]  (rendering.py:279), materialised for the training path */
 int objnerf_sample_points(const float* rays, const float* z_vals, int64_t n_rays, int S, float* xyz, void* stream);
 
+/* ---- any architecture `config.model` can describe (models/nerf_model.py:18-95) ----
+ * objnerf_mlp_eval's persistent kernel is specialised for the architecture of every shipped reference config (D 8, W 256,
+ * skips [4], inst_D 4, inst_W 128, inst_skips [2], 10 / 4 / 6 frequencies, 16 + 8 voxel channels, 64-d code).  Other shapes run
+ * layer by layer on the fp32 MFMA GEMM (bias / LeakyReLU / sigmoid epilogues, torch.cat inputs as column blocks), on the
+ * reference's own nn.Linear tensors (no packing), activations in a caller-provided workspace -- still no CPU / PyTorch path. */
+typedef struct {
+  int32_t D, W;                    /* scene branch: xyz_encoding_1..D (nerf_model.py:41-51) */
+  int32_t n_skips; int32_t skips[8];          /* layer indices i (0-based, as config.model.skips) whose input is cat([input, h]) */
+  int32_t inst_D, inst_W;          /* object branch: instance_encoding_1..inst_D (77-88) */
+  int32_t n_inst_skips; int32_t inst_skips[8];
+  int32_t in_xyz;                  /* columns of emb_xyz  (in_channels_xyz, 25-35) */
+  int32_t in_dir;                  /* columns of emb_dir  (in_channels_dir) */
+  int32_t obj_voxel_c;             /* columns of obj_voxel (0 without voxel embedding) */
+  int32_t code_c;                  /* columns of obj_code (N_obj_code_length) */
+} objnerf_arch;
+/* parameter table: HOST array of objnerf_arch_num_param_ptrs() DEVICE pointers, (weight, bias) pairs of
+ *   xyz_encoding_{1..D}.0, xyz_encoding_final, dir_encoding.0, sigma, rgb.0,
+ *   instance_encoding_{1..inst_D}.0, instance_encoding_final.0, inst_dir_encoding.0, instance_sigma, inst_rgb.0
+ * in nn.Linear (out, in) row-major layout */
+int objnerf_arch_num_param_ptrs(const objnerf_arch* arch);
+typedef struct {
+  objnerf_arch arch;
+  const float* const* h_params;
+  int32_t do_scene, do_object, sigma_only, _pad;
+  int64_t n_points;
+  const float* emb_xyz;            /* (P, in_xyz) */
+  const float* emb_dir;            /* (P, in_dir); may be NULL with sigma_only */
+  const float* obj_voxel;          /* (P, obj_voxel_c) */
+  const float* obj_code;           /* (P, code_c) */
+  float* sigma; float* rgb; float* inst_sigma; float* inst_rgb;       /* (P), (P,3), (P), (P,3) */
+  float* workspace;                /* objnerf_mlp_generic_workspace_floats() */
+} objnerf_mlp_generic_args;
+int64_t objnerf_mlp_generic_workspace_floats(const objnerf_arch* arch, int64_t n_points);
+int objnerf_mlp_generic(const objnerf_mlp_generic_args* args, void* stream);
+/* building blocks of the embeddings of such architectures:
+ *   objnerf_voxel_features   the trilinear sparse-voxel lookup of EmbeddingVoxel (embedding_helper.py:331-389) BEFORE the
+ *                            positional encoding, for a table of C channels per row: xyz (n,3) -> out (n, C), row stride ldo
+ *   objnerf_pos_encode_block Embedding.forward on a column block: x (n, C) with row stride ldx -> out (n, C*(2F+1)) with row
+ *                            stride ldo (each part of a torch.cat([...], -1) is written into its own columns); freqs NULL =
+ *                            bands 2^k, else n_freqs device floats (logscale=False)
+ *   objnerf_repeat_rows      out[r] = src[r / repeat]: a per-ray row (direction embedding, object code) repeated over the
+ *                            ray's samples (rendering.py:89-94) */
+int objnerf_voxel_features(const objnerf_voxel_grid* grid, int C, const float* xyz, int64_t n, float* out, int64_t ldo, void* stream);
+int objnerf_pos_encode_block(const float* x, int64_t ldx, int64_t n, int C, int n_freqs, const float* freqs, float* out,
+                             int64_t ldo, void* stream);
+int objnerf_repeat_rows(const float* src, int64_t lds, int64_t n_rows, int C, int repeat, float* out, int64_t ldo, void* stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of the MLP kernel on `stream` ---- */
 /* When enabled, objnerf_mlp_eval brackets its launch with hipEvents; objnerf_timing_read
  * synchronises those events and returns {launch count, total ms} since the last reset. */

@@ -54,6 +54,25 @@ class MlpArgs(C.Structure):
     ]
 
 
+class Arch(C.Structure):
+    _fields_ = [
+        ("D", C.c_int32), ("W", C.c_int32), ("n_skips", C.c_int32), ("skips", C.c_int32 * 8),
+        ("inst_D", C.c_int32), ("inst_W", C.c_int32), ("n_inst_skips", C.c_int32), ("inst_skips", C.c_int32 * 8),
+        ("in_xyz", C.c_int32), ("in_dir", C.c_int32), ("obj_voxel_c", C.c_int32), ("code_c", C.c_int32),
+    ]
+
+
+class MlpGenericArgs(C.Structure):
+    _fields_ = [
+        ("arch", Arch), ("h_params", C.POINTER(C.c_void_p)),
+        ("do_scene", C.c_int32), ("do_object", C.c_int32), ("sigma_only", C.c_int32), ("_pad", C.c_int32),
+        ("n_points", C.c_int64),
+        ("emb_xyz", C.c_void_p), ("emb_dir", C.c_void_p), ("obj_voxel", C.c_void_p), ("obj_code", C.c_void_p),
+        ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
+        ("workspace", C.c_void_p),
+    ]
+
+
 class CompositeArgs(C.Structure):
     _fields_ = [
         ("n_rays", C.c_int64), ("S", C.c_int32),
@@ -212,6 +231,12 @@ SIGNATURES = {
     "objnerf_voxel_embed_backward": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "objnerf_sum_over_samples": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
     "objnerf_sample_points": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, _VP, _VP]),
+    "objnerf_arch_num_param_ptrs": (C.c_int, [C.POINTER(Arch)]),
+    "objnerf_mlp_generic_workspace_floats": (C.c_int64, [C.POINTER(Arch), C.c_int64]),
+    "objnerf_mlp_generic": (C.c_int, [C.POINTER(MlpGenericArgs), _VP]),
+    "objnerf_voxel_features": (C.c_int, [C.POINTER(VoxelGrid), C.c_int, _VP, C.c_int64, _VP, C.c_int64, _VP]),
+    "objnerf_pos_encode_block": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP]),
+    "objnerf_repeat_rows": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, _VP, C.c_int64, _VP]),
     "objnerf_timing_enable": (C.c_int, [C.c_int]),
     "objnerf_timing_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

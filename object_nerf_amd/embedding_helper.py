@@ -93,8 +93,12 @@ def build_voxel_state(pcd_xyz_world, scene_center, scale_factor, voxel_size_worl
 class EmbeddingVoxel(nn.Module):
     def __init__(self, channels, N_freqs, max_voxels, dataset_extra_config):
         super().__init__()
-        if channels != 24 or N_freqs != 6:
-            raise NotImplementedError("object_nerf_amd.EmbeddingVoxel: kernel built for 16+8 channels, 6 frequencies")
+        if channels <= 8 or N_freqs < 0:
+            raise ValueError("EmbeddingVoxel: channels = scene channels + 8 object channels (instance_ftr_C, embedding_helper.py)")
+        # 16 + 8 channels with 6 frequencies is what the fused kernels embed in registers; other sizes are embedded by the
+        # generic kernels (objnerf_voxel_features + objnerf_pos_encode_block) and rendered on the layer-wise path
+        self.fused_layout = (channels == 24 and N_freqs == 6)
+        self.N_freqs = int(N_freqs)
         self.embedding_final = Embedding(channels, N_freqs)
         self.embedding_space_ftr = nn.Embedding(max_voxels, channels)
         self.set_pointclouds(dataset_extra_config)
@@ -173,9 +177,29 @@ class EmbeddingVoxel(nn.Module):
                 "object_nerf_amd/autograd.py, which embeds inside the kernel); call it under torch.no_grad()")
         x = _lib.as_f32(xyz).reshape(-1, 3)
         n = x.shape[0]
+        g = self.grid_struct()
+        if not self.fused_layout:
+            # any channel count / frequency count: raw trilinear features, then each positional encoding written straight
+            # into its column block of cat([PE(scene), PE10(xyz)]) and PE(object) (embedding_helper.py:325-329, 403-409)
+            l = _lib.lib()
+            C_, F = self.channels, self.N_freqs
+            cs, co = C_ - self.instance_ftr_C, self.instance_ftr_C
+            raw = torch.empty(n, C_, dtype=torch.float32, device=x.device)
+            scene = torch.empty(n, cs * (2 * F + 1) + 63, dtype=torch.float32, device=x.device)
+            obj = torch.empty(n, co * (2 * F + 1), dtype=torch.float32, device=x.device)
+            if n == 0:
+                return scene, obj
+            sp = _lib.stream_ptr()
+            _lib.check(l.objnerf_voxel_features(C.byref(g), C_, _lib.ptr(x), n, _lib.ptr(raw), C_, sp), "voxel_features")
+            _lib.check(l.objnerf_pos_encode_block(C.c_void_p(raw.data_ptr()), C_, n, cs, F, None, C.c_void_p(scene.data_ptr()),
+                                                  scene.shape[1], sp), "pos_encode_block")
+            _lib.check(l.objnerf_pos_encode_block(C.c_void_p(x.data_ptr()), 3, n, 3, 10, None,
+                                                  C.c_void_p(scene.data_ptr() + 4 * cs * (2 * F + 1)), scene.shape[1], sp), "pos_encode_block")
+            _lib.check(l.objnerf_pos_encode_block(C.c_void_p(raw.data_ptr() + 4 * cs), C_, n, co, F, None, C.c_void_p(obj.data_ptr()),
+                                                  obj.shape[1], sp), "pos_encode_block")
+            return scene, obj
         scene = torch.empty(n, 271, dtype=torch.float32, device=x.device)
         obj = torch.empty(n, 104, dtype=torch.float32, device=x.device)
-        g = self.grid_struct()
         _lib.check(_lib.lib().objnerf_voxel_embed(C.byref(g), _lib.ptr(x), n, _lib.ptr(scene), _lib.ptr(obj),
                                                   _lib.stream_ptr()), "voxel_embed")
         return scene, obj

@@ -73,8 +73,9 @@ def render_rays_multi(
         if w.device != dev:
             raise RuntimeError("render_rays_multi: the code library is on %s, the rays on %s" % (w.device, dev))
         table = _lib.as_f32(w)
-        if any(i < 0 or i >= table.shape[0] for i in ids) or table.shape[1] != 64:
-            raise RuntimeError("render_rays_multi: object ids must index the (N_max_objs, 64) code table")
+        code_c = int(getattr(coarse, "N_obj_code_length", 64))
+        if any(i < 0 or i >= table.shape[0] for i in ids) or table.shape[1] != code_c:
+            raise RuntimeError("render_rays_multi: object ids must index the (N_max_objs, %d) code table" % code_c)
     elif any(i < 0 for i in ids):
         raise RuntimeError("render_rays_multi: negative object id")
     # limits, raised before anything is enqueued (objnerf_render_rays_multi checks them too).  The joint compositing itself
@@ -84,6 +85,27 @@ def render_rays_multi(
     if I > 0 and (S < 3 or S > 1025 or S + I > 2048):
         raise RuntimeError("render_rays_multi: the importance sampler takes 3 <= N_samples <= 1025 and N_samples + N_importance "
                            "<= 2048 per ray set; got %d + %d" % (S, I))
+
+    from .rendering import fused_path_ok
+    if not fused_path_ok(models, embeddings, I > 0):
+        # any architecture other than the shipped default: the same pipeline stage by stage (object_nerf_amd/generic.py)
+        from . import generic
+        u_rand = noise = None
+        if I > 0 and perturb != 0:
+            u = _randoms["u_rand"] if (_randoms and "u_rand" in _randoms) else torch.rand(K, n, I, device=dev)
+            u_rand = [_lib.as_f32(t.to(dev)) for t in u]
+        if noise_std != 0:
+            pre = _randoms.get("noise") if _randoms else None
+            noise = [_lib.as_f32(pre[0].to(dev)) if pre else torch.randn(n, K * S, device=dev),
+                     (_lib.as_f32(pre[1].to(dev)) if pre else torch.randn(n, K * (S + I), device=dev)) if I > 0 else None]
+        oc, of = generic.render_rays_multi(models, embeddings, table, rays_c, clips, ids, S, I, use_disp, perturb, noise_std,
+                                           white_back, boxes, _linspace(S, dev), _linspace(I, dev) if I > 0 else None, u_rand, noise)
+        results = {"obj_ids_coarse": oc["obj_ids"], "weights_coarse": oc["weights"], "opacity_coarse": oc["opacity"],
+                   "z_vals_coarse": oc["z_vals"], "rgb_coarse": oc["rgb"], "depth_coarse": oc["depth"]}
+        if of is not None:
+            results.update({"weights_fine": of["weights"], "opacity_fine": of["opacity"], "z_vals_fine": of["z_vals"],
+                            "rgb_fine": of["rgb"], "depth_fine": of["depth"]})
+        return results
 
     b3 = mfma_mode() == "bf16x3"
     cfg = _lib.RenderMultiCfg(use_voxel=int(use_voxel), N_samples=S, N_importance=I, use_disp=int(bool(use_disp)),

@@ -11,9 +11,11 @@ Kept from the reference so checkpoints and callers interoperate
 
 Different by design: the module never multiplies anything in PyTorch.  Its parameters are
 gathered once per parameter version into the MFMA operand stream (`packed()`), and both forward
-methods enqueue the HIP kernel (csrc/mlp_kernel.h) on the current stream.  The kernel is
-specialised for the architecture every shipped reference config uses
-(config/default_conf.yml:7-36); other widths/depths are rejected loudly.
+methods enqueue the HIP kernel (csrc/mlp_kernel.h) on the current stream.  That persistent kernel is
+specialised for the architecture every shipped reference config uses (config/default_conf.yml:7-36);
+any other `config.model` shape (D, W, skips, inst_*, N_freq_*, voxel channels, code length) is built
+too and runs layer by layer on the fp32 MFMA GEMM (csrc/generic.hip, object_nerf_amd/generic.py):
+inference only, slower, still no PyTorch arithmetic.
 """
 import ctypes as C
 import os
@@ -93,17 +95,17 @@ class ObjectNeRF(nn.Module):
         self.in_channels_dir = 3 * (1 + 2 * self.N_freq_dir)
         self.inst_channel_in = self.in_channels_xyz + n_code + obj_vox
 
-        # the gfx950 kernel is built for exactly this architecture (csrc/layout.h)
+        self.N_obj_code_length = int(n_code)
+        # the persistent gfx950 kernel is built for exactly this architecture (csrc/layout.h); anything else takes the
+        # layer-wise path (csrc/generic.hip)
         expect = dict(D=8, W=256, skips=[4], inst_D=4, inst_W=128, inst_skips=[2], N_freq_xyz=10, N_freq_dir=4)
         got = dict(D=self.D, W=self.W, skips=self.skips, inst_D=self.inst_D, inst_W=self.inst_W,
                    inst_skips=self.inst_skips, N_freq_xyz=self.N_freq_xyz, N_freq_dir=self.N_freq_dir)
         want_xyz = 271 if self.use_voxel_embedding else 63
         want_obj = 439 if self.use_voxel_embedding else 127
-        if got != expect or self.in_channels_xyz != want_xyz or self.inst_channel_in != want_obj:
-            raise NotImplementedError(
-                "object_nerf_amd.ObjectNeRF: the HIP kernel is specialised for the reference's shipped "
-                "architecture %r with in_channels_xyz=%d, inst_channel_in=%d; got %r (%d, %d)"
-                % (expect, want_xyz, want_obj, got, self.in_channels_xyz, self.inst_channel_in))
+        self.fused_architecture = (got == expect and self.in_channels_xyz == want_xyz and self.inst_channel_in == want_obj)
+        if self.W % 2 or self.inst_W % 2 or self.D < 1 or self.inst_D < 1:
+            raise ValueError("ObjectNeRF: W and inst_W must be even (the colour layers are W // 2 wide), D and inst_D >= 1")
 
         self.activation = nn.LeakyReLU(inplace=True)
         # scene branch (same registration order as the reference so seeded inits coincide)
@@ -158,6 +160,9 @@ class ObjectNeRF(nn.Module):
         return key
 
     def _param_list(self):
+        if not self.fused_architecture:
+            raise RuntimeError("ObjectNeRF: the packed weight stream exists for the default architecture only (internal error: "
+                               "a non-default shape must take the layer-wise path, object_nerf_amd/generic.py)")
         mods = dict(self.named_modules())
         out = []
         for name in PARAM_LAYERS:
@@ -255,6 +260,13 @@ class ObjectNeRF(nn.Module):
         dev = emb_xyz.device
         if emb_xyz.shape[-1] != self.in_channels_xyz:
             raise RuntimeError("emb_xyz has %d channels, expected %d" % (emb_xyz.shape[-1], self.in_channels_xyz))
+        if not self.fused_architecture:      # any other config.model shape: layer by layer on the MFMA GEMM (csrc/generic.hip)
+            from . import generic
+            if emb_dir is None and not sigma_only:
+                raise RuntimeError("ObjectNeRF.forward: emb_dir is required unless sigma_only")
+            sg, c, isg, ic = generic.mlp(self, emb_xyz, emb_dir, inputs.get("obj_voxel"), inputs.get("obj_code"), scene, not scene,
+                                         sigma_only=sigma_only)
+            return (sg, c) if scene else (isg, ic)
         if emb_dir is None:   # sigma_only callers may omit it (tools/extract_mesh.py:85-108)
             emb_dir = torch.zeros(n, self.in_channels_dir, device=dev)
         # OBJNERF_MFMA=bf16x3: the split-bf16 arithmetic mode also for these stand-alone forwards (the density-only variant
@@ -312,6 +324,25 @@ class ObjectNeRF(nn.Module):
             raise NotImplementedError("object_nerf_amd: query_sigma is an inference entry point: call it under torch.no_grad()")
         dev = self.sigma.weight.device
         _lib.require_cuda(self.sigma.weight, "ObjectNeRF parameters")
+        if not self.fused_architecture:
+            # a non-default shape has no fused kernel: the script's own form (embed, then the density head) in chunks
+            if xyz is None:
+                ax = [torch.as_tensor(v).reshape(-1).to(torch.float32).to(dev) for v in lattice]
+                gx, gy, gz = torch.meshgrid(ax[0], ax[1], ax[2], indexing="ij")           # np.meshgrid 'xy': [j, i, k] = (x[i], y[j], z[k])
+                xyz = torch.stack([gx.permute(1, 0, 2), gy.permute(1, 0, 2), gz.permute(1, 0, 2)], -1).reshape(-1, 3)
+            pts = _lib.as_f32(torch.as_tensor(xyz).reshape(-1, 3).to(dev))
+            outs = []
+            code = None if obj_code is None else _lib.as_f32(torch.as_tensor(obj_code).detach().reshape(1, -1).to(dev))
+            for lo in range(0, pts.shape[0], 1 << 18):
+                e = embedding_xyz(pts[lo:lo + (1 << 18)].contiguous())
+                ex, ov = e if isinstance(e, tuple) else (e, None)
+                inp = {"emb_xyz": ex, "obj_voxel": ov}
+                if code is None:
+                    outs.append(self.forward(inp, sigma_only=True)["sigma"])
+                else:
+                    inp["obj_code"] = code.expand(ex.shape[0], -1).contiguous()
+                    outs.append(self.forward_instance(inp, sigma_only=True)["inst_sigma"])
+            return torch.cat(outs, 0) if outs else torch.empty(0, 1, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             blob, aux = self.packed()
             a = _lib.MlpArgs()

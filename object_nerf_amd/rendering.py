@@ -106,6 +106,22 @@ def hoist_enabled():
     return m == "1"
 
 
+def fused_path_ok(models, embeddings, fine):
+    """True when the persistent fused kernel can render this operator set: the default architecture (both models), 2^k
+    frequency bands with the default counts, and -- in voxel mode -- the 16 + 8 channel / 6 frequency table layout.
+    Everything else takes the layer-wise path (object_nerf_amd/generic.py)."""
+    ms = [models["coarse"]] + ([models["fine"]] if fine else [])
+    if not all(getattr(m, "fused_architecture", False) for m in ms):
+        return False
+    ex, ed = embeddings["xyz"], embeddings.get("dir")
+    if isinstance(ex, EmbeddingVoxel):
+        if not ex.fused_layout:
+            return False
+    elif not (isinstance(ex, Embedding) and ex.logscale and ex.N_freqs == 10 and ex.in_channels == 3):
+        return False
+    return isinstance(ed, Embedding) and ed.logscale and ed.N_freqs == 4 and ed.in_channels == 3
+
+
 def _train_packs(coarse, fine):
     mode = os.environ.get("OBJNERF_TRAIN_LAYERWISE", "")
     if mode == "1":
@@ -162,8 +178,40 @@ def render_rays(
     rays_c = _lib.as_f32(rays)
     if rays_c.shape[1] != 8:
         rays_c = rays_c[:, :8].contiguous()
-    if tuple(embedding_instance.shape) != (n, 64):
-        raise RuntimeError("embedding_instance must be (N_rays, 64), got %s" % (tuple(embedding_instance.shape),))
+    code_c = int(getattr(coarse, "N_obj_code_length", 64))
+    if tuple(embedding_instance.shape) != (n, code_c):
+        raise RuntimeError("embedding_instance must be (N_rays, %d), got %s" % (code_c, tuple(embedding_instance.shape)))
+
+    # ---- any architecture other than the shipped default: the same pipeline stage by stage (generic.py) ----
+    if not fused_path_ok(models, embeddings, I > 0):
+        if torch.is_grad_enabled() and (embedding_instance.requires_grad or any(p.requires_grad for m in models.values() for p in m.parameters())):
+            raise NotImplementedError(
+                "object_nerf_amd.render_rays: training (autograd) is built for the default architecture only "
+                "(config/default_conf.yml:7-36); a non-default config.model shape renders under torch.no_grad()")
+        from . import generic
+        rnd = dict(randoms) if randoms else {}
+        if perturb > 0:
+            rnd.setdefault("perturb_rand", torch.rand(n, S, device=dev))
+            if I > 0:
+                rnd.setdefault("u_rand", torch.rand(n, I, device=dev))
+        if noise_std != 0 and "noise" not in rnd:
+            rnd["noise"] = [torch.randn(n, S, device=dev), torch.randn(n, S, device=dev),
+                            torch.randn(n, S + I, device=dev), torch.randn(n, S + I, device=dev)]
+        rnd = {k: ([_lib.as_f32(t) for t in v] if isinstance(v, (list, tuple)) else _lib.as_f32(v)) for k, v in rnd.items()}
+        flags = dict(use_disp=bool(use_disp), perturb=float(perturb), noise_std=float(noise_std), white_back=bool(white_back),
+                     forward_instance=bool(forward_instance), is_eval=is_eval, use_zero_as_last_delta=use_zero_as_last_delta,
+                     frustum_bound_th=float(frustum_bound_th), rays_in_bbox=bool(rays_in_bbox),
+                     pass_through_mask=pass_through_mask.reshape(n).to(torch.uint8).contiguous() if pass_through_mask is not None else None)
+        oc, of = generic.render_rays(models, embeddings, rays_c, _lib.as_f32(embedding_instance.detach()), S, I, flags, rnd,
+                                     _linspace(S, dev), _linspace(I, dev) if I > 0 else None,
+                                     lambda n_, s_: _alloc_out(n_, s_, dev, forward_instance))
+        results = {}
+        for typ, o in (("coarse", oc), ("fine", of)):
+            if o is None:
+                continue
+            for k in ("weights", "opacity", "z_vals", "rgb", "depth") + (("rgb_instance", "depth_instance", "opacity_instance") if forward_instance else ()):
+                results["%s_%s" % (k, typ)] = o[k]
+        return results
 
     # ---- training: autograd is recording and something on the path wants a gradient -> differentiable path ----
     table = emb_xyz.embedding_space_ftr.weight if use_voxel else None

@@ -152,16 +152,21 @@ def per_ray_ids(n_rays, ids=(5, 4, 2, 1, 3), seed=0):
 
 
 def build_scene(types, use_voxel=True, preset=SCANNET_LIKE, max_voxels=800_000, n_points=200_000, device="cpu",
-                n_importance=64):
+                n_importance=64, model_overrides=None, logscale=True):
     """Builds {models, embeddings, code_library} with the given module types (a namespace offering
-    ObjectNeRF, Embedding, EmbeddingVoxel, CodeLibrary -- the drop-in package or the reference)."""
+    ObjectNeRF, Embedding, EmbeddingVoxel, CodeLibrary -- the drop-in package or the reference), the way train.py:40-65
+    derives them from config.model.  model_overrides: non-default config.model entries (D, W, skips, inst_*, N_freq_*,
+    N_scn_voxel_size, N_obj_code_length, ...); logscale=False: linearly spaced frequency bands (embedding_helper.py:54-55)."""
     cfg = default_model_config(use_voxel_embedding=use_voxel, N_max_voxels=max_voxels, N_importance=n_importance)
+    cfg.update(model_overrides or {})
+    lk = {} if logscale else {"logscale": False}
     if use_voxel:
-        emb_xyz = types.EmbeddingVoxel(24, 6, max_voxels, dataset_extra(preset, n_points))
+        emb_xyz = types.EmbeddingVoxel(cfg.N_scn_voxel_size + cfg.N_obj_voxel_size, cfg.N_freq_voxel, max_voxels,
+                                       dataset_extra(preset, n_points))
         fill_table(emb_xyz, 0)
     else:
-        emb_xyz = types.Embedding(3, 10)
-    emb_dir = types.Embedding(3, 4)
+        emb_xyz = types.Embedding(3, cfg.N_freq_xyz, **lk)
+    emb_dir = types.Embedding(3, cfg.N_freq_dir, **lk)
     coarse = fill_w1(types.ObjectNeRF(cfg), 1)
     fine = fill_w1(types.ObjectNeRF(cfg), 2)
     codes = fill_codes(types.CodeLibrary(cfg), 0)

@@ -174,6 +174,43 @@ def multi_training_mode(ref, scene):
     save("multi_train_random", dict(out))
 
 
+def other_architectures(ref, scene):
+    """config.model shapes other than the shipped default (cases.ARCH_SCENES) through the REAL reference: render_rays in
+    eval mode and with the training-time flags, render_rays_multi, and the two MLP forwards on materialised embeddings."""
+    for name in cases.ARCH_SCENES:
+        sc = scene(name)
+        rays, ids, ptm, sets, boxes = cases.arch_inputs(name)
+        ar = cases.ARCH_RENDER
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        out = {}
+        r = ref.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, chunk=32768, N_samples=ar["N_samples"],
+                            N_importance=ar["N_importance"], perturb=0, noise_std=0, is_eval=True)
+        out.update({"eval_" + k: v for k, v in r.items()})
+        r = ref.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, chunk=32768, N_samples=ar["N_samples"],
+                            N_importance=ar["N_importance"], perturb=0, noise_std=0, is_eval=False, frustum_bound_th=0.025,
+                            rays_in_bbox=True, white_back=True, pass_through_mask=ptm)
+        out.update({"flags_" + k: v for k, v in r.items()})
+        if cases.ARCH_SCENES[name][0]:      # the reference's render_rays_multi unpacks (scene, object) features: voxel mode only
+            r = ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets], cases.MULTI["obj_ids"],
+                                      N_samples=ar["N_samples"], N_importance=ar["N_importance"], perturb=0, noise_std=0, chunk=32768,
+                                      white_back=False, background_skip_bbox={4: ref_import.make_box(boxes[0])})
+            out.update({"multi_" + k: v for k, v in r.items()})
+        # the forwards on the embeddings of 150 points (ObjectNeRF.forward / forward_instance, sigma_only too)
+        pts = cases.voxel_points(150)
+        e = sc.embeddings["xyz"](pts.clone())
+        ex, ov = e if isinstance(e, tuple) else (e, None)
+        ed = sc.embeddings["dir"](torch.nn.functional.normalize(pts.flip(-1), dim=-1))
+        m = sc.models["fine"]
+        code = sc.code_library.embedding_instance(torch.full((pts.shape[0],), 3, dtype=torch.long))
+        o = m({"emb_xyz": ex, "emb_dir": ed})
+        oi = m.forward_instance({"emb_xyz": ex, "emb_dir": ed, "obj_voxel": ov, "obj_code": code})
+        out.update(fwd_emb_xyz=ex, fwd_emb_dir=ed, fwd_sigma=o["sigma"], fwd_rgb=o["rgb"], fwd_inst_sigma=oi["inst_sigma"],
+                   fwd_inst_rgb=oi["inst_rgb"])
+        if ov is not None:
+            out["fwd_obj_voxel"] = ov
+        save(name, out)
+
+
 def sigma_grids(ref, scene):
     """tools/extract_mesh.py:62-113 issued on a 32^3 lattice with the REAL reference modules (the script itself is a
     __main__ with a checkpoint and mcubes; its query loop is the part restated here, line by line): nerf_fine's density
@@ -226,9 +263,14 @@ def main():
         with torch.no_grad():
             sigma_grids(ref, scene)
         return
+    if "--arch" in sys.argv:         # only the non-default architectures
+        with torch.no_grad():
+            other_architectures(ref, scene)
+        return
     if "--multi-train" in sys.argv:
         with torch.no_grad():
             multi_training_mode(ref, scene)
+        other_architectures(ref, scene)
         return
     if "--full-frame" in sys.argv:   # only the 640x480 frame (about five minutes of CPU)
         with torch.no_grad():

@@ -31,9 +31,21 @@ LEAKY_SLOPE = 0.01      # nn.LeakyReLU() default, nerf_model.py:38
 # ---------------------------------------------------------------------------------------------
 # embeddings
 # ---------------------------------------------------------------------------------------------
-def pos_encode(x, n_freqs):
-    """Embedding.forward, embedding_helper.py:57-74: [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]"""
-    freqs = 2 ** torch.linspace(0, n_freqs - 1, n_freqs)
+# config.model entries the restatement is parameterised by (models/nerf_model.py:18-95; defaults = config/default_conf.yml:7-36);
+# `arch` arguments below are dicts holding any subset of these keys
+DEFAULT_ARCH = dict(D=8, skips=(4,), inst_D=4, inst_skips=(2,), n_freq_xyz=10, n_freq_dir=4, n_freq_voxel=6, logscale=True)
+
+
+def _arch(arch):
+    a = dict(DEFAULT_ARCH)
+    a.update(arch or {})
+    return a
+
+
+def pos_encode(x, n_freqs, logscale=True):
+    """Embedding.forward, embedding_helper.py:57-74: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...], bands 2^k or (logscale=False,
+    :54-55) torch.linspace(1, 2^(F-1), F)"""
+    freqs = 2 ** torch.linspace(0, n_freqs - 1, n_freqs) if logscale else torch.linspace(1, 2 ** (n_freqs - 1), n_freqs)
     out = [x]
     for f in freqs:
         out.append(torch.sin(f * x))
@@ -231,25 +243,27 @@ def sigma_grid(params, grid, x, y, z, obj_code=None, chunk=32768):
 # ---------------------------------------------------------------------------------------------
 # render_rays
 # ---------------------------------------------------------------------------------------------
-def eval_points(params, grid, xyz, rays_d, codes, forward_instance=True, scene=True, chunk=32768):
+def eval_points(params, grid, xyz, rays_d, codes, forward_instance=True, scene=True, chunk=32768, arch=None):
     """The MLP chunk loop of inference_model, rendering.py:86-137.  xyz (N,S,3); rays_d (N,3);
-    codes (N,64).  grid None = plain positional encoding."""
+    codes (N,64).  grid None = plain positional encoding.  arch: non-default config.model entries (DEFAULT_ARCH)."""
+    A = _arch(arch)
     n, s, _ = xyz.shape
     pts = xyz.reshape(-1, 3)
-    emb_dir = pos_encode(rays_d, 4).repeat_interleave(s, 0)
+    emb_dir = pos_encode(rays_d, A["n_freq_dir"], A["logscale"]).repeat_interleave(s, 0)
     code_rep = codes.repeat_interleave(s, 0) if codes is not None else None
     outs = [[], [], [], []]
     for i in range(0, pts.shape[0], chunk):
         p = pts[i:i + chunk]
         if grid is not None:
-            e_xyz, e_obj = voxel_embed(p, grid)
+            e_xyz, e_obj = voxel_embed(p, grid, n_freq_voxel=A["n_freq_voxel"])        # xyz: Embedding(3, 10) whatever the config (:84)
         else:
-            e_xyz, e_obj = pos_encode(p, 10), None
+            e_xyz, e_obj = pos_encode(p, A["n_freq_xyz"], A["logscale"]), None
         if scene:
-            sg, c = mlp_scene(params, e_xyz, emb_dir[i:i + chunk])
+            sg, c = mlp_scene(params, e_xyz, emb_dir[i:i + chunk], D=A["D"], skips=A["skips"])
             outs[0].append(sg); outs[1].append(c)
         if forward_instance:
-            sg, c = mlp_object(params, e_xyz, emb_dir[i:i + chunk], e_obj, code_rep[i:i + chunk])
+            sg, c = mlp_object(params, e_xyz, emb_dir[i:i + chunk], e_obj, code_rep[i:i + chunk], inst_D=A["inst_D"],
+                               inst_skips=A["inst_skips"])
             outs[2].append(sg); outs[3].append(c)
     sigma = torch.cat(outs[0], 0).view(n, s) if scene else None
     rgb = torch.cat(outs[1], 0).view(n, s, 3) if scene else None
@@ -261,8 +275,8 @@ def eval_points(params, grid, xyz, rays_d, codes, forward_instance=True, scene=T
 def render_rays(params_coarse, params_fine, grid, rays, N_samples=64, use_disp=False, perturb=0.0, noise_std=0.0,
                 N_importance=0, white_back=False, forward_instance=True, embedding_instance=None,
                 frustum_bound_th=0.0, pass_through_mask=None, rays_in_bbox=False, is_eval=False,
-                use_zero_as_last_delta=False, randoms=None, chunk=32768, z_fine_override=None):
-    """models/rendering.py:233-337.  randoms: optional {"perturb_rand","u_rand","noise":[4]}.
+                use_zero_as_last_delta=False, randoms=None, chunk=32768, z_fine_override=None, arch=None):
+    """models/rendering.py:233-337.  randoms: optional {"perturb_rand","u_rand","noise":[4]}.  arch: see DEFAULT_ARCH.
     z_fine_override: test hook -- evaluate the fine pass at these (N, S+I) depths instead of the sampled ones
     (teacher forcing; removes the importance sampler's fp32 sensitivity from gradient comparisons)."""
     o, d = rays[:, 0:3], rays[:, 3:6]
@@ -273,7 +287,7 @@ def render_rays(params_coarse, params_fine, grid, rays, N_samples=64, use_disp=F
 
     def one_pass(typ, params, z, nz, nz_i):
         xyz = o[:, None, :] + d[:, None, :] * z[..., None]              # :279 / :316
-        sg, c, isg, ic = eval_points(params, grid, xyz, d, embedding_instance, forward_instance, True, chunk)
+        sg, c, isg, ic = eval_points(params, grid, xyz, d, embedding_instance, forward_instance, True, chunk, arch)
         r = composite(z, sg, c, isg, ic, nz, nz_i, noise_std, white_back, use_zero_as_last_delta,
                       (not is_eval) and frustum_bound_th > 0, frustum_bound_th, pass_through_mask, rays_in_bbox)
         for k, v in r.items():
@@ -401,7 +415,7 @@ def composite_multi(z_list, rgb_list, sigma_list, noise_std=0.0, white_back=Fals
 
 def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, obj_instance_ids, N_samples=64,
                       use_disp=False, perturb=0.0, noise_std=0.0, N_importance=0, white_back=False,
-                      skip_boxes=None, chunk=32768, randoms=None):
+                      skip_boxes=None, chunk=32768, randoms=None, arch=None):
     """render_rays_multi, multi_rendering.py:160-325.  skip_boxes: list of box dicts for points_in_boxes, applied to the
     id-0 (background) ray set.  Training-mode draws (perturb != 0: sample_pdf(det=False) draws torch.rand(N, I) once per
     ray set, :272-274 -> rendering.py:40; noise_std != 0: one torch.randn_like per joint compositing, :126) are taken
@@ -414,9 +428,9 @@ def render_rays_multi(params_coarse, params_fine, grid, code_table, rays_list, o
         n = rays.shape[0]
         if oid > 0:   # object branch with that id's code (multi_rendering.py:45-51, 63-69)
             codes = code_table[oid][None].expand(n, -1)
-            _, _, sg, c = eval_points(params, grid, xyz, d, codes, True, False, chunk)
+            _, _, sg, c = eval_points(params, grid, xyz, d, codes, True, False, chunk, arch)
         else:
-            sg, c, _, _ = eval_points(params, grid, xyz, d, None, False, True, chunk)
+            sg, c, _, _ = eval_points(params, grid, xyz, d, None, False, True, chunk, arch)
         sg = sg.clone()
         sg[z[:, -1] == 0] = -1e5                                          # :40,83,92
         if oid == 0 and skip_boxes:

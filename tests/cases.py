@@ -24,6 +24,18 @@ SCENES = {"voxel": (True, 200_000), "plain": (False, 0), "sparse": (True, 1500),
           "toydesk2_800k": (True, 200_000, synth.TOYDESK2, 800_000),
           "scannet_800k": (True, 200_000, synth.SCANNET_LIKE, 800_000)}
 
+# architectures OTHER than the shipped default (models/nerf_model.py:18-95 builds any of them; the product renders them on
+# its layer-wise path, object_nerf_amd/generic.py): name -> (use_voxel, n_points, config.model overrides, logscale)
+ARCH_SCENES = {
+    # narrower / shallower, skips elsewhere, fewer frequencies with LINEAR bands, a 32-d code
+    "arch_plain_small": (False, 0, dict(D=6, W=128, skips=[3], inst_D=3, inst_W=64, inst_skips=[1], N_freq_xyz=8, N_freq_dir=3,
+                                        N_obj_code_length=32), False),
+    # voxel mode with 12 + 8 feature channels and 4 voxel frequencies, no skip in the object branch, two skips in the scene one
+    "arch_voxel_odd": (True, 200_000, dict(D=5, W=192, skips=[2, 4], inst_D=2, inst_W=96, inst_skips=[], N_scn_voxel_size=12,
+                                           N_freq_voxel=4, N_freq_dir=5), True),
+}
+ARCH_RENDER = dict(N_samples=24, N_importance=40, n_rays=20)
+
 # render_rays cases: scene, kwargs for render_rays, extras
 RENDER_CASES = {
     # BASELINE configs[1]-like: scene + object, 64+64, eval
@@ -61,9 +73,34 @@ RENDER_CASES = {
 
 
 def scene_for(types, name, device="cpu"):
+    if name in ARCH_SCENES:
+        use_voxel, n_points, over, logscale = ARCH_SCENES[name]
+        return synth.build_scene(types, use_voxel, preset=synth.SCANNET_LIKE, max_voxels=MAX_VOXELS, n_points=max(n_points, 1),
+                                 device=device, model_overrides=over, logscale=logscale)
     use_voxel, n_points = SCENES[name][:2]
     preset, max_voxels = (SCENES[name][2], SCENES[name][3]) if len(SCENES[name]) > 2 else (synth.SCANNET_LIKE, MAX_VOXELS)
     return synth.build_scene(types, use_voxel, preset=preset, max_voxels=max_voxels, n_points=max(n_points, 1), device=device)
+
+
+def oracle_arch(name):
+    """the oracle's `arch` dict (oracle.objnerf_oracle.DEFAULT_ARCH keys) of an ARCH_SCENES entry"""
+    _, _, over, logscale = ARCH_SCENES[name]
+    m = {"D": "D", "skips": "skips", "inst_D": "inst_D", "inst_skips": "inst_skips", "N_freq_xyz": "n_freq_xyz",
+         "N_freq_dir": "n_freq_dir", "N_freq_voxel": "n_freq_voxel"}
+    a = {m[k]: (tuple(v) if isinstance(v, list) else v) for k, v in over.items() if k in m}
+    a["logscale"] = logscale
+    return a
+
+
+def arch_inputs(name):
+    """rays, per-ray ids, pass-through mask and the multi ray sets / box of the non-default-architecture goldens"""
+    n = ARCH_RENDER["n_rays"]
+    rays_all = synth.camera_rays(64, 48, far=3.0)
+    rays = rays_all[torch.arange(0, rays_all.shape[0], 149)[:n]].contiguous()
+    ids = synth.per_ray_ids(n, seed=5)
+    ptm = (torch.arange(n) % 4 == 0).view(n, 1)
+    sets, boxes = multi_inputs()
+    return rays, ids, ptm, [s_[:n].contiguous() for s_ in sets], boxes
 
 
 def render_inputs(case):

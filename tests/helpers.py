@@ -208,7 +208,7 @@ def frame_report(case, out, g):
 FLOOR_FACTOR = 3.0      # end-to-end fine-pass tolerance in units of the reference's own fp32-vs-fp64 distance: BOTH arithmetic modes
 
 
-def oracle_multi_f64(sc, sets, obj_ids, boxes=None, randoms=None, **kw):
+def oracle_multi_f64(sc, sets, obj_ids, boxes=None, randoms=None, arch=None, **kw):
     """oracle.render_rays_multi in float64 on the same inputs (the reference's arithmetic carried out exactly enough):
     its distance from the reference's fp32 result is the yardstick of the fine-pass keys"""
     from oracle import objnerf_oracle as O
@@ -223,7 +223,7 @@ def oracle_multi_f64(sc, sets, obj_ids, boxes=None, randoms=None, **kw):
             return O.render_rays_multi(dbl(state(sc.models["coarse"])), dbl(state(sc.models["fine"])),
                                        dbl(oracle_grid(sc.embeddings["xyz"])),
                                        sc.code_library.embedding_instance.weight.detach().cpu().double(),
-                                       [s.detach().cpu().double() for s in sets], list(obj_ids), skip_boxes=boxes, randoms=rnd, **kw)
+                                       [s.detach().cpu().double() for s in sets], list(obj_ids), skip_boxes=boxes, randoms=rnd, arch=arch, **kw)
     finally:
         torch.set_default_dtype(old)
 
@@ -269,7 +269,7 @@ def grade_multi(r, g, what, f64=None, sets=None, n_samples=64):
     print(what, "; ".join(report))
 
 
-def oracle_f64(sc, use_voxel, rays, codes, ptm, randoms, kw):
+def oracle_f64(sc, use_voxel, rays, codes, ptm, randoms, kw, arch=None):
     """the oracle in float64 on the same inputs -> fp32-vs-fp64 noise floor per key"""
     from oracle import objnerf_oracle as O
     old = torch.get_default_dtype()
@@ -283,6 +283,6 @@ def oracle_f64(sc, use_voxel, rays, codes, ptm, randoms, kw):
                        noise=[t.double() for t in randoms["noise"]])
         with torch.no_grad():
             return O.render_rays(dbl(state(sc.models["coarse"])), dbl(state(sc.models["fine"])), grid, rays.double(),
-                                 embedding_instance=codes.double(), pass_through_mask=ptm, randoms=rnd, **kw)
+                                 embedding_instance=codes.double(), pass_through_mask=ptm, randoms=rnd, arch=arch, **kw)
     finally:
         torch.set_default_dtype(old)

@@ -116,9 +116,28 @@ def test_module_types_and_state_dict_names():
     assert sum(p.numel() for p in plain.parameters()) == 704_840
 
 
-def test_unsupported_architecture_is_rejected():
-    with pytest.raises(NotImplementedError):
-        A.ObjectNeRF(A.default_model_config(W=128))
+def test_other_architectures_are_built_like_the_reference_builds_them():
+    """models/nerf_model.py:18-95 builds any config.model shape; so does the drop-in (round 3 raised for anything but the
+    shipped default).  Non-default shapes are flagged for the layer-wise path; parameter names and shapes follow the config."""
+    assert A.ObjectNeRF(A.default_model_config()).fused_architecture
+    m = A.ObjectNeRF(A.default_model_config(W=128, D=6, skips=[3], inst_D=3, inst_W=64, inst_skips=[1], N_freq_xyz=8,
+                                            N_freq_dir=3, N_obj_code_length=32, use_voxel_embedding=False))
+    assert not m.fused_architecture and m.in_channels_xyz == 51 and m.in_channels_dir == 21 and m.inst_channel_in == 83
+    sd = m.state_dict()
+    assert sd["xyz_encoding_4.0.weight"].shape == (128, 128 + 51) and sd["xyz_encoding_6.0.weight"].shape == (128, 128)
+    assert "xyz_encoding_7.0.weight" not in sd and sd["instance_encoding_2.0.weight"].shape == (64, 64 + 83)
+    assert sd["dir_encoding.0.weight"].shape == (64, 128 + 21) and sd["inst_rgb.0.weight"].shape == (3, 32)
+    from object_nerf_amd import generic
+    a = generic.arch_of(m)
+    assert (a.D, a.W, a.n_skips, a.skips[0], a.inst_D, a.inst_W, a.inst_skips[0], a.in_xyz, a.in_dir, a.obj_voxel_c, a.code_c) == \
+        (6, 128, 1, 3, 3, 64, 1, 51, 21, 0, 32)
+    l = _lib.lib()
+    assert l.objnerf_arch_num_param_ptrs(C.byref(a)) == 2 * (6 + 4) + 2 * (3 + 4)
+    assert l.objnerf_mlp_generic_workspace_floats(C.byref(a), 1000) == 1000 * (2 * 128 + 128 + 64)
+    a.W = 127
+    assert l.objnerf_mlp_generic_workspace_floats(C.byref(a), 1000) < 0 and b"architecture" in l.objnerf_last_error()
+    with pytest.raises(ValueError):
+        A.ObjectNeRF(A.default_model_config(W=255))
     e = A.Embedding(3, 4, logscale=False)           # built (frequency table); only the fused renderer insists on 2^k bands
     assert torch.equal(e.freq_bands, torch.linspace(1, 8, 4)) and e.out_channels == 27
 
