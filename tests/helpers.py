@@ -244,10 +244,11 @@ def grade_multi(r, g, what, f64=None, sets=None, n_samples=64):
             assert torch.equal(r[k].cpu()[nz], g[k][nz])
             continue
         err = normwise(r[k], g[k])
-        if k.endswith("coarse"):
-            assert err <= 1e-4, "%s/%s %.3e" % (what, k, err)
-            continue
         floor = normwise(g[k], f64[k])
+        if k.endswith("coarse"):      # the BASELINE contract's 1e-4, or the reference's own floor where that is larger (a sample
+            # on a face of the removed object's box flips between its sigma and -1e5 within fp32 roundoff, multi_rendering.py:239-241)
+            assert err <= max(1e-4, FLOOR_FACTOR * floor), "%s/%s %.3e (fp64 floor %.3e)" % (what, k, err, floor)
+            continue
         tol = max(FLOOR_FACTOR * floor, 2e-5)
         report.append("%s %.1e (floor %.1e)" % (k, err, floor))
         assert err <= tol, "%s/%s: normwise %.3e > %.1f x fp64 floor %.3e" % (what, k, err, FLOOR_FACTOR, floor)

@@ -28,7 +28,7 @@ trace() {   # trace NAME CMD...: kernel trace + per-kernel table (rocpd database
 for step in "$@"; do
   arg=${step#*:}; [ "$arg" == "$step" ] && arg=""
   case ${step%%:*} in
-    tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -x -q -m gpu -k "$arg" > $O/gpu_tests_k.txt 2>&1; echo "gpu tests -k '$arg' rc=$?"; tail -3 $O/gpu_tests_k.txt
+    tests) if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -x -q -rP -m gpu -k "$arg" > $O/gpu_tests_k.txt 2>&1; echo "gpu tests -k '$arg' rc=$?"; tail -3 $O/gpu_tests_k.txt
            else timeout 1500 python -m pytest tests -x -q -m gpu > $O/gpu_tests.txt 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_tests.txt; fi ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.txt ;;
     bench) timeout 900 python bench.py --steps 20 --warmup 5 ${arg:+--config $arg} > $O/bench${arg:+_c$arg}.json 2> $O/bench${arg:+_c$arg}.err; echo "bench $arg rc=$?"; tail -1 $O/bench${arg:+_c$arg}.json | cut -c1-400 ;;
