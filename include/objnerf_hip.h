@@ -38,7 +38,8 @@ typedef struct {
 } objnerf_voxel_grid;
 
 /* ---- packed MLP weights of one models/nerf_model.py::ObjectNeRF ---- */
-/* sizes (in floats) of the weight stream and the aux (bias + heads) block */
+/* sizes (in floats) of the weight stream and the aux block (biases + heads, then the hoisted weight columns of
+ * objnerf_ray_bias as a compact matrix) */
 int64_t objnerf_blob_floats(int use_voxel);
 int64_t objnerf_aux_floats(void);
 /* number of parameter tensors the packer consumes, and their canonical order:
@@ -182,9 +183,10 @@ typedef struct {
   int32_t lat_n[3];
 } objnerf_mlp_args;
 #define OBJNERF_RAY_BIAS_FLOATS 448
-/* out: objnerf_ray_bias_floats(n_rays) floats -- the (n_rays, OBJNERF_RAY_BIAS_FLOATS) vectors for
- * objnerf_mlp_args.ray_bias, followed by the call's own scratch (the hoisted weight columns as a compact matrix).
- * Uses blob, aux, mfma_bf16x3, rays, codes / code_stride, n_rays, use_voxel, do_scene, do_object of `args`. */
+/* out: objnerf_ray_bias_floats(n_rays) = n_rays * OBJNERF_RAY_BIAS_FLOATS floats -- the vectors for
+ * objnerf_mlp_args.ray_bias.  Uses aux (the hoisted weight columns sit behind the aux block as a compact matrix, gathered by
+ * objnerf_pack_weights), rays, codes / code_stride, n_rays, use_voxel, do_scene, do_object of `args`, and its ray subset
+ * (ray_index / n_active) when given: only the listed rays' vectors are written. */
 int64_t objnerf_ray_bias_floats(int64_t n_rays);
 int objnerf_ray_bias(const objnerf_mlp_args* args, float* out, void* stream);
 #define OBJNERF_SEG_REC_FLOATS 16

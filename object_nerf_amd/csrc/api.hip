@@ -73,7 +73,7 @@ int objnerf_abi_version(void) { return OBJNERF_ABI_VERSION; }
 const char* objnerf_last_error(void) { return g_err; }
 
 int64_t objnerf_blob_floats(int use_voxel) { return (int64_t)total_chunks(use_voxel != 0) * kChunkFloats; }
-int64_t objnerf_aux_floats(void) { return kAuxFloats; }
+int64_t objnerf_aux_floats(void) { return kAuxFloats + kRbMatFloats; }
 int objnerf_num_param_ptrs(void) { return kNumParamPtrs; }
 int64_t objnerf_param_numel(int use_voxel, int ptr_id) {
   if (ptr_id < 0 || ptr_id >= kNumParamPtrs) return -1;
@@ -86,7 +86,7 @@ int objnerf_pack_index(int use_voxel, uint32_t* blob_idx, uint32_t* aux_idx) {
   const bool vox = use_voxel != 0;
   const long nblob = objnerf_blob_floats(use_voxel);
   for (long i = 0; i < nblob; ++i) blob_idx[i] = kPackZero;
-  for (int i = 0; i < kAuxFloats; ++i) aux_idx[i] = kPackZero;
+  for (int i = 0; i < kAuxFloats + kRbMatFloats; ++i) aux_idx[i] = kPackZero;      // the tail is written by the packer itself
 
   for (int l = 0; l < L_COUNT; ++l) {
     const int nt = layer_nt(l), kg = kChunkTiles / nt, ks_n = layer_ks(vox, l);

@@ -218,6 +218,11 @@ constexpr uint32_t kPackZero = 0xFFFFFFFFu;   // index-map entry meaning "0.0f"
 // per-ray vectors of the hoisted terms (mlp_kernel HOIST, ray_bias_kernel): [O1 128 | O3 128 | SD 128 | OD 64] in the
 // aux-bias layout of each layer
 constexpr int kRayBiasFloats = 448;
+// the weight columns those vectors are made from, as a compact matrix wm[group][c][16] + bias[group][16] (group = 16
+// consecutive floats of the per-ray vector, c = input column: 64 code / 27 direction columns): gathered ONCE per parameter
+// version by objnerf_pack_weights and kept behind the aux block (objnerf_aux_floats() = kAuxFloats + kRbMatFloats)
+constexpr int kRbGroups = kRayBiasFloats / 16;                  // 28: O1 8 | O3 8 | SD 8 | OD 4
+constexpr int kRbMatFloats = kRbGroups * 64 * 16 + kRbGroups * 16;
 
 // ---- split-bf16 weight stream (OBJNERF_MFMA=bf16x3, fused inference kernel) --------------------------
 // fp32 products on the bf16 matrix pipe: w = w_hi + w_mid + w_lo with three 8-bit-mantissa pieces (truncation splits

@@ -797,6 +797,7 @@ struct RayBiasArgs {
   long code_stride, n_rays;
   int use_voxel, do_scene, do_object;
   float* out;
+  const int32_t* ray_index; const int32_t* n_active;      // optional ray subset (objnerf_mlp_args): only the listed rays are computed
 };
 __device__ __forceinline__ float blob_weight(const float* blob, bool vox, int l, int ks, int half, int row) {
   const int nt = layer_nt(l), kg = kChunkTiles / nt;
@@ -817,8 +818,6 @@ __device__ __forceinline__ float blob_weight_b3(const void* blob, bool vox, int 
 // Step 1 (one workgroup per input column): the hoisted weight columns as a compact matrix wm[group][c][16] + bias[group][16], group = 16
 // consecutive floats of the per-ray vector (one (layer, out tile, lane half) of the MLP kernel's D layout), c = input
 // column (64 code columns or 27 direction columns) -- read from the packed stream by the packer's own layout arithmetic.
-constexpr int kRbGroups = kRayBiasFloats / 16;                  // 28: O1 8 | O3 8 | SD 8 | OD 4
-constexpr int kRbMatFloats = kRbGroups * 64 * 16 + kRbGroups * 16;
 template <bool B3>
 __global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs a, float* __restrict__ wm) {
   const int o = threadIdx.x;                  // position in the per-ray vector
@@ -848,8 +847,9 @@ __global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs
 // the 28 groups in 7 parts (blockIdx.y): a 1,024-ray chunk of the editor still spreads over 112 workgroups.
 constexpr int kRbParts = 7;                                     // 28 groups of 16 outputs in 7 parts of 4 (blockIdx.y)
 __global__ void __launch_bounds__(64) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ wm) {
-  const long ray = (long)blockIdx.x * 64 + threadIdx.x;
-  if (ray >= a.n_rays) return;
+  const long slot = (long)blockIdx.x * 64 + threadIdx.x;
+  if (slot >= (a.n_active ? (long)*a.n_active : a.n_rays)) return;
+  const long ray = a.ray_index ? (long)a.ray_index[slot] : slot;      // vectors stay indexed by the ray's own number
   const int g0 = blockIdx.y * (kRbGroups / kRbParts);
   float x[64], pe[28];
   if (a.do_object) {
@@ -1177,17 +1177,21 @@ int objnerf_composite_finish(const float* seg_records, int64_t n_rays, int S, in
   return check_launch("composite_finish");
 }
 
-int64_t objnerf_ray_bias_floats(int64_t n_rays) { return n_rays < 0 ? -1 : n_rays * kRayBiasFloats + kRbMatFloats; }
+int64_t objnerf_ray_bias_floats(int64_t n_rays) { return n_rays < 0 ? -1 : n_rays * kRayBiasFloats; }
 
+// One launch: the compact matrix of the hoisted weight columns was gathered when the weights were packed (it sits behind the
+// aux block, objnerf_pack_weights) -- round 3 re-gathered it on every call, per ray set, pass and slab.  With a ray subset
+// (objnerf_mlp_args.ray_index / n_active: render_rays_multi's culled object sets keep a fifth of the frame or less) only the
+// listed rays are computed.
 int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   if (!m || !out || !m->blob || !m->aux || !m->rays || m->n_rays < 0) return set_error(-1, "ray_bias: bad arguments");
   if (m->do_object && !m->codes) return set_error(-1, "ray_bias: the object branch needs codes");
+  if ((m->ray_index == nullptr) != (m->n_active == nullptr)) return set_error(-1, "ray_bias: ray_index and n_active go together");
   if (m->n_rays == 0) return 0;
-  RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out};
-  float* wm = out + m->n_rays * kRayBiasFloats;          // the compact weight matrix lives behind the vectors
-  if (m->mfma_bf16x3) hipLaunchKernelGGL(ray_bias_weights_kernel<true>, dim3(64), dim3(448), 0, (hipStream_t)stream, a, wm);   // blob = the split-bf16 stream
-  else hipLaunchKernelGGL(ray_bias_weights_kernel<false>, dim3(64), dim3(448), 0, (hipStream_t)stream, a, wm);
-  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 63) / 64), kRbParts), dim3(64), 0, (hipStream_t)stream, a, (const float*)wm);
+  RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out,
+                m->ray_index, m->n_active};
+  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 63) / 64), kRbParts), dim3(64), 0, (hipStream_t)stream, a,
+                     m->aux + kAuxFloats);
   return check_launch("ray_bias");
 }
 
@@ -1313,6 +1317,10 @@ int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t
   const long nb = objnerf_blob_floats(use_voxel), na = objnerf_aux_floats();
   hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, pp, blob);
   hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(na, 256)), dim3(256), 0, (hipStream_t)stream, aux_idx, na, pp, aux);
+  // behind the aux block: the hoisted weight columns as the compact matrix objnerf_ray_bias reads (once per parameter
+  // version instead of once per call; the split-bf16 stream holds the same values, so the matrix serves both modes)
+  RayBiasArgs a{blob, aux, nullptr, nullptr, 0, 0, use_voxel, 1, 1, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(ray_bias_weights_kernel<false>, dim3(64), dim3(448), 0, (hipStream_t)stream, a, aux + kAuxFloats);
   return check_launch("pack_weights");
 }
 
