@@ -491,6 +491,9 @@ typedef struct {
   int32_t mfma_bf16x3;
 } objnerf_train_args;
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points);
+/* scratch of objnerf_mlp_train_backward: the gradients w.r.t. every layer's pre-activation output (12.9 KB per point) + the
+ * partial tiles of the grouped weight-gradient pass (64 tiles x ~P/1640 slices x 66 KB: 1.0 GB at the reference batch of
+ * 393,216 points) + the head kernels' partial sums */
 int64_t objnerf_train_scratch_floats(int64_t n_points);
 int objnerf_mlp_train_forward(const objnerf_train_args* args, void* stream);
 /* Backward of the call above (same args, outputs and workspace untouched in between).

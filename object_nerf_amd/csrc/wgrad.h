@@ -33,7 +33,11 @@ struct WgTile {                // one output tile: rows [128 by, +128), columns 
 constexpr int kWgradMaxSlices = 256;                   // k slices per tile (fewer and longer ones beyond that)
 constexpr int kWgradSliceIters = 64;                  // k iterations (of 32 points) per slice
 constexpr int kWgradMaxProducts = 32;
-constexpr int kWgradMaxTiles = 96;
+constexpr int kWgradMaxTiles = 96;                    // capacity of the tile list (kernel argument)
+// tiles the partial-tile scratch is sized for: the model's 28 products make 63 tiles of 128 x 128 with both branches in voxel
+// mode (47 without the object branch, fewer in plain-PE mode) -- round 3 sized the slot area for all 96 list entries (1.5 GB at
+// the reference batch); a pass with more tiles than this is refused by WgradBatch::launch
+constexpr int kWgradSlotTiles = 64;
 constexpr long kWgradSlotFloats = 128 * 128 + 128;    // a partial tile + its partial row sums
 struct WgradArgs {             // passed by value (2.5 KB of kernel arguments: no device-side list to copy)
   WgProduct prod[kWgradMaxProducts];
@@ -67,7 +71,7 @@ constexpr long kWgradListFloats = 1024;               // device copy of the Wgra
 // number of k slices of every tile (host): kWgradSliceIters k iterations each (OBJNERF_WGRAD_KITERS overrides: tuning),
 // at most kWgradMaxSlices
 int wgrad_slices(long P);
-inline long wgrad_slot_floats(long P) { return (long)kWgradMaxTiles * wgrad_slices(P) * kWgradSlotFloats; }
+inline long wgrad_slot_floats(long P) { return (long)kWgradSlotTiles * wgrad_slices(P) * kWgradSlotFloats; }
 inline long wgrad_scratch_floats(long P) {
   return wgrad_slot_floats(P) + (long)kMaxHeads * ((P + kHeadChunk - 1) / kHeadChunk) * kHeadSlotFloats + kWgradListFloats;
 }

@@ -669,6 +669,7 @@ void WgradBatch::add_head(const float* dY, int no, const float* X, long ldx, int
 }
 int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
   if (overflow) return set_error(-3, "wgrad: work list overflow");
+  if (a.ntile > kWgradSlotTiles) return set_error(-3, "wgrad: more output tiles than the scratch is sized for (kWgradSlotTiles)");
   if (P <= 0) return 0;
   a.P = P;
   a.partials = scratch;

@@ -20,7 +20,7 @@ def test_state_dict_round_trip(sname):
     buf = io.BytesIO()
     torch.save({"state_dict": sd, "epoch": 3}, buf)       # what a Lightning .ckpt holds
     buf.seek(0)
-    sc2 = checkpoint.build_from_state_dict(torch.load(buf))
+    sc2 = checkpoint.build_from_state_dict(torch.load(buf, weights_only=True))
     sd2 = checkpoint.export_state_dict(sc2)
     assert list(sd) == list(sd2)
     for k in sd:
@@ -42,7 +42,7 @@ def test_reference_written_checkpoint_fixture_loads_and_the_oracle_reproduces_th
     import os
     import helpers as H
     from oracle import objnerf_oracle as O
-    ckpt = torch.load(os.path.join(cases.GOLDEN_DIR, "reference_small.ckpt"), map_location="cpu")
+    ckpt = torch.load(os.path.join(cases.GOLDEN_DIR, "reference_small.ckpt"), map_location="cpu", weights_only=True)
     sd = ckpt["state_dict"]
     assert sd["embedding_xyz.voxel_idx_map"].dtype == torch.int64 and sd["embedding_xyz.embedding_space_ftr.weight"].shape == (6500, 24)
     sc = checkpoint.build_from_state_dict(ckpt)

@@ -26,7 +26,7 @@ KW = dict(N_samples=64, N_importance=64, perturb=0, noise_std=0, is_eval=True)
 
 
 def load():
-    ckpt = torch.load(CKPT, map_location="cpu")
+    ckpt = torch.load(CKPT, map_location="cpu", weights_only=True)      # tensors and plain containers only: no pickle code runs
     return ckpt, checkpoint.build_from_state_dict(ckpt, device=DEV)
 
 
