@@ -310,6 +310,18 @@ __global__ void __launch_bounds__(256) composite_finish_kernel(const float* __re
   for (long ray = wave; ray < n_rays; ray += nwaves) {
     RayAcc s, q;
     float* w = weights + ray * S;
+    // Up to 256 samples: the ray's local weights are fetched up front, all sweeps at once, before the (dependent) walk over
+    // the segment records -- one wave per ray with a single load in flight left the kernel bound by latency x concurrency
+    // (1.76 TB/s in round 3), not by bandwidth.  Same arithmetic, same order: bit-equal results.
+    const bool pre = S <= 256;
+    float wv[4] = {0.f, 0.f, 0.f, 0.f}, tw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pre) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int i = jj * 64 + lane;
+        if (i < S) wv[jj] = w[i];
+      }
+    }
     // lane l rescales sample l of segments l >> 5, l >> 5 + 2, ...: two segments per sweep of the wave
     for (int j = 0; j < nseg; j += 2) {
       const float* r0 = rec + (ray * nseg + j) * kSegRecFloats;
@@ -325,7 +337,20 @@ __global__ void __launch_bounds__(256) composite_finish_kernel(const float* __re
         if (inst_weights) { Tlo = Ql; Thi = Qh; }
       }
       const int i = j * 32 + lane;
-      if (i < S) w[i] = (lane < 32 ? Tlo : Thi) * w[i];
+      if (pre) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (jj == (j >> 1)) tw[jj] = lane < 32 ? Tlo : Thi;
+      } else if (i < S) {
+        w[i] = (lane < 32 ? Tlo : Thi) * w[i];
+      }
+    }
+    if (pre) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int i = jj * 64 + lane;
+        if (i < S) w[i] = tw[jj] * wv[jj];
+      }
     }
     if (lane == 0) {
       opacity[ray] = s.opacity;
