@@ -25,12 +25,15 @@ def _sub(sd, prefix):
     return OrderedDict((k[len(prefix):], v) for k, v in sd.items() if k.startswith(prefix))
 
 
-def embedding_voxel_from_state(sub):
-    """EmbeddingVoxel whose grid state comes from checkpoint buffers (no point cloud needed)."""
+def embedding_voxel_from_state(sub, n_freq_voxel=6):
+    """EmbeddingVoxel whose grid state comes from checkpoint buffers (no point cloud needed).  The channel count is the
+    table's; the number of voxel frequencies is not in a checkpoint -- it comes from config.model.N_freq_voxel."""
     table = sub["embedding_space_ftr.weight"]
     ev = EmbeddingVoxel.__new__(EmbeddingVoxel)
     nn.Module.__init__(ev)
-    ev.embedding_final = Embedding(table.shape[1], 6)
+    ev.N_freqs = int(n_freq_voxel)
+    ev.fused_layout = (table.shape[1] == 24 and ev.N_freqs == 6)       # what the fused kernels embed in registers
+    ev.embedding_final = Embedding(table.shape[1], ev.N_freqs)
     ev.embedding_space_ftr = nn.Embedding(table.shape[0], table.shape[1])
     for b in _VOXEL_BUFFERS:
         ev.register_buffer(b, sub[b].clone())
@@ -60,7 +63,7 @@ def build_from_state_dict(state_dict, model_config=None, device=None):
             models[typ] = m
     if "coarse" not in models:
         raise RuntimeError("checkpoint has no nerf_coarse.* parameters")
-    emb_xyz = embedding_voxel_from_state(_sub(sd, "embedding_xyz.")) if use_voxel else Embedding(3, cfg["N_freq_xyz"])
+    emb_xyz = embedding_voxel_from_state(_sub(sd, "embedding_xyz."), cfg.get("N_freq_voxel", 6)) if use_voxel else Embedding(3, cfg["N_freq_xyz"])
     codes = CodeLibrary(cfg)
     sub = _sub(sd, "code_library.")
     if sub:

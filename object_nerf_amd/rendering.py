@@ -114,12 +114,14 @@ def fused_path_ok(models, embeddings, fine):
     if not all(getattr(m, "fused_architecture", False) for m in ms):
         return False
     ex, ed = embeddings["xyz"], embeddings.get("dir")
+    def plain(e, nf):      # 2^k bands, the default count (modules unpickled from before `logscale` existed are logscale)
+        return isinstance(e, Embedding) and getattr(e, "logscale", True) and e.N_freqs == nf and e.in_channels == 3
     if isinstance(ex, EmbeddingVoxel):
-        if not ex.fused_layout:
+        if not getattr(ex, "fused_layout", ex.channels == 24 and ex.embedding_final.N_freqs == 6):
             return False
-    elif not (isinstance(ex, Embedding) and ex.logscale and ex.N_freqs == 10 and ex.in_channels == 3):
+    elif not plain(ex, 10):
         return False
-    return isinstance(ed, Embedding) and ed.logscale and ed.N_freqs == 4 and ed.in_channels == 3
+    return plain(ed, 4)
 
 
 def _train_packs(coarse, fine):
