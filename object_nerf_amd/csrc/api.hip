@@ -225,7 +225,8 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   if ((fused && !query ? a->n_rays * (int64_t)a->S : a->n_points) == 0) return 0;   // nothing to do
   if (!a->do_scene && !a->do_object) return set_error(-1, "mlp_eval: no branch selected");
   const bool comp = a->comp_w != nullptr;      // compositing in the epilogue: sigma / rgb need not be written
-  if (a->ray_bias && (!fused || a->sigma_only)) return set_error(-1, "mlp_eval: ray_bias needs the fused form");
+  if (a->ray_bias && (!fused || (a->sigma_only && (a->do_scene || !a->do_object))))
+    return set_error(-1, "mlp_eval: ray_bias needs the fused form (with sigma_only: the object query, one vector for all points)");
   if (comp) {
     if (!fused || !a->do_scene || !a->comp_rec || a->ray_index || a->sigma_only || a->S < 32 || (a->S & 31))
       return set_error(-1, "mlp_eval: comp_w needs the fused form, the scene branch, comp_rec, S % 32 == 0 and no ray subset");

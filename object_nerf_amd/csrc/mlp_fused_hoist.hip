@@ -13,6 +13,14 @@ static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStr
 
 int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
+#ifndef OBJ_TUNE_ONLY_MAIN
+  if (a.sigma_only) {        // object-branch density query on points / a lattice with the code's terms hoisted
+    if (sc || !ob) return set_error(-1, "mlp_eval(points, sigma_only): ray_bias serves the object query only");
+    if (a.use_voxel) hipLaunchKernelGGL((mlp_kernel<true, true, false, true, true, false, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+    else hipLaunchKernelGGL((mlp_kernel<false, true, false, true, true, false, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+    return check_launch("mlp_eval(points, sigma_only, hoisted)");
+  }
+#endif
 #ifdef OBJ_TUNE_ONLY_MAIN   // tuning builds (tools/tune_mlp.py): only the bench instantiation, to compile fast
   if (!(a.use_voxel && sc && ob)) return set_error(-9, "tuning build: only voxel scene+object is compiled");
   launch<true, true, true>(a, ntiles, grid, s);

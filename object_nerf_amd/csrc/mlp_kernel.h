@@ -1068,7 +1068,9 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false, bool HOIST = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr) {
   static_assert(!B3 || !SIGMA_ONLY, "split-bf16 mode: every layer (no density-only variant)");
-  static_assert(!HOIST || (FUSED && !SAVE && !SIGMA_ONLY), "hoisting: inference form of the fused kernel");
+  // (with SIGMA_ONLY: the object-branch density query, whose ONE code is constant over all points -- its share of
+  // instance_encoding_1 / _3 arrives as a single vector at ray_bias, every point reads "ray" 0)
+  static_assert(!HOIST || (FUSED && !SAVE && (!SIGMA_ONLY || (DO_OBJ && !DO_SCENE))), "hoisting: inference form of the fused kernel");
   constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");

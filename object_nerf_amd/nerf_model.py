@@ -380,6 +380,18 @@ class ObjectNeRF(nn.Module):
                     raise RuntimeError("query_sigma: obj_code must be ONE 64-d code (the script repeats one id over the chunk)")
                 a.do_object, a.codes, a.code_stride, a.inst_sigma = 1, code.data_ptr(), 0, sig.data_ptr()
                 keep.append(code)
+                from .rendering import hoist_enabled
+                if hoist_enabled():
+                    # the ONE code is constant over all points: its share of instance_encoding_1 / _3 as one hoisted vector
+                    # ("ray" 0 of objnerf_ray_bias; the dummy ray row only feeds the direction terms the query never reads)
+                    l = _lib.lib()
+                    ray0 = torch.zeros(1, 8, dtype=torch.float32, device=dev)
+                    rb = torch.empty(l.objnerf_ray_bias_floats(1), dtype=torch.float32, device=dev)
+                    a.rays, a.n_rays = ray0.data_ptr(), 1
+                    _lib.check(l.objnerf_ray_bias(C.byref(a), _lib.ptr(rb), _lib.stream_ptr()), "ray_bias")
+                    a.rays, a.n_rays = None, 0
+                    a.ray_bias = rb.data_ptr()
+                    keep += [ray0, rb]
             _lib.check(_lib.lib().objnerf_mlp_eval(C.byref(a), _lib.stream_ptr()), "mlp_eval(points, sigma_only)")
         return sig
 

@@ -131,6 +131,21 @@ def test_sigma_query_matches_the_reference_mesh_tool(sname):
             m4 = fine.forward_instance({"emb_xyz": ex, "obj_code": code.expand(pts.shape[0], 64).contiguous()}, sigma_only=True)["inst_sigma"]
         check(s0, m0, 2e-5, "fused vs memory form / scene")
         check(s4, m4, 2e-5, "fused vs memory form / object")
+    # the object query hoists its ONE code (a constant of the whole query) like the render path hoists per-ray terms:
+    # same sums in another association; OBJNERF_HOIST=0 contracts the code per point
+    import os
+    old = os.environ.get("OBJNERF_HOIST")
+    os.environ["OBJNERF_HOIST"] = "0"
+    try:
+        with torch.no_grad():
+            s4_plain = fine.query_sigma(emb, lattice=(x, y, z), obj_code=code)
+    finally:
+        if old is None:
+            os.environ.pop("OBJNERF_HOIST")
+        else:
+            os.environ["OBJNERF_HOIST"] = old
+    assert not torch.equal(s4_plain, s4) and H.normwise(s4, s4_plain) < 2e-6
+    check(s4_plain[:, 0], g["%s_obj%d" % (sname, oid)], 2e-5, "sigma query / object, code contracted per point / " + sname)
 
 
 def test_sigma_query_lattice_order_tails_and_errors():
