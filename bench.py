@@ -661,7 +661,7 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
 
 def split_bf16_leg(wl, args, lib, fence, allreduce, evals_job):
     """The same steps in the opt-in split-bf16 arithmetic mode (OBJNERF_MFMA=bf16x3: the fp32 contraction carried out on
-    the bf16 matrix pipe with exactly split operands, DESIGN.md section 3) with ITS roofline: 6 bf16 MFMA products per
+    the bf16 matrix pipe with exactly split operands, DESIGN.md section 3.1) with ITS roofline: 6 bf16 MFMA products per
     fp32 product, so the fp32-equivalent ceiling is 2500 / 6 = 416.7 TFLOP/s."""
     key = wl.gather_keys[0]
     ref_rgb = wl.last[key].clone()

@@ -454,7 +454,7 @@ __device__ __forceinline__ void sample_pdf_ray(const float* bins_lds, float* cdf
   // fp32 terms is exact to ~1e-16 relative in any association order, so the fp32-rounded prefixes equal the sequential
   // ones except when a float64 sum lies within that distance of an fp32 rounding boundary (probability ~1e-9 per
   // element).  Why it matters: u = 1 (the last deterministic sample) lands in the last bin or one bin earlier depending
-  // on whether cdf[-1] is <= 1 or > 1 -- a whole-bin discontinuity decided by the last ulp of this sum (DESIGN.md §4); an
+  // on whether cdf[-1] is <= 1 or > 1 -- a whole-bin discontinuity decided by the last ulp of this sum (DESIGN.md §3.3); an
   // fp32 running sum drifts several ulps from 1 and flips that decision on ~40 % of opaque rays.
   double carry = 0.0;
   if (lane == 0) cdf_lds[0] = 0.f;

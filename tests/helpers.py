@@ -124,7 +124,7 @@ def fine_pass_on_reference_depths(sc, case, g, device="cuda"):
 def moved_rays(z_ours, z_ref, z_coarse, frac=0.25):
     """Per-ray mask: some fine depth differs from the reference's by more than `frac` of the ray's smallest coarse
     spacing -- an importance sample that landed in a different place of its bin or in another bin (the discontinuities
-    of rendering.py:43-60: the searchsorted decision, the denom < eps branch, and u = 1 against cdf[-1]; DESIGN.md §4).
+    of rendering.py:43-60: the searchsorted decision, the denom < eps branch, and u = 1 against cdf[-1]; DESIGN.md §3.3).
     Everything on such a ray that is indexed by sample position (weights_, z_vals_) is then shifted, not perturbed."""
     zo, zr, zc = z_ours.detach().cpu().double(), z_ref.detach().cpu().double(), z_coarse.detach().cpu().double()
     gap = (zc[:, 1:] - zc[:, :-1]).abs()

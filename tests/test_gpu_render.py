@@ -8,7 +8,7 @@ floor: the reference's own fp32 result moves by 1e-4..1e-1 (normwise, weights_/z
 the same code runs in fp64, so end to end they are graded against that floor:
 error vs the fp32 reference <= 3x floor in BOTH arithmetic modes (measured worst ratios 1.84 fp32 MFMA and 2.49
 split-bf16, profiles/r02_parity.md; round 1 needed 20x because its sampler
-summed the cdf in fp32 where the reference's CPU cumsum accumulates in float64 -- DESIGN.md §4),
+summed the cdf in fp32 where the reference's CPU cumsum accumulates in float64 -- DESIGN.md §3.3),
 plus: no more rays whose importance samples MOVED (helpers.moved_rays) than the float64 oracle
 itself has + 1, PSNR(ours, reference) >= 60 dB and |dPSNR| <= 0.1 dB against a fixed synthetic
 target.  The fine pass itself is held to 1e-4 by test_fine_pass_teacher_forced (reference depths fed
