@@ -8,6 +8,8 @@
 // Compiled with -ffp-contract=off; see device_math.h.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <stdlib.h>
+#include <string.h>
 #include <math.h>
 #include "layout.h"
 #include "device_math.h"
@@ -366,6 +368,81 @@ __global__ void __launch_bounds__(256) composite_finish_kernel(const float* __re
         rgb_inst[ray * 3 + 2] = q.b + 1.f - q.opacity;
       }
     }
+  }
+}
+
+// The same, laid out for memory parallelism (round 4): a workgroup takes 64 rays; every thread first puts its share of the
+// 64 x S local weights in flight (16-byte loads, all independent), threads 0..63 meanwhile walk one ray's records each (the
+// RayAcc chain is per ray and sequential anyway) and leave the segments' incoming transmittances in LDS; after one barrier
+// the weights are rescaled and stored.  The one-wave-per-ray form above is a chain of three dependent memory round trips per
+// wave (records -> weights -> store): 1.75 TB/s however the loads were ordered.  Same arithmetic in the same order: bit-equal.
+constexpr int kFinishRays = 64;
+__global__ void __launch_bounds__(256) composite_finish_block_kernel(const float* __restrict__ rec, long n_rays, int S, int has_inst,
+                                                                     int white_back, float* __restrict__ weights,
+                                                                     float* __restrict__ opacity, float* __restrict__ rgb_map,
+                                                                     float* __restrict__ depth, float* __restrict__ rgb_inst,
+                                                                     float* __restrict__ depth_inst, float* __restrict__ opacity_inst,
+                                                                     int inst_weights) {
+  extern __shared__ __attribute__((aligned(16))) float tm[];       // [ray in block][segment]: incoming transmittance
+  const int tid = threadIdx.x;
+  const int nseg = S >> 5;
+  const long ray0 = (long)blockIdx.x * kFinishRays;
+  const int nr = (int)(n_rays - ray0 < kFinishRays ? n_rays - ray0 : kFinishRays);
+  f32x4* wv = (f32x4*)(weights + ray0 * S);                        // S % 32 == 0: 128-byte aligned
+  const int nvec = nr * (S >> 2);
+  constexpr int PRE = 16;                                          // 16-byte pieces per thread in flight (covers S <= 256)
+  f32x4 pre[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int v = tid + 256 * k;
+    if (v < nvec) pre[k] = wv[v];
+  }
+  if (tid < nr) {
+    const long ray = ray0 + tid;
+    RayAcc s, q;
+    const float* r = rec + ray * nseg * kSegRecFloats;
+    for (int j = 0; j < nseg; ++j, r += kSegRecFloats) {
+      const f32x4 a = *(const f32x4*)r, b = *(const f32x4*)(r + 4);
+      float T = s.step(SegTotals{a[0], a[1], a[2], a[3], b[0], b[1]});
+      if (has_inst) {
+        const f32x4 c = *(const f32x4*)(r + 8), d = *(const f32x4*)(r + 12);
+        const float Q = q.step(SegTotals{c[0], c[1], c[2], c[3], d[0], d[1]});
+        if (inst_weights) T = Q;
+      }
+      tm[tid * nseg + j] = T;
+    }
+    opacity[ray] = s.opacity;
+    depth[ray] = s.depth;
+    rgb_map[ray * 3 + 0] = white_back ? s.r + 1.f - s.opacity : s.r;
+    rgb_map[ray * 3 + 1] = white_back ? s.g + 1.f - s.opacity : s.g;
+    rgb_map[ray * 3 + 2] = white_back ? s.b + 1.f - s.opacity : s.b;
+    if (has_inst) {
+      opacity_inst[ray] = q.opacity;
+      depth_inst[ray] = q.depth;
+      rgb_inst[ray * 3 + 0] = q.r + 1.f - q.opacity;      // always white-backed, rendering.py:223
+      rgb_inst[ray * 3 + 1] = q.g + 1.f - q.opacity;
+      rgb_inst[ray * 3 + 2] = q.b + 1.f - q.opacity;
+    }
+  }
+  __syncthreads();
+  const int vps = S >> 2;                                          // 16-byte pieces per ray
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int v = tid + 256 * k;
+    if (v < nvec) {
+      const int rl = v / vps, seg = (v - rl * vps) >> 3;           // 8 pieces per 32-sample segment
+      const float t = tm[rl * nseg + seg];
+      f32x4 w = pre[k];
+      w[0] = t * w[0]; w[1] = t * w[1]; w[2] = t * w[2]; w[3] = t * w[3];
+      wv[v] = w;
+    }
+  }
+  for (int v = tid + 256 * PRE; v < nvec; v += 256) {              // S > 256: the rest without the early fetch
+    const int rl = v / vps, seg = (v - rl * vps) >> 3;
+    const float t = tm[rl * nseg + seg];
+    f32x4 w = wv[v];
+    w[0] = t * w[0]; w[1] = t * w[1]; w[2] = t * w[2]; w[3] = t * w[3];
+    wv[v] = w;
   }
 }
 
@@ -1195,10 +1272,19 @@ int objnerf_composite_finish(const float* seg_records, int64_t n_rays, int S, in
   if (!seg_records || !weights || !opacity || !rgb_map || !depth) return set_error(-1, "composite_finish: null pointer");
   if (has_instance && (!rgb_inst || !depth_inst || !opacity_inst)) return set_error(-1, "composite_finish: instance outputs missing");
   if (inst_weights && !has_instance) return set_error(-1, "composite_finish: inst_weights without the instance set");
-  const long waves = n_rays < 262144 ? n_rays : 262144;
-  hipLaunchKernelGGL(composite_finish_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, seg_records,
-                     (long)n_rays, S, has_instance != 0, white_back, weights, opacity, rgb_map, depth, rgb_inst, depth_inst,
-                     opacity_inst, inst_weights != 0);
+  // OBJNERF_FINISH=wave: the one-wave-per-ray form of round 3 (A/B switch; results are bit-equal)
+  static const bool per_wave = [] { const char* e = getenv("OBJNERF_FINISH"); return e && !strcmp(e, "wave"); }();
+  const long blocks = (n_rays + kFinishRays - 1) / kFinishRays;
+  if (per_wave || blocks > 0x7fffffffL) {
+    const long waves = n_rays < 262144 ? n_rays : 262144;
+    hipLaunchKernelGGL(composite_finish_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, seg_records,
+                       (long)n_rays, S, has_instance != 0, white_back, weights, opacity, rgb_map, depth, rgb_inst, depth_inst,
+                       opacity_inst, inst_weights != 0);
+  } else {
+    hipLaunchKernelGGL(composite_finish_block_kernel, dim3((unsigned)blocks), dim3(256), (size_t)kFinishRays * (S >> 5) * sizeof(float),
+                       (hipStream_t)stream, seg_records, (long)n_rays, S, has_instance != 0, white_back, weights, opacity, rgb_map,
+                       depth, rgb_inst, depth_inst, opacity_inst, inst_weights != 0);
+  }
   return check_launch("composite_finish");
 }
 
