@@ -496,6 +496,9 @@ def run(args, renderer=None, backend="nccl", argv=None):
                                "launches": int(launches.value), "avg_launch_ms": kms.value / max(1, launches.value),
                                "flop_per_eval": wl.flop_per_eval if wl.flop_per_eval else {"scene": FLOP_SCENE, "object": FLOP_OBJECT},
                                "flop_per_launch_avg": flop / max(1, launches.value), "mlp_time_frac_of_step": mlp_s / (t1 - t0),
+                               # what `traffic` is to be held against: z 4 + local weights 4 + segment records 2 + per-ray vectors 19 +
+                               # rays / codes 3 bytes per evaluated sample point
+                               "algorithmic_bytes_per_launch_avg": 32.0 * wl.evals_rank * args.steps / max(1, launches.value),
                                "measured_on": "rank 0"}
             from object_nerf_amd.rendering import composite_mode, hoist_enabled
             if hoist_enabled():

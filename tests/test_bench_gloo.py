@@ -158,8 +158,13 @@ def test_self_launch_starts_every_rank_and_propagates_failures(tmp_path):
         "if 'fail' in sys.argv: time.sleep(30)\n")
     args = bench.parse(["--gpus", "3"])
     assert bench.self_launch(args, [str(tmp_path), "--gpus", "3"], cmd=[sys.executable, str(child)]) == 0
-    assert sorted(os.listdir(tmp_path)) == ["child.py", "rank0.of3", "rank1.of3", "rank2.of3"]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith(("child", "rank"))) == ["child.py", "rank0.of3", "rank1.of3", "rank2.of3"]
     assert (tmp_path / "rank2.of3").read_text() == "--gpus 3"
+    # --one-gpu: every rank gets LOCAL_RANK 0 (they share cuda:0; run() then takes gloo with host-staged messages)
+    one = tmp_path / "one.py"
+    one.write_text("import os, sys\nopen(os.path.join(sys.argv[1], 'lr%s_%s' % (os.environ['RANK'], os.environ['LOCAL_RANK'])), 'w').write('')\n")
+    assert bench.self_launch(bench.parse(["--gpus", "3", "--one-gpu"]), [str(tmp_path)], cmd=[sys.executable, str(one)]) == 0
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("lr")) == ["lr0_0", "lr1_0", "lr2_0"]
     import time
     t0 = time.time()
     assert bench.self_launch(args, [str(tmp_path), "fail"], cmd=[sys.executable, str(child)]) == 7
