@@ -19,7 +19,15 @@
 #include <hip/hip_runtime.h>
 #include "device_math.h"
 
+#include <utility>
+#include <type_traits>
+
 namespace objnerf {
+
+template <int... Is, class F>
+__device__ __forceinline__ void gemm_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
 
 enum GemmEpilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_LEAKY = 2, EPI_BIAS_SIGMOID = 3, EPI_LEAKY_BWD = 4 };
 
@@ -56,6 +64,12 @@ constexpr int GTILE = GBM * GLDK;   // floats per staged operand tile (>= GBK * 
 #endif
 #ifndef OBJ_GEMM_FRAG_PIPE
 #define OBJ_GEMM_FRAG_PIPE 0   // full tiles: LDS fragment reads software-pipelined one 16-MFMA group ahead
+#endif
+#ifndef OBJ_GEMM_SPREAD_FETCH
+// 1: full tiles: the eight 16-byte global loads of the next k tile are issued two at a time in front of the four 16-MFMA
+// groups of the current one instead of as one burst (a burst queues at the CU's 64 B/clk vector-memory path and stalls the
+// issuing waves -- what profiles/r03_wgrad_ablations.md measured for the weight-gradient loop)
+#define OBJ_GEMM_SPREAD_FETCH 0
 #endif
 #ifndef OBJ_GEMM_TAIL
 // 1: a ragged last column tile with at most 3 of its four 32-column sub-tiles live is computed by a second launch of the
@@ -153,6 +167,14 @@ struct GemmOperand {
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i] += step;
   }
+  // one piece of the next tile (unconditional 16-byte load: only when can_spread()); advance() after all four
+  __device__ __forceinline__ bool can_spread(long k0, long kend) const { return fast && k0 + GBK <= kend; }
+  template <int I>
+  __device__ __forceinline__ void fetch_one() { v[I] = aligned ? gload4(p[I]) : gload4u(p[I]); }
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] += step;
+  }
   __device__ __forceinline__ void put(float* lds, int tid) const {
     if (K_CONTIG) {
 #pragma unroll
@@ -246,7 +268,8 @@ __global__ void __launch_bounds__(256) OBJ_GEMM_OCC gemm_kernel(const GemmArgs g
         opb.put(Bs, tid);
         __syncthreads();
       }
-      if (more) {                            // next tile's global loads fly under this tile's MFMAs
+      const bool spread = OBJ_GEMM_SPREAD_FETCH && !TAIL && more && opa.can_spread(k0 + GBK, kend) && opb.can_spread(k0 + GBK, kend);   // uniform
+      if (more && !spread) {                 // next tile's global loads fly under this tile's MFMAs
         opa.fetch(k0 + GBK, kend, tid);
         opb.fetch(k0 + GBK, kend, tid);
       }
@@ -297,13 +320,20 @@ __global__ void __launch_bounds__(256) OBJ_GEMM_OCC gemm_kernel(const GemmArgs g
           __builtin_amdgcn_sched_barrier(0);
         }
 #else
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {       // 4 MFMA steps per fragment read
+        gemm_static_for_impl([&](auto S4) __attribute__((always_inline)) {       // 4 MFMA steps per fragment read
+          constexpr int s4 = decltype(S4)::value;
           f32x4 a[2], b[2];
 #pragma unroll
           for (int i = 0; i < 2; ++i) a[i] = GemmOperand<A_KC>::frag(As, wm * 64 + i * 32 + rl, half, s4);
 #pragma unroll
           for (int j = 0; j < 2; ++j) b[j] = GemmOperand<B_KC>::frag(Bs, wn * 64 + j * 32 + rl, half, s4);
+          if constexpr (OBJ_GEMM_SPREAD_FETCH) {
+            if (spread) {                      // this group's share of the next tile's loads
+              opa.template fetch_one<s4>();
+              opb.template fetch_one<s4>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -311,7 +341,9 @@ __global__ void __launch_bounds__(256) OBJ_GEMM_OCC gemm_kernel(const GemmArgs g
 #pragma unroll
               for (int j = 0; j < 2; ++j)
                 acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[2 * i + j], 0, 0, 0);
-        }
+          if constexpr (OBJ_GEMM_SPREAD_FETCH) __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, 4>{});
+        if (spread) { opa.advance(); opb.advance(); }
 #endif
       }
       if (NBUF == 2) {
