@@ -71,6 +71,12 @@ constexpr int GTILE = GBM * GLDK;   // floats per staged operand tile (>= GBK * 
 // issuing waves -- what profiles/r03_wgrad_ablations.md measured for the weight-gradient loop)
 #define OBJ_GEMM_SPREAD_FETCH 0
 #endif
+#ifndef OBJ_GEMM_SPREAD_FWD
+// 1: the same for the forward shape only (both operands K-contiguous: Y = X W^T, the layer-wise MLP of generic.hip and of the
+// OBJNERF_TRAIN_LAYERWISE path).  Measured on MI355X (profiles/r04_gemm_variants.txt): forward shapes 0.63 -> 0.67, 0.47 -> 0.54,
+// 0.37 -> 0.45 of peak; the dX / dW shapes LOSE 4-8 % with it, so they keep the burst
+#define OBJ_GEMM_SPREAD_FWD 1
+#endif
 #ifndef OBJ_GEMM_TAIL
 // 1: a ragged last column tile with at most 3 of its four 32-column sub-tiles live is computed by a second launch of the
 // TAIL instantiation: 4 x 1 wave layout, wave w owns row sub-tile w and the live column sub-tiles, so that tile costs
@@ -268,7 +274,8 @@ __global__ void __launch_bounds__(256) OBJ_GEMM_OCC gemm_kernel(const GemmArgs g
         opb.put(Bs, tid);
         __syncthreads();
       }
-      const bool spread = OBJ_GEMM_SPREAD_FETCH && !TAIL && more && opa.can_spread(k0 + GBK, kend) && opb.can_spread(k0 + GBK, kend);   // uniform
+      constexpr bool kSpread = OBJ_GEMM_SPREAD_FETCH || (OBJ_GEMM_SPREAD_FWD && A_KC && B_KC);
+      const bool spread = kSpread && !TAIL && more && opa.can_spread(k0 + GBK, kend) && opb.can_spread(k0 + GBK, kend);   // uniform
       if (more && !spread) {                 // next tile's global loads fly under this tile's MFMAs
         opa.fetch(k0 + GBK, kend, tid);
         opb.fetch(k0 + GBK, kend, tid);
@@ -327,7 +334,7 @@ __global__ void __launch_bounds__(256) OBJ_GEMM_OCC gemm_kernel(const GemmArgs g
           for (int i = 0; i < 2; ++i) a[i] = GemmOperand<A_KC>::frag(As, wm * 64 + i * 32 + rl, half, s4);
 #pragma unroll
           for (int j = 0; j < 2; ++j) b[j] = GemmOperand<B_KC>::frag(Bs, wn * 64 + j * 32 + rl, half, s4);
-          if constexpr (OBJ_GEMM_SPREAD_FETCH) {
+          if constexpr (kSpread) {
             if (spread) {                      // this group's share of the next tile's loads
               opa.template fetch_one<s4>();
               opb.template fetch_one<s4>();
@@ -341,7 +348,7 @@ __global__ void __launch_bounds__(256) OBJ_GEMM_OCC gemm_kernel(const GemmArgs g
 #pragma unroll
               for (int j = 0; j < 2; ++j)
                 acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[2 * i + j], 0, 0, 0);
-          if constexpr (OBJ_GEMM_SPREAD_FETCH) __builtin_amdgcn_sched_barrier(0);
+          if constexpr (kSpread) __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, 4>{});
         if (spread) { opa.advance(); opb.advance(); }
 #endif
