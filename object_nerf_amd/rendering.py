@@ -110,6 +110,8 @@ def fused_path_ok(models, embeddings, fine):
     """True when the persistent fused kernel can render this operator set: the default architecture (both models), 2^k
     frequency bands with the default counts, and -- in voxel mode -- the 16 + 8 channel / 6 frequency table layout.
     Everything else takes the layer-wise path (object_nerf_amd/generic.py)."""
+    if os.environ.get("OBJNERF_PATH", "fused") == "layerwise":      # developer switch: the default architecture through the
+        return False                                                   # layer-wise path too (cross-check, tools/arch_bench.py)
     ms = [models["coarse"]] + ([models["fine"]] if fine else [])
     if not all(getattr(m, "fused_architecture", False) for m in ms):
         return False

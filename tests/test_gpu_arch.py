@@ -121,3 +121,29 @@ def test_forwards_and_embeddings_on_another_architecture(name):
                                skips=arch["skips"], sigma_only=True)[0]
         got = m.query_sigma(sc.embeddings["xyz"], lattice=(x, y, z))
         assert got.shape == want.shape and H.normwise(got, want) <= 2e-5
+
+
+def test_default_architecture_through_the_layerwise_path_agrees_with_the_fused_kernels(monkeypatch):
+    """OBJNERF_PATH=layerwise sends the DEFAULT architecture through generic.py / generic.hip as well: two independent
+    implementations of the same pipeline (persistent fused kernel with in-register embeddings vs stage-by-stage GEMMs on
+    materialised embeddings) on the same weights -- coarse keys to fp32 roundoff, fine keys within the reference golden's
+    floor-based tolerance of each other's reference."""
+    case = "voxel_eval"
+    c = cases.RENDER_CASES[case]
+    sc = scene(c["scene"])
+    g = cases.load_golden("render_" + case)
+    rays, ids, _, _ = cases.render_inputs(case)
+    kw = dict(c["kw"], perturb=0, noise_std=0)
+    with torch.no_grad():
+        codes = sc.code_library({"instance_ids": ids.to(DEV)})["embedding_instance"]
+        fused = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, **kw)
+        monkeypatch.setenv("OBJNERF_PATH", "layerwise")
+        lw = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, **kw)
+    f64 = H.oracle_f64(sc, True, rays, g["_codes"], None, None, c["kw"])
+    assert sorted(lw) == sorted(fused)
+    for k in fused:
+        if k.endswith("coarse"):
+            assert H.normwise(lw[k], fused[k]) <= 2e-5, (k, H.normwise(lw[k], fused[k]))
+        floor = H.normwise(g[k], f64[k])
+        tol = max(H.FLOOR_FACTOR * floor, 2e-5) if k.endswith("fine") else 1e-4
+        assert H.normwise(lw[k], g[k]) <= tol, "layer-wise path vs reference: %s %.3e (floor %.3e)" % (k, H.normwise(lw[k], g[k]), floor)
