@@ -947,12 +947,13 @@ __global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs
 // Step 2: lane = ray (its code and direction embedding in registers), the weights of 16 outputs at a time as wave-uniform
 // (scalar) operands; every lane stores the 16 outputs as one 64-byte piece of its ray's vector.  One wave per workgroup and
 // the 28 groups in 7 parts (blockIdx.y): a 1,024-ray chunk of the editor still spreads over 112 workgroups.
-constexpr int kRbParts = 7;                                     // 28 groups of 16 outputs in 7 parts of 4 (blockIdx.y)
+constexpr int kRbParts = 7;                                     // 28 groups of 16 outputs in 7 parts of 4 (blockIdx.y); small batches: 28 parts of 1
 __global__ void __launch_bounds__(64) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ wm) {
   const long slot = (long)blockIdx.x * 64 + threadIdx.x;
   if (slot >= (a.n_active ? (long)*a.n_active : a.n_rays)) return;
   const long ray = a.ray_index ? (long)a.ray_index[slot] : slot;      // vectors stay indexed by the ray's own number
-  const int g0 = blockIdx.y * (kRbGroups / kRbParts);
+  const int gpp = kRbGroups / (int)gridDim.y;                   // groups per part (gridDim.y = 7 or 28)
+  const int g0 = blockIdx.y * gpp;
   float x[64], pe[28];
   if (a.do_object) {
     const float* cp = a.codes + ray * a.code_stride;
@@ -979,7 +980,7 @@ __global__ void __launch_bounds__(64) ray_bias_kernel(const RayBiasArgs a, const
   float* out = a.out + ray * kRayBiasFloats;
   const float* bias = wm + kRbGroups * 64 * 16;
 #pragma unroll 1
-  for (int g = g0; g < g0 + kRbGroups / kRbParts; ++g) {
+  for (int g = g0; g < g0 + gpp; ++g) {
     const bool is_code = g < 16;
     const bool live = is_code ? a.do_object != 0 : (g < 24 ? a.do_scene != 0 : a.do_object != 0);
     if (!live) continue;                       // uniform
@@ -1301,7 +1302,10 @@ int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   if (m->n_rays == 0) return 0;
   RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out,
                 m->ray_index, m->n_active};
-  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 63) / 64), kRbParts), dim3(64), 0, (hipStream_t)stream, a,
+  // a wave computes 64 rays x (28 / parts) groups: below ~8k rays 7 parts leave most of the 1,024 SIMDs without a wave and the one
+  // wave each busy has 4 groups to do back to back (12 us at 1,024 rays); 28 parts of one group fill the machine 4x better
+  const unsigned parts = m->n_rays <= 8192 ? (unsigned)kRbGroups : (unsigned)kRbParts;
+  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 63) / 64), parts), dim3(64), 0, (hipStream_t)stream, a,
                      m->aux + kAuxFloats);
   return check_launch("ray_bias");
 }
