@@ -11,6 +11,7 @@
 #   trace       rocprofv3 --kernel-trace --stats of bench.py (headline) -> kernel table
 #   trace:train the same of tools/train_bench.py           trace:mesh  of the density query
 #   pmc         tools/pmc_run.sh (counter passes of the headline frame)
+#   parity      tools/parity_report.py + tools/frame_parity.py (per-key tables against the reference goldens)
 #   small       tools/small_batch.py                       edit   tools/edit_bench.py          arch   tools/arch_bench.py
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=$1; shift
@@ -36,6 +37,8 @@ for step in "$@"; do
     train) timeout 300 python tools/train_bench.py > $O/train_bench.txt 2>&1; echo "train rc=$?"; tail -2 $O/train_bench.txt ;;
     mesh)  timeout 600 python tools/mesh_query_bench.py 512 $O/mesh_query.md > $O/mesh_query.log 2>&1; echo "mesh rc=$?"; tail -8 $O/mesh_query.log ;;
     small) timeout 600 python tools/small_batch.py $O/small_batch.md > $O/small_batch.log 2>&1; echo "small rc=$?"; tail -8 $O/small_batch.log ;;
+    parity) timeout 900 python tools/parity_report.py $O/parity.md > $O/parity.log 2>&1; echo "parity rc=$?"; tail -16 $O/parity.md | cut -c1-160
+            timeout 600 python tools/frame_parity.py $O/frame_parity.md > $O/frame_parity.log 2>&1; echo "frame parity rc=$?"; tail -6 $O/frame_parity.md | cut -c1-200 ;;
     arch)  timeout 600 python tools/arch_bench.py $O/arch_bench.md > $O/arch_bench.log 2>&1; echo "arch rc=$?"; tail -6 $O/arch_bench.log ;;
     edit)  timeout 600 python tools/edit_bench.py > $O/edit_bench.txt 2>&1; echo "edit rc=$?"; tail -3 $O/edit_bench.txt ;;
     trace) case "$arg" in
