@@ -568,6 +568,25 @@ typedef struct {
 } objnerf_mlp_generic_args;
 int64_t objnerf_mlp_generic_workspace_floats(const objnerf_arch* arch, int64_t n_points);
 int objnerf_mlp_generic(const objnerf_mlp_generic_args* args, void* stream);
+/* Training of such architectures: objnerf_mlp_generic with every layer's output kept (workspace: activations, D*W + W + W/2
+ * (+ inst_D*inst_W + inst_W + inst_W/2) floats per point), and its backward -- dgrad GEMMs with the LeakyReLU backward in the
+ * epilogue, split-K weight / bias gradients ACCUMULATED (+=, fp32 atomics) into h_param_grads (same order as h_params), and the
+ * gradients w.r.t. the inputs: the first emb_cols columns of emb_xyz (P, emb_cols) (the voxel-feature part; 0 = none), obj_voxel
+ * (P, obj_voxel_c), obj_code (P, code_c), all overwritten.  d_*: gradients w.r.t. sigma (P), rgb (P,3), inst_sigma, inst_rgb.
+ * The default architecture trains on the fused kernels (objnerf_mlp_train_forward / _backward). */
+int64_t objnerf_mlp_generic_train_workspace_floats(const objnerf_arch* arch, int64_t n_points);
+int64_t objnerf_mlp_generic_train_scratch_floats(const objnerf_arch* arch, int64_t n_points);
+int objnerf_mlp_generic_train_forward(const objnerf_mlp_generic_args* args, void* stream);
+int objnerf_mlp_generic_train_backward(const objnerf_mlp_generic_args* args, const float* d_sigma, const float* d_rgb,
+                                       const float* d_inst_sigma, const float* d_inst_rgb, float* const* h_param_grads,
+                                       float* d_emb_xyz, int emb_cols, float* d_obj_voxel, float* d_obj_code, float* scratch,
+                                       void* stream);
+/* backward of objnerf_pos_encode_block w.r.t. x: d_x (n, C; row stride ldd) = d_out[:, :C] + sum_k f_k (cos(f_k x) d_sin_k -
+ * sin(f_k x) d_cos_k); and of objnerf_voxel_features w.r.t. the table: table_grad (n_rows, C) += trilinear scatter of d_raw */
+int objnerf_pos_encode_block_backward(const float* x, int64_t ldx, int64_t n, int C, int n_freqs, const float* freqs,
+                                      const float* d_out, int64_t ldo, float* d_x, int64_t ldd, void* stream);
+int objnerf_voxel_features_backward(const objnerf_voxel_grid* grid, int C, const float* xyz, int64_t n, const float* d_raw,
+                                    int64_t ldd, float* table_grad, void* stream);
 /* building blocks of the embeddings of such architectures:
  *   objnerf_voxel_features   the trilinear sparse-voxel lookup of EmbeddingVoxel (embedding_helper.py:331-389) BEFORE the
  *                            positional encoding, for a table of C channels per row: xyz (n,3) -> out (n, C), row stride ldo

@@ -234,6 +234,12 @@ SIGNATURES = {
     "objnerf_arch_num_param_ptrs": (C.c_int, [C.POINTER(Arch)]),
     "objnerf_mlp_generic_workspace_floats": (C.c_int64, [C.POINTER(Arch), C.c_int64]),
     "objnerf_mlp_generic": (C.c_int, [C.POINTER(MlpGenericArgs), _VP]),
+    "objnerf_mlp_generic_train_workspace_floats": (C.c_int64, [C.POINTER(Arch), C.c_int64]),
+    "objnerf_mlp_generic_train_scratch_floats": (C.c_int64, [C.POINTER(Arch), C.c_int64]),
+    "objnerf_mlp_generic_train_forward": (C.c_int, [C.POINTER(MlpGenericArgs), _VP]),
+    "objnerf_mlp_generic_train_backward": (C.c_int, [C.POINTER(MlpGenericArgs), _VP, _VP, _VP, _VP, C.POINTER(_VP), _VP, C.c_int, _VP, _VP, _VP, _VP]),
+    "objnerf_pos_encode_block_backward": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP]),
+    "objnerf_voxel_features_backward": (C.c_int, [C.POINTER(VoxelGrid), C.c_int, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP]),
     "objnerf_voxel_features": (C.c_int, [C.POINTER(VoxelGrid), C.c_int, _VP, C.c_int64, _VP, C.c_int64, _VP]),
     "objnerf_pos_encode_block": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP]),
     "objnerf_repeat_rows": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, _VP, C.c_int64, _VP]),

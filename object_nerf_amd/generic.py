@@ -6,7 +6,8 @@ behind `render_rays` is specialised for the architecture every shipped reference
 the same pipeline, stage by stage through the C ABI -- coarse depths, sample points, embeddings written column block by
 column block, the layer-wise MLP of csrc/generic.hip (fp32 MFMA GEMMs with bias / LeakyReLU / sigmoid epilogues),
 compositing, inverse-CDF sampling -- with the intermediate tensors in memory.  Python only allocates and enqueues; there is
-still no CPU or PyTorch arithmetic on the path.  Inference only: training a non-default shape raises.
+still no CPU or PyTorch arithmetic on the path.  With autograd recording `render_rays` takes `RenderRaysGenericFn` below: the
+same stages with every layer's activations kept, and their backward.
 """
 import ctypes as C
 
@@ -266,3 +267,211 @@ def render_rays_multi(models, embeddings, table, rays_c, clips, ids, S, I, use_d
         of = alloc(K * (S + I), False)
         one_pass(models["fine"], zf, of, None, noise[1] if noise else None)
     return oc, of
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training of non-default architectures: a differentiable render_rays on the layer-wise path
+# ---------------------------------------------------------------------------------------------------------------------
+def _freqs_dev(emb, dev):
+    """device table of an Embedding's bands when they are not 2^k (logscale=False), else None"""
+    if getattr(emb, "logscale", True):
+        return None
+    if getattr(emb, "_bands_dev", None) is None or emb._bands_dev.device != dev:
+        emb._bands_dev = emb.freq_bands.to(torch.float32).to(dev).contiguous()
+    return emb._bands_dev
+
+
+class _GPass:
+    __slots__ = ("z", "S", "xyz", "raw", "emb_xyz", "obj_voxel", "emb_dir", "code_pts", "sigma", "rgb", "isig", "irgb", "ws", "noise", "noise_i")
+
+
+class RenderRaysGenericFn(torch.autograd.Function):
+    """`render_rays` with autograd recording for ANY config.model architecture (the default one trains on the fused kernels,
+    object_nerf_amd/autograd.py): forward = the stages of `generic.render_rays` with every layer's activations kept
+    (objnerf_mlp_generic_train_forward), backward = compositing backward -> layer-wise MLP backward
+    (objnerf_mlp_generic_train_backward) -> positional-encoding / trilinear backward into the voxel table -> per-ray sums
+    of the code gradients.  Gradients: every ObjectNeRF parameter of both models, the voxel feature table, the codes; none
+    through the sampler (rendering.py:307 detaches) or the occlusion mask."""
+
+    @staticmethod
+    def forward(ctx, meta, rays, codes, table, *params):
+        from .autograd import _composite_args, _empty, _ptr_table
+        l = _lib.lib()
+        st = _lib.stream_ptr()
+        dev = rays.device
+        n, S, I = rays.shape[0], meta["S"], meta["I"]
+        fi = meta["forward_instance"]
+        mc, mf = meta["models"]
+        exyz, edir = meta["emb_xyz"], meta["emb_dir"]
+        vox = meta["use_voxel"]
+        npar = len(params) // (2 if I > 0 else 1)
+        p_c = [_lib.as_f32(p.detach()) for p in params[:npar]]
+        p_f = [_lib.as_f32(p.detach()) for p in params[npar:2 * npar]] if I > 0 else None
+        rays_c, codes_c = _lib.as_f32(rays.detach()), _lib.as_f32(codes.detach())
+        rnd = meta["randoms"]
+        arch = arch_of(mc)
+        in_dir = arch.in_dir
+        emb_dir_ray = _empty(n, in_dir, dev=dev)
+        dirs = rays_c[:, 3:6].contiguous()
+        _lib.check(l.objnerf_pos_encode_block(_lib.ptr(dirs), 3, n, 3, edir.N_freqs, _lib.ptr(_freqs_dev(edir, dev)), _lib.ptr(emb_dir_ray),
+                                              in_dir, st), "pos_encode_block")
+
+        def run_pass(model, z, pp, noise, noise_i):
+            ps = _GPass()
+            Sx = z.shape[1]
+            P = n * Sx
+            ps.S, ps.z = Sx, z
+            ps.xyz = _empty(P, 3, dev=dev)
+            _lib.check(l.objnerf_sample_points(_lib.ptr(rays_c), _lib.ptr(z), n, Sx, _lib.ptr(ps.xyz), st), "sample_points")
+            ps.emb_xyz = _empty(P, arch.in_xyz, dev=dev)
+            ps.raw = ps.obj_voxel = None
+            if vox:
+                C_, F = exyz.channels, exyz.N_freqs
+                cs, co = C_ - exyz.instance_ftr_C, exyz.instance_ftr_C
+                g = meta["grid"]
+                ps.raw = _empty(P, C_, dev=dev)
+                ps.obj_voxel = _empty(P, co * (2 * F + 1), dev=dev)
+                _lib.check(l.objnerf_voxel_features(C.byref(g), C_, _lib.ptr(ps.xyz), P, _lib.ptr(ps.raw), C_, st), "voxel_features")
+                _lib.check(l.objnerf_pos_encode_block(C.c_void_p(ps.raw.data_ptr()), C_, P, cs, F, None, _lib.ptr(ps.emb_xyz), arch.in_xyz, st), "pe")
+                _lib.check(l.objnerf_pos_encode_block(_lib.ptr(ps.xyz), 3, P, 3, 10, None,
+                                                      C.c_void_p(ps.emb_xyz.data_ptr() + 4 * cs * (2 * F + 1)), arch.in_xyz, st), "pe")
+                _lib.check(l.objnerf_pos_encode_block(C.c_void_p(ps.raw.data_ptr() + 4 * cs), C_, P, co, F, None, _lib.ptr(ps.obj_voxel),
+                                                      ps.obj_voxel.shape[1], st), "pe")
+            else:
+                _lib.check(l.objnerf_pos_encode_block(_lib.ptr(ps.xyz), 3, P, 3, exyz.N_freqs, _lib.ptr(_freqs_dev(exyz, dev)),
+                                                      _lib.ptr(ps.emb_xyz), arch.in_xyz, st), "pe")
+            ps.emb_dir = _repeat(emb_dir_ray, Sx)
+            ps.code_pts = _repeat(codes_c, Sx) if fi else None
+            ps.sigma, ps.rgb = _empty(P, dev=dev), _empty(P, 3, dev=dev)
+            ps.isig, ps.irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
+            ps.ws = _empty(l.objnerf_mlp_generic_train_workspace_floats(C.byref(arch), P), dev=dev)
+            ps.noise, ps.noise_i = noise, noise_i
+            ga, keep = _generic_train_args(arch, ps, pp, fi)
+            _lib.check(l.objnerf_mlp_generic_train_forward(C.byref(ga), st), "mlp_generic_train_forward")
+            outs = {"weights": _empty(n, Sx, dev=dev), "opacity": _empty(n, dev=dev), "rgb": _empty(n, 3, dev=dev), "depth": _empty(n, dev=dev)}
+            if fi:
+                outs.update({"rgb_instance": _empty(n, 3, dev=dev), "depth_instance": _empty(n, dev=dev), "opacity_instance": _empty(n, dev=dev)})
+            ca = _composite_args(meta, ps, outs)
+            _lib.check(l.objnerf_composite(C.byref(ca), st), "composite")
+            return ps, outs
+
+        z_c = _empty(n, S, dev=dev)
+        pr = rnd.get("perturb_rand") if meta["perturb"] > 0 else None
+        _lib.check(l.objnerf_sample_coarse(_lib.ptr(rays_c), _lib.ptr(meta["z_steps"]), _lib.ptr(pr) if pr is not None else None,
+                                           float(meta["perturb"]), int(meta["use_disp"]), n, S, _lib.ptr(z_c), st), "sample_coarse")
+        nz = rnd.get("noise", [None] * 4)
+        passes, results = [], {}
+        ps, outs = run_pass(mc, z_c, p_c, nz[0], nz[1])
+        passes.append(ps)
+        results.update({"%s_coarse" % k: v for k, v in outs.items()})
+        results["z_vals_coarse"] = z_c
+        if I > 0:
+            z_f = _empty(n, S + I, dev=dev)
+            det = meta["perturb"] == 0
+            u = meta["u_det"] if det else rnd["u_rand"]
+            _lib.check(l.objnerf_sample_pdf_merge(_lib.ptr(z_c), _lib.ptr(outs["weights"]), _lib.ptr(u), 0 if det else I, n, S, I, 1e-5, None,
+                                                  _lib.ptr(z_f), st), "sample_pdf_merge")
+            ps, outs = run_pass(mf, z_f, p_f, nz[2], nz[3])
+            passes.append(ps)
+            results.update({"%s_fine" % k: v for k, v in outs.items()})
+            results["z_vals_fine"] = z_f
+        keys = sorted(results)
+        ctx.meta, ctx.passes, ctx.keys, ctx.arch = meta, passes, keys, arch
+        ctx.p_c, ctx.p_f, ctx.rays_c = p_c, p_f, rays_c
+        ctx.table_shape = table.shape if table is not None else None
+        ctx.n_params, ctx.code_c = len(params), codes_c.shape[1]
+        out = tuple(results[k] for k in keys)
+        ctx.mark_non_differentiable(*[results[k] for k in keys if k.startswith(("weights_", "z_vals_"))])
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .autograd import _MAPS, _composite_args, _empty, _ptr_table
+        l = _lib.lib()
+        st = _lib.stream_ptr()
+        meta, arch = ctx.meta, ctx.arch
+        fi, vox = meta["forward_instance"], meta["use_voxel"]
+        exyz = meta["emb_xyz"]
+        dev = ctx.rays_c.device
+        n = ctx.rays_c.shape[0]
+        g = dict(zip(ctx.keys, grads))
+        d_table = torch.zeros(ctx.table_shape, dtype=torch.float32, device=dev) if vox else None
+        d_codes = torch.zeros(n, ctx.code_c, dtype=torch.float32, device=dev) if fi else None
+        all_grads = []
+        for typ, ps, pp in zip(("coarse", "fine"), ctx.passes, (ctx.p_c, ctx.p_f)):
+            gp = [torch.zeros_like(p) for p in pp]
+            all_grads.append(gp)
+            P, Sx = ps.emb_xyz.shape[0], ps.S
+            gm_t = {k: (_lib.as_f32(g["%s_%s" % (k, typ)]) if g.get("%s_%s" % (k, typ)) is not None else None) for k in _MAPS}
+            if all(v is None for v in gm_t.values()):
+                continue
+            d_sigma, d_rgb = _empty(P, dev=dev), _empty(P, 3, dev=dev)
+            d_isig, d_irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
+            ca = _composite_args(meta, ps)
+            _lib.check(l.objnerf_composite_backward(
+                C.byref(ca), _lib.ptr(gm_t["rgb"]), _lib.ptr(gm_t["depth"]), _lib.ptr(gm_t["opacity"]), _lib.ptr(gm_t["rgb_instance"]),
+                _lib.ptr(gm_t["depth_instance"]), _lib.ptr(gm_t["opacity_instance"]), _lib.ptr(d_sigma), _lib.ptr(d_rgb), _lib.ptr(d_isig),
+                _lib.ptr(d_irgb), st), "composite_backward")
+            ga, keep = _generic_train_args(arch, ps, pp, fi)
+            gtable = _ptr_table(gp)
+            emb_cols = 0
+            d_emb = d_ov = d_code = None
+            if vox:
+                F = exyz.N_freqs
+                cs, co = exyz.channels - exyz.instance_ftr_C, exyz.instance_ftr_C
+                emb_cols = cs * (2 * F + 1)
+                d_emb = _empty(P, emb_cols, dev=dev)
+            if fi and arch.obj_voxel_c > 0:
+                d_ov = _empty(P, arch.obj_voxel_c, dev=dev)
+            if fi and arch.code_c > 0:
+                d_code = _empty(P, arch.code_c, dev=dev)
+            scratch = _empty(l.objnerf_mlp_generic_train_scratch_floats(C.byref(arch), P), dev=dev)
+            _lib.check(l.objnerf_mlp_generic_train_backward(C.byref(ga), _lib.ptr(d_sigma), _lib.ptr(d_rgb), _lib.ptr(d_isig), _lib.ptr(d_irgb),
+                                                            gtable, _lib.ptr(d_emb), emb_cols, _lib.ptr(d_ov), _lib.ptr(d_code),
+                                                            _lib.ptr(scratch), st), "mlp_generic_train_backward")
+            if vox:
+                C_ = exyz.channels
+                d_raw = torch.zeros(P, C_, dtype=torch.float32, device=dev)
+                _lib.check(l.objnerf_pos_encode_block_backward(C.c_void_p(ps.raw.data_ptr()), C_, P, cs, F, None, _lib.ptr(d_emb), emb_cols,
+                                                               C.c_void_p(d_raw.data_ptr()), C_, st), "pe_backward")
+                if d_ov is not None:
+                    _lib.check(l.objnerf_pos_encode_block_backward(C.c_void_p(ps.raw.data_ptr() + 4 * cs), C_, P, co, F, None, _lib.ptr(d_ov),
+                                                                   arch.obj_voxel_c, C.c_void_p(d_raw.data_ptr() + 4 * cs), C_, st), "pe_backward")
+                _lib.check(l.objnerf_voxel_features_backward(C.byref(meta["grid"]), C_, _lib.ptr(ps.xyz), P, _lib.ptr(d_raw), C_,
+                                                             _lib.ptr(d_table), st), "voxel_features_backward")
+            if d_code is not None:
+                _lib.check(l.objnerf_sum_over_samples(_lib.ptr(d_code), n, Sx, arch.code_c, _lib.ptr(d_codes), st), "sum_over_samples")
+        flat = list(all_grads[0]) + (list(all_grads[1]) if len(all_grads) > 1 else [])
+        flat += [None] * (ctx.n_params - len(flat))
+        return (None, None, d_codes, d_table, *flat)
+
+
+def _generic_train_args(arch, ps, params, fi):
+    g = _lib.MlpGenericArgs()
+    g.arch = arch
+    tab = (C.c_void_p * len(params))(*[t.data_ptr() for t in params])
+    g.h_params = tab
+    g.do_scene, g.do_object, g.sigma_only, g.n_points = 1, int(fi), 0, ps.emb_xyz.shape[0]
+    g.emb_xyz, g.emb_dir = ps.emb_xyz.data_ptr(), ps.emb_dir.data_ptr()
+    g.sigma, g.rgb = ps.sigma.data_ptr(), ps.rgb.data_ptr()
+    if fi:
+        g.inst_sigma, g.inst_rgb = ps.isig.data_ptr(), ps.irgb.data_ptr()
+        if arch.code_c > 0:
+            g.obj_code = ps.code_pts.data_ptr()
+        if arch.obj_voxel_c > 0:
+            g.obj_voxel = ps.obj_voxel.data_ptr()
+    g.workspace = ps.ws.data_ptr()
+    return g, tab
+
+
+def train_param_list(model):
+    """the model's parameters in objnerf_arch_num_param_ptrs() order (weight, bias pairs)"""
+    mods = dict(model.named_modules())
+    names = ["xyz_encoding_%d.0" % (i + 1) for i in range(model.D)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"]
+    names += ["instance_encoding_%d.0" % (i + 1) for i in range(model.inst_D)] + [
+        "instance_encoding_final.0", "inst_dir_encoding.0", "instance_sigma", "inst_rgb.0"]
+    out = []
+    for nme in names:
+        out += [mods[nme].weight, mods[nme].bias]
+    return out

@@ -188,10 +188,11 @@ def render_rays(
 
     # ---- any architecture other than the shipped default: the same pipeline stage by stage (generic.py) ----
     if not fused_path_ok(models, embeddings, I > 0):
-        if torch.is_grad_enabled() and (embedding_instance.requires_grad or any(p.requires_grad for m in models.values() for p in m.parameters())):
-            raise NotImplementedError(
-                "object_nerf_amd.render_rays: training (autograd) is built for the default architecture only "
-                "(config/default_conf.yml:7-36); a non-default config.model shape renders under torch.no_grad()")
+        from . import generic
+        gtable = emb_xyz.embedding_space_ftr.weight if use_voxel else None
+        gplist = generic.train_param_list(coarse) + (generic.train_param_list(models["fine"]) if I > 0 else [])
+        wants_grad = torch.is_grad_enabled() and (embedding_instance.requires_grad or any(p.requires_grad for p in gplist)
+                                                  or (gtable is not None and gtable.requires_grad))
         from . import generic
         rnd = dict(randoms) if randoms else {}
         if perturb > 0:
@@ -202,6 +203,20 @@ def render_rays(
             rnd["noise"] = [torch.randn(n, S, device=dev), torch.randn(n, S, device=dev),
                             torch.randn(n, S + I, device=dev), torch.randn(n, S + I, device=dev)]
         rnd = {k: ([_lib.as_f32(t) for t in v] if isinstance(v, (list, tuple)) else _lib.as_f32(v)) for k, v in rnd.items()}
+        if wants_grad:
+            # training a non-default architecture: the same stages with every layer's activations kept + their backward
+            meta = dict(S=S, I=I, use_voxel=use_voxel, forward_instance=bool(forward_instance), use_disp=bool(use_disp),
+                        perturb=float(perturb), noise_std=float(noise_std), white_back=bool(white_back), is_eval=is_eval,
+                        use_zero_as_last_delta=use_zero_as_last_delta, frustum_bound_th=float(frustum_bound_th),
+                        rays_in_bbox=bool(rays_in_bbox), randoms=rnd, z_steps=_linspace(S, dev),
+                        u_det=_linspace(I, dev) if I > 0 else None, grid=emb_xyz.grid_struct() if use_voxel else None,
+                        ptm=pass_through_mask.reshape(n).to(torch.uint8).contiguous() if pass_through_mask is not None else None,
+                        models=(coarse, models["fine"] if I > 0 else None), emb_xyz=emb_xyz, emb_dir=embeddings["dir"])
+            outs = generic.RenderRaysGenericFn.apply(meta, rays_c, embedding_instance, gtable, *gplist)
+            keys = sorted(["%s_%s" % (k, t) for t in (("coarse", "fine") if I > 0 else ("coarse",))
+                           for k in (["weights", "opacity", "z_vals", "rgb", "depth"]
+                                     + (["rgb_instance", "depth_instance", "opacity_instance"] if forward_instance else []))])
+            return dict(zip(keys, outs))
         flags = dict(use_disp=bool(use_disp), perturb=float(perturb), noise_std=float(noise_std), white_back=bool(white_back),
                      forward_instance=bool(forward_instance), is_eval=is_eval, use_zero_as_last_delta=use_zero_as_last_delta,
                      frustum_bound_th=float(frustum_bound_th), rays_in_bbox=bool(rays_in_bbox),

@@ -55,9 +55,6 @@ def test_render_rays_on_another_architecture_matches_the_reference(name):
             assert moved <= moved64 + 1
             assert H.psnr(out["rgb_fine"], g[pre + "rgb_fine"]) >= 60.0
             print(name, pre, "; ".join(rep))
-    # training a non-default shape is refused loudly (the differentiable kernels are built for the default architecture)
-    with pytest.raises(NotImplementedError, match="default architecture"):
-        A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, perturb=0, noise_std=0, **base)
 
 
 def test_render_rays_multi_on_another_architecture_matches_the_reference():
@@ -147,3 +144,90 @@ def test_default_architecture_through_the_layerwise_path_agrees_with_the_fused_k
         floor = H.normwise(g[k], f64[k])
         tol = max(H.FLOOR_FACTOR * floor, 2e-5) if k.endswith("fine") else 1e-4
         assert H.normwise(lw[k], g[k]) <= tol, "layer-wise path vs reference: %s %.3e (floor %.3e)" % (k, H.normwise(lw[k], g[k]), floor)
+
+
+def _loss(res, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    tot = 0.0
+    for k in sorted(res):
+        if k.startswith(("weights_", "z_vals_")):
+            continue
+        tot = tot + (res[k] * torch.randn(res[k].shape, generator=g).to(res[k].device)).sum()
+    return tot
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("name", sorted(cases.ARCH_SCENES))
+def test_training_another_architecture_matches_autograd_through_the_oracle(name):
+    """`render_rays` with autograd recording on a non-default config.model shape: the layer-wise training path
+    (generic.RenderRaysGenericFn: activations of every layer kept, dgrad GEMMs with the LeakyReLU backward in the epilogue,
+    split-K weight gradients, positional-encoding / trilinear backward into a 12 + 8 channel table, per-ray code sums) against
+    PyTorch autograd through the oracle at teacher-forced fine depths: every parameter of both models, the voxel table, the codes."""
+    sc = cases.scene_for(A, name, device=DEV)          # a fresh scene: gradients accumulate on its parameters
+    use_voxel = cases.ARCH_SCENES[name][0]
+    arch = cases.oracle_arch(name)
+    rays, ids, ptm, _, _ = cases.arch_inputs(name)
+    S, I = 12, 20
+    kw = dict(N_samples=S, N_importance=I, perturb=0, noise_std=0, is_eval=False, frustum_bound_th=0.025)
+    codes = sc.code_library({"instance_ids": ids.to(DEV)})["embedding_instance"]
+    res = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, pass_through_mask=ptm.to(DEV), **kw)
+    assert all(res[k].requires_grad for k in res if k.startswith("rgb_"))
+    _loss(res).backward()
+
+    def prep(sd):
+        return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sd.items()}
+    pc, pf = prep(sc.models["coarse"].state_dict()), prep(sc.models["fine"].state_dict())
+    ctab = sc.code_library.embedding_instance.weight.detach().cpu().clone().requires_grad_(True)
+    grid = None
+    if use_voxel:
+        grid = H.oracle_grid(sc.embeddings["xyz"])
+        grid["table"] = grid["table"].clone().requires_grad_(True)
+    ro = O.render_rays(pc, pf, grid, rays, embedding_instance=ctab[ids], pass_through_mask=ptm, arch=arch,
+                       z_fine_override=res["z_vals_fine"].detach().cpu(), **kw)
+    _loss(ro).backward()
+    for k in ro:
+        assert H.normwise(res[k], ro[k]) < 1e-4, k
+    errs = {}
+    for typ, mod, ref in (("coarse", sc.models["coarse"], pc), ("fine", sc.models["fine"], pf)):
+        for pname, p in mod.named_parameters():
+            assert p.grad is not None, pname
+            if ref[pname].grad is None:
+                assert p.grad.abs().max().item() == 0, pname
+                continue
+            errs["%s.%s" % (typ, pname)] = _rel_l2(p.grad, ref[pname].grad)
+    errs["codes"] = _rel_l2(sc.code_library.embedding_instance.weight.grad, ctab.grad)
+    if use_voxel:
+        errs["voxel table"] = _rel_l2(sc.embeddings["xyz"].embedding_space_ftr.weight.grad, grid["table"].grad)
+    print(name, "worst parameter-gradient rel L2 error %.2e over %d tensors" % (max(errs.values()), len(errs)))
+    for k, e in errs.items():
+        assert e < 2e-4, "%s: rel L2 grad error %.3e" % (k, e)
+
+
+def test_layerwise_training_path_agrees_with_the_fused_training_kernels(monkeypatch):
+    """the DEFAULT architecture trained through both differentiable paths (OBJNERF_PATH=layerwise: generic.hip's GEMM chain;
+    default: the fused forward / dgrad-chain / grouped weight-gradient kernels): same forward values, same gradients"""
+    rays = H.test_rays(24, stride=97)
+    ids = synth_ids = __import__("object_nerf_amd").synth.per_ray_ids(24, seed=5)
+    ptm = (torch.arange(24) % 3 == 0).view(24, 1)
+    kw = dict(N_samples=16, N_importance=16, perturb=0, noise_std=0, is_eval=False, frustum_bound_th=0.025)
+    grads = {}
+    for path in ("fused", "layerwise"):
+        monkeypatch.setenv("OBJNERF_PATH", path)
+        sc = cases.scene_for(A, "voxel", device=DEV)
+        codes = sc.code_library({"instance_ids": ids.to(DEV)})["embedding_instance"]
+        res = A.render_rays(sc.models, sc.embeddings, rays.to(DEV), embedding_instance=codes, pass_through_mask=ptm.to(DEV), **kw)
+        _loss(res).backward()
+        g = {"%s.%s" % (t, n): p.grad.clone() for t in ("coarse", "fine") for n, p in sc.models[t].named_parameters()}
+        g["codes"] = sc.code_library.embedding_instance.weight.grad.clone()
+        g["table"] = sc.embeddings["xyz"].embedding_space_ftr.weight.grad.clone()
+        grads[path] = (g, {k: v.detach().clone() for k, v in res.items()})
+    for k in grads["fused"][1]:
+        if k.endswith("coarse"):
+            assert H.normwise(grads["layerwise"][1][k], grads["fused"][1][k]) < 2e-5, k
+    worst = max(_rel_l2(grads["layerwise"][0][k], grads["fused"][0][k]) for k in grads["fused"][0] if k.startswith("coarse.") or k in ("codes",))
+    print("layer-wise vs fused training path, coarse-model gradients: worst rel L2 %.2e" % worst)
+    assert worst < 2e-4
