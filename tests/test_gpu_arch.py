@@ -227,7 +227,7 @@ def test_layerwise_training_path_agrees_with_the_fused_training_kernels(monkeypa
         grads[path] = (g, {k: v.detach().clone() for k, v in res.items()})
     for k in grads["fused"][1]:
         if k.endswith("coarse"):
-            assert H.normwise(grads["layerwise"][1][k], grads["fused"][1][k]) < 2e-5, k
+            assert H.normwise(grads["layerwise"][1][k], grads["fused"][1][k]) < 1e-4, k
     worst = max(_rel_l2(grads["layerwise"][0][k], grads["fused"][0][k]) for k in grads["fused"][0] if k.startswith("coarse.") or k in ("codes",))
     print("layer-wise vs fused training path, coarse-model gradients: worst rel L2 %.2e" % worst)
     assert worst < 2e-4
