@@ -526,9 +526,6 @@ def run(args, renderer=None, backend="nccl", argv=None):
         if args.one_gpu:
             res["config"]["one_gpu"] = ("all %d ranks share cuda:0, collectives over gloo with host-staged messages: a run of the "
                                         "N > 1 code path on a one-GPU box, not a scaling measurement" % world)
-    if rank == 0 and lib is not None:
-        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and args.as_rank is None)     # every config at N = 1
-        res["roofline"].update(pmc_traffic(args, cfg_id, live=want_pmc and dist is None))
     if rank == 0 and args.as_rank is not None:
         res["config"]["as_rank"] = list(args.as_rank)       # this line is ONE rank's share of a WORLD-rank frame, rendered alone
     if rank == 0 and world == 1 and args.cpu_rays > 0 and args.as_rank is None:
@@ -537,6 +534,23 @@ def run(args, renderer=None, backend="nccl", argv=None):
     if rank == 0:
         res["config"]["mean_" + wl.gather_keys[0]] = float(out[wl.gather_keys[0]].double().mean().item())   # float64: independent of layout / reduction order
         res["config"]["bits_" + wl.gather_keys[0]] = bit_sum(out[wl.gather_keys[0]])
+    if rank == 0 and lib is not None:
+        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and args.as_rank is None)     # every config at N = 1
+        live = want_pmc and dist is None
+        if live:
+            # the counter passes are child processes of their own: hand this process's device memory back first (everything the
+            # line needs has been computed), so that the children see the GPU a stand-alone `tools/pmc_run.sh` sees -- measured
+            # with the parent's scenes and caching-allocator blocks still resident, the same passes read 3.8-5.9 GB per launch
+            # against 3.5-3.6 GB stand-alone in the same session
+            import gc
+            out = None
+            wl.last = wl.sc = None
+            if hasattr(wl, "rays"):
+                wl.rays = wl.codes = None
+            gc.collect()
+            torch.cuda.empty_cache()
+        res["roofline"].update(pmc_traffic(args, cfg_id, live=live))
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -720,8 +734,8 @@ def pmc_traffic(args, cfg_id, live):
         try:
             base = tempfile.mkdtemp(prefix="objnerf_pmc_", dir="/tmp")
             child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg_id), "--width", str(args.width),
-                     "--height", str(args.height), "--max-voxels", str(args.max_voxels), "--steps", "1", "--warmup", "0",
-                     "--cpu-rays", "0", "--split-bf16-steps", "0", "--pmc", "off", "--pmc-child"]
+                     "--height", str(args.height), "--max-voxels", str(args.max_voxels), "--steps", "1", "--warmup", "1",
+                     "--cpu-rays", "0", "--split-bf16-steps", "0", "--train-steps", "0", "--pmc", "off", "--pmc-child"]
             tot = {}
             t0 = time.perf_counter()
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -746,7 +760,8 @@ def pmc_traffic(args, cfg_id, live):
             log("PMC passes: %.1f s" % (time.perf_counter() - t0))
             return {"traffic": fetch + write, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KB -> B)",
                     "traffic_fetch_bytes_per_launch": fetch, "traffic_write_bytes_per_launch": write,
-                    "traffic_source": "rocprofv3 --pmc passes run by this bench.py invocation (1 step each)"}
+                    "traffic_source": "rocprofv3 --pmc passes run by this bench.py invocation (1 warm-up + 1 step each, averaged "
+                                      "over the kernel's launches)"}
         except Exception as e:
             log("live PMC collection failed (%s: %s); using the committed profile" % (type(e).__name__, e))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))

@@ -30,6 +30,7 @@ def main(pmc_dir, out_json, evals=58982400, mfma_per_32=13536):
             wall = sum(e - s for s, e in per_dispatch.values()) * 1e-9
             launches = len(per_dispatch)
     g = sums.get
+    evals = evals * launches / 2.0          # `evals` is per frame = two launches; a pass with a warm-up frame has four
     mfma = g("SQ_INSTS_MFMA", 0.0)
     d = {"launches_per_pass": launches, "mfma_instructions": mfma, "mfma_instructions_expected": evals / 32.0 * mfma_per_32,
          "kernel_wall_s_all_launches": wall}
@@ -55,7 +56,8 @@ def main(pmc_dir, out_json, evals=58982400, mfma_per_32=13536):
         d["write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0 / launches
         d["hbm_traffic_bytes_per_launch"] = d["fetch_bytes_per_launch_corrected_x2"] + d["write_bytes_per_launch"]
         d["hbm_traffic_bytes_per_eval"] = d["hbm_traffic_bytes_per_launch"] * launches / evals
-    json.dump({"workload": "python bench.py --steps 1 --warmup 0 --cpu-rays 0 (one 640x480 frame, 64 + 64, scene + object, voxel)",
+    json.dump({"workload": "python bench.py --steps 1 --warmup 1 --cpu-rays 0 (640x480 frames, 64 + 64, scene + object, voxel; counters summed over "
+                           "the kernel's launches of a pass)",
                "raw_sum_over_launches": sums, "derived": d}, open(out_json, "w"), indent=1)
     print(json.dumps(d, indent=1))
 
