@@ -56,7 +56,9 @@
 #define OBJ_PREFETCH_SCENE 1 // density query, scene branch: gather prologue of the NEXT tile staged on the chunk barriers of xyz_encoding_1
 #endif
 #ifndef OBJ_XCD_TILES
-#define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers)
+#define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers); 1: its
+                             // workgroups walk it side by side (shipped), 2: each workgroup walks its own contiguous run of it
+                             // (round 4, measured: the counter's fetch per launch 4.8 -> 9.2 GB, time equal -- rejected)
 #endif
 #ifndef OBJ_SPREAD_DMA
 #define OBJ_SPREAD_DMA 1     // fp32 stream: weight DMA pieces issued between the MFMA groups instead of as a burst
@@ -1108,10 +1110,24 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   const bool by_xcd = false;
 #endif
   const long tiles_per_xcd = (ntiles + 7) / 8;
+#if OBJ_XCD_TILES == 2
+  // Tuning variant (round 4, NOT shipped): inside its eighth every workgroup walks its OWN contiguous run, so that the XCD's 32
+  // workgroups hold pixels of ~32 different image rows at about the same column (a strip compact in both image directions)
+  // instead of 32-64 horizontally neighbouring pixels of one row.  Measured on the headline frame (tools/xcd_ab.sh,
+  // profiles/r04_xcd_ab.txt): time equal, memory-side fetch per launch 4.8 -> 9.2 GB -- 32 workgroups each streaming their own
+  // table rows turn the 0.4 MB of L2 the weight stream leaves free over faster than 64 neighbouring rays that share most rows.
+  const long wgs_per_xcd = gridDim.x >> 3;
+  const long run = by_xcd ? (tiles_per_xcd + wgs_per_xcd - 1) / wgs_per_xcd : 0;
+  const long xcd_end = by_xcd ? (((blockIdx.x & 7) + 1) * tiles_per_xcd < ntiles ? ((blockIdx.x & 7) + 1) * tiles_per_xcd : ntiles) : ntiles;
+  const long tile_first = by_xcd ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) * run : blockIdx.x;
+  const long tile_step = by_xcd ? 1 : gridDim.x;
+  const long tile_end = by_xcd ? (tile_first + run < xcd_end ? tile_first + run : xcd_end) : ntiles;
+#else
   const long tile_first = by_xcd ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   const long tile_step = by_xcd ? (gridDim.x >> 3) : gridDim.x;
   const long tile_end = by_xcd ? (((blockIdx.x & 7) + 1) * tiles_per_xcd < ntiles ? ((blockIdx.x & 7) + 1) * tiles_per_xcd : ntiles)
                                : ntiles;
+#endif
   // a workgroup without a tile (the grid is sized for all n_rays, a culled ray subset may need far fewer): leave before
   // the weight DMA, the aux staging and the first gather prologue are issued -- uniform per workgroup
   if (tile_first >= tile_end) return;
