@@ -760,6 +760,10 @@ def pmc_traffic(args, cfg_id, live):
             log("PMC passes: %.1f s" % (time.perf_counter() - t0))
             return {"traffic": fetch + write, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KB -> B)",
                     "traffic_fetch_bytes_per_launch": fetch, "traffic_write_bytes_per_launch": write,
+                    "traffic_note": "L2 -> fabric requests (Infinity-Cache hits included, MI355X_MICROARCH.md), not DRAM bytes: mostly "
+                                    "voxel-table rows re-requested after the 4 MB L2 (3.55 MB of it the weight stream) turned over, "
+                                    "plus the per-ray vectors counted twice by the x2 correction.  Varies 3.5-5.9 GB per launch between "
+                                    "boxes / sessions at identical kernel time; the kernel is MFMA-bound (~10 GB/s of this traffic)",
                     "traffic_source": "rocprofv3 --pmc passes run by this bench.py invocation (1 warm-up + 1 step each, averaged "
                                       "over the kernel's launches)"}
         except Exception as e:
