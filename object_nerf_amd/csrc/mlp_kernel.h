@@ -833,6 +833,7 @@ struct TilePrologue {
       return;
     }
     long slot = pc / a.S;
+    sidx = (int)(pc - slot * a.S);                                   // the point's sample index inside its ray
     if (a._strip_w > 0) {      // uniform: image-ordered rays visited in column strips (objnerf_mlp_args.row_width)
       const long band = (long)a.row_width * a._strip_rows;          // rays of one XCD's eighth = whole image rows
       const long b = slot / band, vb = slot - b * band;
@@ -844,7 +845,6 @@ struct TilePrologue {
     // ray subset (objnerf_mlp_args.ray_index): tiles walk the listed rays only; p stays the point's index in the
     // full (n_rays, S) arrays, so depths are read and results written in place
     ray = a.ray_index ? (long)a.ray_index[slot] : slot;
-    sidx = (int)(pc - slot * a.S);
     p = ray * a.S + sidx;
     const float* r = a.rays + ray * 8;
 #pragma unroll
