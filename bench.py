@@ -269,9 +269,10 @@ class Workload:
                            forward_instance=fi, frustum_bound_th=self.preset["frustum_bound_th"], is_eval=True)
             if cfg_id in (2, 3):
                 self.kw["rays_in_bbox"] = True
-            if (scaling != "strong" or world == 1) and os.environ.get("OBJNERF_BENCH_ROW_HINT", "1") != "0":
-                # the batch is a whole frame in row-major pixel order: tell the renderer (a scheduling hint -- rays are visited in
-                # column strips so that vertically neighbouring pixels' table rows meet in L2 --, results are bit-equal without it)
+            if (scaling != "strong" or world == 1) and os.environ.get("OBJNERF_BENCH_ROW_HINT", "0") == "1":
+                # opt-in A/B switch (tools/row_hint_ab.sh): the batch is a whole frame in row-major pixel order; with the hint the
+                # renderer visits rays in column strips.  Results are bit-equal; measured: no effect on time or on the fetch
+                # counter (profiles/r04_nt_ab.txt), so the headline runs without it
                 self.kw["row_width"] = self.W
             self.flop_per_eval = FLOP_BOTH if fi else FLOP_SCENE
             self.evals_rank = float(self.n_local) * (self.S + (self.S + self.I if self.I > 0 else 0))
@@ -765,9 +766,9 @@ def pmc_traffic(args, cfg_id, live):
             return {"traffic": fetch + write, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KB -> B)",
                     "traffic_fetch_bytes_per_launch": fetch, "traffic_write_bytes_per_launch": write,
                     "traffic_note": "L2 -> fabric requests (Infinity-Cache hits included, MI355X_MICROARCH.md), not DRAM bytes: mostly "
-                                    "voxel-table rows re-requested after the 4 MB L2 (3.55 MB of it the weight stream) turned over, "
-                                    "plus the per-ray vectors counted twice by the x2 correction.  Varies 3.5-5.9 GB per launch between "
-                                    "boxes / sessions at identical kernel time; the kernel is MFMA-bound (~10 GB/s of this traffic)",
+                                    "misses of the 3.55 MB weight stream every tile replays out of the 4 MB L2 (0.2-0.4 % of 0.5-1.1 TB of "
+                                    "L2 reads per launch).  Varies 1.7-4.5 GB per launch between identical runs (physical placement of "
+                                    "the weight pages); the kernel is MFMA-bound (~7 GB/s of this traffic), profiles/r04_nt_ab.txt",
                     "traffic_source": "rocprofv3 --pmc passes run by this bench.py invocation (1 warm-up + 1 step each, averaged "
                                       "over the kernel's launches)"}
         except Exception as e:

@@ -549,10 +549,46 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT])
 
 // HOIST: per-ray vectors (objnerf_mlp_args.ray_bias, aux-bias layout [m][half][16]) and the epilogue that adds them
 constexpr int kRbO1 = 0, kRbO3 = 128, kRbSD = 256, kRbOD = 384;
+#ifndef OBJ_NT_TABLE
+#define OBJ_NT_TABLE 1       // feature-table rows with the non-temporal hint as well (A/B: profiles/r04_nt_ab.txt)
+#endif
+#ifndef OBJ_NT_IDX
+#define OBJ_NT_IDX 0         // ... and the corner -> row index map
+#endif
+__device__ __forceinline__ f32x4 table_load(const float* p) {
+#if OBJ_NT_TABLE
+  return __builtin_nontemporal_load((const f32x4*)p);
+#else
+  return *(const f32x4*)p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ T idx_load(const T* p) {
+#if OBJ_NT_IDX
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+#ifndef OBJ_NT_RAYVEC
+#define OBJ_NT_RAYVEC 1      // per-ray vectors (550 MB per pass, read once per wave) fetched with the non-temporal hint
+#endif
 template <int NT>
 __device__ __forceinline__ void load_rb(f32x16 (&dst)[NT], const float* p) {
 #pragma unroll
-  for (int m = 0; m < NT; ++m) dst[m] = *(const f32x16*)(p + m * 32);
+  for (int m = 0; m < NT; ++m) {
+#if OBJ_NT_RAYVEC
+    // streamed once per wave: must not push the weight stream (3.55 MB of the XCD's 4 MB L2, replayed by every tile) out --
+    // a 0.4 % miss rate of THAT stream is what the memory-side counters mostly see (profiles/r04_pmc.md)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = __builtin_nontemporal_load((const f32x4*)(p + m * 32 + 4 * q));
+      dst[m][4 * q] = v[0]; dst[m][4 * q + 1] = v[1]; dst[m][4 * q + 2] = v[2]; dst[m][4 * q + 3] = v[3];
+    }
+#else
+    dst[m] = *(const f32x16*)(p + m * 32);
+#endif
+  }
 }
 template <int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT]) {
@@ -872,7 +908,7 @@ struct TilePrologue {
       for (int k = 0; k < 8; ++k) {
         const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
         const bool ok = cx >= 0.f && cx < X && cy >= 0.f && cy < Y && cz >= 0.f && cz < Z;
-        idx[k] = ok ? g.idx_map[((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz] : -1;
+        idx[k] = ok ? idx_load(g.idx_map + (((size_t)(int)cx * g.shape[1] + (int)cy) * g.shape[2] + (int)cz)) : -1;
       }
     }
   }
@@ -886,9 +922,9 @@ struct TilePrologue {
         const int row = (r < 0 || r >= g.n_rows) ? -1 : r;
         idx[4 * H + j] = row;
         const float* t = g.table + (size_t)(row < 0 ? 0 : row) * kVoxC;
-        rows[3 * j + 0] = *(const f32x4*)(t + half * 8);
-        rows[3 * j + 1] = *(const f32x4*)(t + half * 8 + 4);
-        rows[3 * j + 2] = *(const f32x4*)(t + kScnVoxC + half * 4);
+        rows[3 * j + 0] = table_load(t + half * 8);
+        rows[3 * j + 1] = table_load(t + half * 8 + 4);
+        rows[3 * j + 2] = table_load(t + kScnVoxC + half * 4);
       }
     }
   }
@@ -921,9 +957,9 @@ struct TilePrologue {
         const int row = (r < 0 || r >= g.n_rows) ? -1 : r;
         idx[2 * Q + j] = row;
         const float* t = g.table + (size_t)(row < 0 ? 0 : row) * kVoxC;
-        rows[3 * j + 0] = *(const f32x4*)(t + half * 8);
-        rows[3 * j + 1] = *(const f32x4*)(t + half * 8 + 4);
-        rows[3 * j + 2] = *(const f32x4*)(t + kScnVoxC + half * 4);
+        rows[3 * j + 0] = table_load(t + half * 8);
+        rows[3 * j + 1] = table_load(t + half * 8 + 4);
+        rows[3 * j + 2] = table_load(t + kScnVoxC + half * 4);
       }
     }
   }
