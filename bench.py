@@ -53,6 +53,10 @@ import subprocess
 import sys
 import time
 
+# the host driver supports dmabuf IPC only: RCCL needs this BEFORE the HIP runtime comes up (i.e. before `import torch`
+# touches the device), not just before init_process_group
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
@@ -630,7 +634,10 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
         if dist is not None and world > 1:
             broadcast_parameters(params + [b for m in mods for b in m.buffers()], src=0)
         rays_all = synth.camera_rays(args.width, args.height).to(dev)
-        opt = torch.optim.Adam(params, lr=1e-3)
+        # the reference builds torch.optim.Adam(parameters, lr, eps, weight_decay) (utils/__init__.py:36-38); `fused=True` is the
+        # same update in one multi-tensor kernel instead of five (OBJNERF_BENCH_ADAM=foreach restores torch's default)
+        fused = torch.device(dev).type == "cuda" and os.environ.get("OBJNERF_BENCH_ADAM", "fused") == "fused"
+        opt = torch.optim.Adam(params, lr=1e-3, fused=fused)
         table = sc.embeddings["xyz"].embedding_space_ftr.weight
         sync = GradientSync(params, active_rows={table: sc.embeddings["xyz"].active_rows()})
         g = torch.Generator(device=dev).manual_seed(rank)
@@ -656,16 +663,21 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
             step()
         fence()
         t0 = time.perf_counter()
+        host = 0.0                                   # host time spent ENQUEUEING (waits at the synchronisations excluded)
         for i in range(args.train_steps):
+            th = time.perf_counter()
             loss = step()
+            host += time.perf_counter() - th
             if i % 8 == 7:
                 torch.cuda.synchronize()
         fence()
         dt = allreduce(time.perf_counter() - t0, "MAX") / args.train_steps
+        host /= args.train_steps
         l1 = loss.item()
         evals = float(n_rays) * 192 * world
         tflops = evals * FLOP_BOTH * 3.0 / dt / 1e12
         return {"ms_per_step": 1e3 * dt, "steps": args.train_steps, "rays_per_rank": n_rays, "n_gpus": world,
+                "host_enqueue_ms_per_step": 1e3 * host,
                 "value": evals / dt, "unit": "ray-samples/s (forward + backward + Adam)",
                 "workload": "train.py:147-180 batch: %d rays x (64 coarse + 64 fine), perturb 1, noise_std 1, scene + object "
                             "branches, occlusion mask, voxel embedding, ScanNet-like scene, Adam on both MLPs + codes + voxel table"
@@ -676,6 +688,7 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
                                                 "step incl. sampling, compositing, gradient exchange and Adam"},
                 "gradient_exchange": ("GradientSync: %d flat all-reduce(s) of %s bytes" % (len(sync.buckets), sync.message_bytes()))
                                      if (dist is not None and world > 1) else "none (1 rank)",
+                "optimizer": "torch.optim.Adam(lr=1e-3, %s)" % ("fused=True" if fused else "foreach"),
                 "loss_first": l0, "loss_last": l1}
     except Exception as e:      # an optional leg must never cost the headline line
         return {"error": "%s: %s" % (type(e).__name__, e)}

@@ -33,6 +33,23 @@ PARAM_LAYERS = _SCENE_LAYERS + _OBJ_LAYERS
 
 _index_cache = {}   # (use_voxel, device) -> (blob_idx, aux_idx) uint32 device tensors
 
+# Parameter updates that do not bump `Tensor._version`: torch's FUSED optimizers (`Adam(fused=True)` writes the parameters
+# inside one multi-tensor kernel; measured: `_version` stays put, torch 2.10) -- the cached weight streams would go stale
+# silently.  Every torch.optim.Optimizer.step() therefore advances a process-wide epoch that is part of the cache key
+# (a re-gather costs a few microseconds of device time per model).
+_optimizer_epoch = [0]
+
+
+def _on_optimizer_step(*_args, **_kwargs):
+    _optimizer_epoch[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _register_step_hook(_on_optimizer_step)
+except ImportError:      # older torch: `_version` / invalidate_packed() are the only signals
+    pass
+
 
 def _pack_index(use_voxel, device):
     key = (bool(use_voxel), str(device))
@@ -138,7 +155,9 @@ class ObjectNeRF(nn.Module):
         """Drops the cached weight streams.  They are re-gathered automatically when a parameter's
         (data_ptr, _version) changes -- optimizer steps, load_state_dict, .to() -- but in-place writes made through
         `.data` (`p.data.copy_(w)`, EMA / weight-clipping code, some manual checkpoint loaders) do not bump
-        `_version`: call this after them.  OBJNERF_PACK_CHECK=1 adds a content checksum to the cache key (one small
+        `_version`: call this after them.  (Steps of any torch.optim.Optimizer -- fused ones included, which do not bump
+        `_version` either -- are seen through a global step hook, and the differentiable render_rays re-gathers on every
+        call.)  OBJNERF_PACK_CHECK=1 adds a content checksum to the cache key (one small
         reduction + host read per parameter set and call: a debugging aid, not for production)."""
         self._packed = self._packed_key = None
         self._packed_bwd = self._packed_bwd_key = None
@@ -153,7 +172,7 @@ class ObjectNeRF(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _pack_key(self, params):
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (_optimizer_epoch[0],)
         if os.environ.get("OBJNERF_PACK_CHECK") == "1":
             with torch.no_grad():
                 key += (float(sum(p.detach().double().sum() for p in params)),)

@@ -133,6 +133,11 @@ def _train_packs(coarse, fine):
 
     b3 = mfma_mode() == "bf16x3"      # split-bf16 arithmetic in the two fused kernels (the GEMMs stay fp32 MFMA)
 
+    # a training call never trusts the cache: whatever updated the parameters since the last call (a fused or third-party
+    # optimizer, `.data` writes) may not have bumped `_version`, and the weights change every step anyway
+    for m in {id(m): m for m in (coarse, fine) if m is not None}.values():
+        m.invalidate_packed()
+
     def one(m):
         if m is None:
             return None

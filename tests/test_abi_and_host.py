@@ -288,3 +288,20 @@ def test_library_never_allocates_or_synchronises():
     assert not hits, hits
     waits = [ln for ln in open(os.path.join(csrc, "api.hip")) if "hipEventSynchronize" in ln.split("//")[0]]
     assert len(waits) == 1            # objnerf_timing_read
+
+
+def test_weight_stream_cache_key_sees_fused_optimizer_steps():
+    """torch's fused optimizers update the parameters without bumping `Tensor._version` (checked here, so that the reason for
+    the global step hook stays visible): the cache key of the packed weight stream must change with every Optimizer.step()"""
+    m = A.ObjectNeRF(A.default_model_config())
+    params = m._param_list()
+    for fused in (False, True):
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=fused)
+        for p in m.parameters():
+            p.grad = torch.ones_like(p)
+        k0 = m._pack_key(params)
+        v0 = params[0]._version
+        opt.step()
+        assert m._pack_key(params) != k0
+        if fused and params[0]._version == v0:
+            assert m._pack_key(params)[:-1] == k0[:-1]      # ... and only the step hook saw it

@@ -182,13 +182,35 @@ def test_render_rays_gradients_match_oracle_autograd(case):
     print(case, "worst parameter-gradient rel L2 error %.2e" % worst)
 
 
-def test_training_step_updates_weights_and_repacks():
-    """an optimizer step on the HIP gradients changes the render, through the automatic weight repack"""
+class _DataSGD:
+    """an update the tensor version counters never see (`p.data` writes: EMA / clipping code, hand-written optimizers)"""
+
+    def __init__(self, params, lr):
+        self.params, self.lr = list(params), lr
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        for p in self.params:
+            if p.grad is not None:
+                p.data.add_(p.grad, alpha=-self.lr)
+
+
+@pytest.mark.parametrize("kind", ["adam_foreach", "adam_fused", "data_writes"])
+def test_training_step_updates_weights_and_repacks(kind):
+    """an optimizer step on the HIP gradients changes the render, through the automatic weight repack -- also when the
+    optimizer does not bump `Tensor._version` (torch's fused Adam: measured; `.data` writes): the training path re-gathers the
+    weight stream on every call, and inference after a torch optimizer's step sees it through the global step hook"""
     sc = cases.scene_for(A, "plain", device=DEV)
     rays = H.test_rays(32).to(DEV)
     ids = synth.per_ray_ids(32).to(DEV)
     params = [p for m in (sc.models["coarse"], sc.models["fine"], sc.code_library) for p in m.parameters()]
-    opt = torch.optim.Adam(params, lr=1e-3)
+    if kind == "data_writes":
+        opt = _DataSGD(params, lr=5e-2)
+    else:
+        opt = torch.optim.Adam(params, lr=1e-3, fused=(kind == "adam_fused"))
     target = torch.full((32, 3), 0.25, device=DEV)
 
     def step():
@@ -202,6 +224,9 @@ def test_training_step_updates_weights_and_repacks():
         return loss.item()
     losses = [step() for _ in range(8)]
     assert losses[-1] < losses[0]
+    if kind == "data_writes":      # the one case the INFERENCE cache cannot see by itself (documented): invalidate_packed()
+        for m in (sc.models["coarse"], sc.models["fine"]):
+            m.invalidate_packed()
     with torch.no_grad():      # inference path sees the updated parameters (re-packed weight stream)
         codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
         r_inf = A.render_rays(sc.models, sc.embeddings, rays, N_samples=16, N_importance=16, perturb=0, noise_std=0,

@@ -27,7 +27,7 @@ def main(n_rays=2048, steps=5):
     sc = synth.build_scene(A, True, preset=synth.SCANNET_LIKE, max_voxels=800_000, device=dev)
     rays_all = synth.camera_rays(640, 480).to(dev)
     params = [p for m in (sc.models["coarse"], sc.models["fine"], sc.code_library, sc.embeddings["xyz"]) for p in m.parameters()]
-    opt = torch.optim.Adam(params, lr=1e-3)
+    opt = torch.optim.Adam(params, lr=1e-3, fused=os.environ.get("OBJNERF_BENCH_ADAM", "fused") == "fused")
     sync = GradientSync(params)
     g = torch.Generator(device=dev).manual_seed(rank)
     target = torch.rand(n_rays, 3, device=dev, generator=g)
