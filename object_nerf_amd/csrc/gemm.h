@@ -113,6 +113,10 @@ struct GemmOperand {
   long rows_left;        // row-contiguous: rows - (first of this thread's 4 rows); K-contiguous: unused
   bool ok[4];            // K-contiguous: piece's row is inside the operand
   bool fast;             // uniform: every full k tile can be fetched with unconditional 16-byte loads
+  bool over;             // uniform, row-contiguous only: the operand has fewer than 128 rows from row0 on, but a 128-row read of
+                         // any k line that has GBK more lines after it stays inside the matrix (it runs on into the next lines):
+                         // such k tiles are fetched whole as well -- the surplus rows only meet output rows / columns that are
+                         // never stored (measured on the 104-column object-voxel products, profiles/r04_train_ab.txt)
   bool aligned;          // ... whose addresses are 16-byte aligned (else the unaligned-vector form of the same load)
   f32x4 v[4];
 
@@ -130,6 +134,7 @@ struct GemmOperand {
       step = GBK;
       rows_left = 0;
       fast = true;
+      over = false;
       aligned = vec;
     } else {
       // thread -> k = tid/32 + 8 i, rows 4 (tid % 32) .. + 3
@@ -142,13 +147,14 @@ struct GemmOperand {
       }
       step = GBK * ld;
       fast = row0 + GBM <= rows;
+      over = !fast && row0 < rows && row0 + GBM <= (long)(GBK + 1) * ld;
       aligned = vec;
     }
   }
   // k0: first k of the tile being fetched.  The contraction range must be zero-filled in BOTH operands
   // (0 x garbage could be NaN), which only the last tile of a split needs.
   __device__ __forceinline__ void fetch(long k0, long kend, int tid) {
-    if (fast && k0 + GBK <= kend) {            // uniform branches
+    if ((fast && k0 + GBK <= kend) || (over && k0 + 2 * GBK <= kend)) {            // uniform branches
       if (aligned) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = gload4(p[i]);

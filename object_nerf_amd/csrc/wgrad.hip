@@ -104,6 +104,9 @@ struct WgOperand {             // one operand of a full tile: 128 columns ("rows
   unsigned off[4];             // this thread's four 16-byte pieces (k = tid / 32 + 8 i, columns 4 (tid % 32) .. + 3): bytes from base
   int cols_left;               // columns of the operand from this thread's first one on (<= 0: none)
   bool fast, aligned;          // uniform: all 128 columns exist; 16-byte aligned pieces
+  bool over;                   // uniform: fewer than 128 columns, but a 128-column read of any row that has GBK more rows after
+                               // it stays inside the matrix (it runs on into the next rows): the branch-free loop may fetch such
+                               // rows whole -- the surplus columns only ever meet output rows / columns that are never read back
   f32x4 v[4];
   __device__ __forceinline__ void init(const float* src, long ld, long row0, long rows, long kbeg, int tid) {
     base = (const char*)(src + kbeg * ld + row0);
@@ -112,6 +115,7 @@ struct WgOperand {             // one operand of a full tile: 128 columns ("rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) off[i] = 4u * (unsigned)(((tid >> 5) + 8 * i) * ld + 4 * (tid & 31));
     fast = row0 + GBN <= rows;
+    over = !fast && row0 + GBN <= (long)(GBK + 1) * ld;
     aligned = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
   }
   // the contraction range must be zero-filled in BOTH operands (0 x garbage could be NaN): only a ragged last tile needs it
@@ -252,9 +256,12 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
     buf ^= 1;
   };
   int krem = klen;
-  if (opa.fast && opb.fast && krem >= 3 * GBK) {       // uniform
+  // a panel with fewer than 128 columns (the 104-column object voxel embedding, the 64 rows of the object direction layer) used to
+  // take the branchy loop for its whole slice; it now leaves the branch-free loop one k tile earlier instead (WgOperand::over)
+  const int steady_min = (opa.fast && opb.fast ? 3 : 4) * GBK;
+  if ((opa.fast || opa.over) && (opb.fast || opb.over) && krem >= steady_min) {       // uniform
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the second tile is in registers (and the compiler knows it)
-    for (; krem >= 3 * GBK; krem -= GBK) k_tile(std::true_type{}, krem);
+    for (; krem >= steady_min; krem -= GBK) k_tile(std::true_type{}, krem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   for (; krem > 0; krem -= GBK) k_tile(std::false_type{}, krem);
