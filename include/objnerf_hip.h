@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 7
+#define OBJNERF_ABI_VERSION 8
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -502,6 +502,13 @@ typedef struct {
   /* blob / blob_bwd are split-bf16 streams (objnerf_pack_weights_b3 / objnerf_pack_weights_bwd_b3): the fused forward
    * (fused inputs required) and the fused dgrad chain run in the split-bf16 arithmetic mode; the GEMMs stay fp32 */
   int32_t mfma_bf16x3;
+  int32_t _pad2;
+  /* optional (ABI 8), read by objnerf_mlp_train_backward only, voxel mode: the sample positions (P,3) the embeddings were
+   * taken at and the feature table's gradient (n_rows, 24; accumulated into).  When both are given the call also does
+   * objnerf_voxel_embed_backward's work for this pass -- the scatter of d_emb_xyz / d_obj_voxel into the table -- right
+   * after the embedding-gradient products (one call less per pass; on a side stream beside the weight-gradient kernels it
+   * measured slower, CHANGELOG.md). */
+  const float* scatter_xyz; float* scatter_table_grad;
 } objnerf_train_args;
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points);
 /* scratch of objnerf_mlp_train_backward: the gradients w.r.t. every layer's pre-activation output (12.9 KB per point) + the

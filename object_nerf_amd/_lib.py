@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 7     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 8     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -98,7 +98,8 @@ class TrainArgs(C.Structure):
         ("rays", C.c_void_p), ("z_vals", C.c_void_p), ("n_rays", C.c_int64), ("S", C.c_int32), ("_pad", C.c_int32),
         ("codes", C.c_void_p), ("code_stride", C.c_int64),
         ("grid", VoxelGrid),
-        ("mfma_bf16x3", C.c_int32),
+        ("mfma_bf16x3", C.c_int32), ("_pad2", C.c_int32),
+        ("scatter_xyz", C.c_void_p), ("scatter_table_grad", C.c_void_p),
     ]
 
 

@@ -229,12 +229,13 @@ class RenderRaysFn(torch.autograd.Function):
             d_ov = _empty(P, 104, dev=dev) if (fi and vox) else None
             d_code = _empty(P, 64, dev=dev) if fi else None
             scratch = _empty(l.objnerf_train_scratch_floats(P), dev=dev)
+            if vox:      # the table scatter rides inside the call (objnerf_train_args.scatter_*)
+                assert ps.xyz.is_contiguous() and d_table.is_contiguous()
+                a.grid = meta["grid"]
+                a.scatter_xyz, a.scatter_table_grad = ps.xyz.data_ptr(), d_table.data_ptr()
             _lib.check(l.objnerf_mlp_train_backward(C.byref(a), _lib.ptr(d_sigma), _lib.ptr(d_rgb), _lib.ptr(d_isig),
                                                     _lib.ptr(d_irgb), gtable, _lib.ptr(d_emb), _lib.ptr(d_ov), _lib.ptr(d_code),
                                                     _lib.ptr(scratch), st), "mlp_train_backward")
-            if vox:
-                _lib.check(l.objnerf_voxel_embed_backward(C.byref(meta["grid"]), _lib.ptr(ps.xyz), P, _lib.ptr(d_emb),
-                                                          _lib.ptr(d_ov), _lib.ptr(d_table), st), "voxel_embed_backward")
             if fi:
                 _lib.check(l.objnerf_sum_over_samples(_lib.ptr(d_code), n, Sx, 64, _lib.ptr(d_codes), st), "sum_over_samples")
         flat = list(param_grads[0]) + (list(param_grads[1]) if len(param_grads) > 1 else [])

@@ -54,6 +54,7 @@ struct Ctx {
   hipStream_t s;
   int rc;
 };
+
 static inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 
 // C = A' * B' helpers over row-major activations / nn.Linear weights
@@ -284,6 +285,27 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     }
   }
 
+  // ---- phase B0 (before the weight gradients: the dgrad results are consumed while they are cache-hot): gradients w.r.t.
+  // the embeddings: every consumer layer's dY W block in one segmented product per input ----
+  {
+    const int ov = vox ? kObjVoxPE : 0;
+    const DgradSeg emb[4] = {{d.A(5), 256, Wt(P_S5), cx + 256, 256}, {d.A(1), 256, Wt(P_S1), cx, 256},
+                             {d.B(3), 128, Wt(P_O3), co + 128, 128}, {d.B(1), 128, Wt(P_O1), co, 128}};
+    if (ce) lin_dgrad_multi(c, emb, obj ? 4 : 2, P, ce, d_emb_xyz, cx);       // only the voxel-feature columns (see above)
+    if (obj) {
+      const DgradSeg ovs[2] = {{d.B(3), 128, Wt(P_O3) + cx, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx, co, 128}};
+      if (vox) lin_dgrad_multi(c, ovs, 2, P, kObjVoxPE, d_obj_voxel, kObjVoxPE);
+      const DgradSeg cds[2] = {{d.B(3), 128, Wt(P_O3) + cx + ov, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx + ov, co, 128}};
+      lin_dgrad_multi(c, cds, 2, P, kCodeC, d_obj_code, kCodeC);
+    }
+  }
+  // ---- the voxel-table scatter of those gradients (objnerf_train_args.scatter_*).  On a SIDE stream beside the weight-gradient
+  // kernels it was measured slower (20.30 vs 20.05 ms per step, profiles/r04_train_ab.txt: its workgroups take compute units from
+  // MFMA-bound kernels that already run at the part's power limit), so it is simply enqueued here ----
+  if (vox && a->scatter_xyz && a->scatter_table_grad && !c.rc)
+    c.rc = objnerf_voxel_embed_backward(&a->grid, a->scatter_xyz, P, d_emb_xyz, obj ? d_obj_voxel : nullptr,
+                                        a->scatter_table_grad, c.s);
+
   // ---- phase B: weight / bias gradients dW = dY^T X.  All products of the pass go into ONE work list and one persistent,
   // deterministic stream-K launch (wgrad.h); OBJNERF_WGRAD=atomic keeps round 2's one split-K launch with atomic
   // accumulation per product (developer A/B switch) ----
@@ -337,19 +359,6 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     }
   }
   if (!atomic_wgrad && !c.rc) c.rc = batch.launch(P, scratch + (kWsScene + kWsObj) * P, c.s);
-  // ---- gradients w.r.t. the embeddings: every consumer layer's dY W block in one segmented product per input ----
-  {
-    const int ov = vox ? kObjVoxPE : 0;
-    const DgradSeg emb[4] = {{d.A(5), 256, Wt(P_S5), cx + 256, 256}, {d.A(1), 256, Wt(P_S1), cx, 256},
-                             {d.B(3), 128, Wt(P_O3), co + 128, 128}, {d.B(1), 128, Wt(P_O1), co, 128}};
-    if (ce) lin_dgrad_multi(c, emb, obj ? 4 : 2, P, ce, d_emb_xyz, cx);       // only the voxel-feature columns (see above)
-    if (obj) {
-      const DgradSeg ovs[2] = {{d.B(3), 128, Wt(P_O3) + cx, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx, co, 128}};
-      if (vox) lin_dgrad_multi(c, ovs, 2, P, kObjVoxPE, d_obj_voxel, kObjVoxPE);
-      const DgradSeg cds[2] = {{d.B(3), 128, Wt(P_O3) + cx + ov, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx + ov, co, 128}};
-      lin_dgrad_multi(c, cds, 2, P, kCodeC, d_obj_code, kCodeC);
-    }
-  }
   return c.rc;
 }
 

@@ -1,6 +1,7 @@
 // wgrad.hip -- grouped, stream-K, deterministic weight gradients of one backward pass (wgrad.h).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "wgrad.h"
 #include "host_api.h"
