@@ -161,7 +161,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
 // (the fine pass, whose samples cluster at surfaces, ran 8x slower per point than the coarse pass).  The workgroup
 // therefore first sums its contributions per table row in an LDS hash (row id -> 24 floats, ds_add_f32), then sends
 // each row it touched to memory once; contributions that find no slot within 8 probes go to memory directly.
-constexpr int kVbSlots = 512;               // power of two
+#ifndef OBJ_VB_SLOT_BITS
+#define OBJ_VB_SLOT_BITS 8         // 256 slots: 26 KB of LDS, six workgroups per CU (512: three) -- step -0.15 ms, profiles/r04_train_ab.txt
+#endif
+constexpr int kVbSlots = 1 << OBJ_VB_SLOT_BITS;               // power of two
 constexpr int kVbStride = kVoxC + 1;        // odd stride: spreads the rows over the LDS banks
 constexpr int kVbPoints = 128;              // points per workgroup (the aggregation window)
 // 32 lanes per point, lane = voxel channel (0..15 scene, 16..23 object; 24..31 idle), 8 points per pass of a
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxe
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (row[k] < 0) continue;                       // invalid corners were zeroed in the forward pass
-      unsigned h = ((unsigned)row[k] * 2654435761u) >> 23;       // 9 bits
+      unsigned h = ((unsigned)row[k] * 2654435761u) >> (32 - OBJ_VB_SLOT_BITS);
       int slot = -1;
       for (int probe = 0; probe < 8; ++probe) {
         const int prev = atomicCAS(&keys[h], -1, row[k]);
