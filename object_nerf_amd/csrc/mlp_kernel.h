@@ -535,6 +535,10 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[NT], const float* aux, i
   for (int m = 0; m < NT; ++m) acc[m] = *(const f32x16*)(b + m * 32);
 }
 
+#ifndef OBJ_PK_LEAKY
+#define OBJ_PK_LEAKY 1
+#endif
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 template <int NT, bool ACT>
 __device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT]) {
 #pragma unroll
@@ -543,7 +547,19 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT])
 #ifdef OBJ_ABL_FINISH      // timing ablation only: no LeakyReLU arithmetic
     for (int r = 0; r < 16; ++r) h[m][r] = acc[m][r];
 #else
-    for (int r = 0; r < 16; ++r) h[m][r] = ACT ? leaky(acc[m][r]) : acc[m][r];
+    for (int r = 0; r < 16; r += 2) {
+      if constexpr (ACT && OBJ_PK_LEAKY) {
+        // 0.01 v for two values in one v_pk_mul_f32 (gfx950 has packed fp32 mul / fma, no packed max): the same two IEEE
+        // operations per value as leaky() -- bit-equal -- in 1.5 instead of 2 VALU instructions
+        const f32x2 v = {acc[m][r], acc[m][r + 1]};
+        const f32x2 sl = v * 0.01f;
+        h[m][r] = fmaxf(v[0], sl[0]);
+        h[m][r + 1] = fmaxf(v[1], sl[1]);
+      } else {
+        h[m][r] = ACT ? leaky(acc[m][r]) : acc[m][r];
+        h[m][r + 1] = ACT ? leaky(acc[m][r + 1]) : acc[m][r + 1];
+      }
+    }
 #endif
 }
 
@@ -603,9 +619,23 @@ __device__ __forceinline__ void finish_add(const f32x16 (&acc)[NT], const f32x16
 #pragma unroll
   for (int m = 0; m < NT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = acc[m][r] + add[m][r];
-      h[m][r] = ACT ? leaky(v) : v;
+    for (int r = 0; r < 16; r += 2) {
+      if constexpr (OBJ_PK_LEAKY) {      // packed add (+ packed 0.01 v): the same IEEE operations, half the instructions
+        const f32x2 a2 = {acc[m][r], acc[m][r + 1]}, b2 = {add[m][r], add[m][r + 1]};
+        const f32x2 v = a2 + b2;
+        if constexpr (ACT) {
+          const f32x2 sl = v * 0.01f;
+          h[m][r] = fmaxf(v[0], sl[0]);
+          h[m][r + 1] = fmaxf(v[1], sl[1]);
+        } else {
+          h[m][r] = v[0];
+          h[m][r + 1] = v[1];
+        }
+      } else {
+        const float v0 = acc[m][r] + add[m][r], v1 = acc[m][r + 1] + add[m][r + 1];
+        h[m][r] = ACT ? leaky(v0) : v0;
+        h[m][r + 1] = ACT ? leaky(v1) : v1;
+      }
     }
 }
 

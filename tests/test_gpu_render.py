@@ -338,6 +338,48 @@ def test_split_bf16_mode_matches_f32_mfma_mode(monkeypatch):
         A.render_rays(sc.models, sc.embeddings, rays[:8].contiguous(), **dict(kw, embedding_instance=codes[:8]))
 
 
+@pytest.mark.parametrize("multi", [False, True])
+def test_a_whole_call_is_capturable_in_a_hip_graph(multi):
+    """the library only enqueues on the caller's stream, never allocates and never synchronises, so a whole render_rays /
+    render_rays_multi call can be captured once in a hipGraph (torch.cuda.CUDAGraph) and replayed on new inputs written into
+    the captured buffers: the replay is bit-equal to an eager call on the same inputs (launch-bound small calls: the editor's
+    <= 4,096-ray chunks; tools/small_batch.py times it)."""
+    sc = scene("voxel")
+    with torch.no_grad():
+        if multi:
+            sets, boxes = cases.multi_inputs()
+            static = [s.to(DEV).clone() for s in sets]
+            m = cases.MULTI
+            kw = dict(N_samples=m["N_samples"], N_importance=m["N_importance"], perturb=0, noise_std=0, background_skip_bbox={4: boxes[0]})
+
+            def call():
+                return render_rays_multi(sc.models, sc.embeddings, sc.code_library, static, m["obj_ids"], **kw)
+            new_inputs = [torch.roll(s, 7, 0) for s in static]
+        else:
+            rays = H.test_rays(512).to(DEV)
+            static = [rays.clone()]
+            codes = sc.code_library({"instance_ids": synth.per_ray_ids(rays.shape[0]).to(DEV)})["embedding_instance"].contiguous()
+            kw = dict(N_samples=32, N_importance=32, perturb=0, noise_std=0, embedding_instance=codes, is_eval=True)
+
+            def call():
+                return A.render_rays(sc.models, sc.embeddings, static[0], **kw)
+            new_inputs = [torch.roll(rays, 5, 0)]
+        call()                                        # packs the weights, caches the index tables and box arrays
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = call()
+        for dst, src in zip(static, new_inputs):
+            dst.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        replayed = {k: v.clone() for k, v in out.items()}
+        eager = call()
+        torch.cuda.synchronize()
+    for k in eager:
+        assert torch.equal(replayed[k], eager[k]), k
+
+
 def test_render_rays_multi_is_one_enqueue_without_host_round_trips():
     """the whole call -- depths, ray culling, 2K MLP launches, masks, compositing, importance sampling -- is issued
     without the host ever waiting for the device (round 1 read the survivor count back per ray set and pass).  torch's

@@ -2,7 +2,9 @@
 """Small-batch behaviour of render_rays (GPU box): the editor renders <= 4,096-ray chunks (test/config/*.yaml:4) and a
 training step 2,048 rays, far from the 307,200-ray frame the headline is quoted on.  Per batch size: wall time per call
 (host + device, calls issued back to back), device time per call (events around the loop), and host-only time per call
-(the same loop with the device idle at the end) -> where the time goes.
+(the same loop with the device idle at the end) -> where the time goes.  Last column: the same call captured ONCE in a
+hipGraph (torch.cuda.CUDAGraph: the library only enqueues on the caller's stream and never allocates or synchronises, so a
+whole render_rays call is capturable) and replayed -- no host issue, no gaps between the call's eight kernels.
 usage: python tools/small_batch.py [out.md]"""
 import os
 import sys
@@ -21,8 +23,9 @@ DEV = "cuda"
 def main(out=None):
     sc = synth.build_scene(A, use_voxel=True, preset=synth.TOYDESK2, max_voxels=800_000, device=DEV)
     rays_all = synth.preset_rays(synth.TOYDESK2, 640, 480).to(DEV)
-    lines = ["| rays / call | calls | wall ms / call | device ms / call | host-issue ms / call | M ray-samples/s (wall) | of frame rate |",
-             "|---|---|---|---|---|---|---|"]
+    lines = ["| rays / call | calls | wall ms / call | device ms / call | host-issue ms / call | M ray-samples/s (wall) | of frame rate "
+             "| hipGraph replay: device ms / call | of frame rate |",
+             "|---|---|---|---|---|---|---|---|---|"]
     frame_rate = None
     for n in (307200, 32768, 8192, 4096, 2048, 1024):
         idx = torch.linspace(0, rays_all.shape[0] - 1, n).long().to(DEV)
@@ -47,7 +50,27 @@ def main(out=None):
         rate = n * 192 * calls / wall / 1e6
         if frame_rate is None:
             frame_rate = rate
-        lines.append("| %d | %d | %.3f | %.3f | %.3f | %.1f | %.2f |" % (n, calls, 1e3 * wall / calls, dev_ms, 1e3 * t_issue / calls, rate, rate / frame_rate))
+        graph_ms, graph_frac = "n/a", "n/a"
+        if n <= 32768:
+            try:
+                with torch.no_grad():
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        A.render_rays(sc.models, sc.embeddings, rays, **kw)
+                    torch.cuda.synchronize()
+                    g.replay()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(calls):
+                        g.replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                gm = e0.elapsed_time(e1) / calls
+                graph_ms, graph_frac = "%.3f" % gm, "%.3f" % (n * 192 / (gm * 1e-3) / 1e6 / frame_rate)
+            except Exception as e:      # noqa: BLE001 -- report, keep the table
+                graph_ms = "failed: %s" % (str(e).splitlines()[0][:80])
+        lines.append("| %d | %d | %.3f | %.3f | %.3f | %.1f | %.2f | %s | %s |" % (n, calls, 1e3 * wall / calls, dev_ms, 1e3 * t_issue / calls, rate,
+                                                                             rate / frame_rate, graph_ms, graph_frac))
     txt = "\n".join(lines)
     print(txt)
     if out:
