@@ -273,11 +273,6 @@ class Workload:
                            forward_instance=fi, frustum_bound_th=self.preset["frustum_bound_th"], is_eval=True)
             if cfg_id in (2, 3):
                 self.kw["rays_in_bbox"] = True
-            if (scaling != "strong" or world == 1) and os.environ.get("OBJNERF_BENCH_ROW_HINT", "0") == "1":
-                # opt-in A/B switch (tools/row_hint_ab.sh): the batch is a whole frame in row-major pixel order; with the hint the
-                # renderer visits rays in column strips.  Results are bit-equal; measured: no effect on time or on the fetch
-                # counter (profiles/r04_nt_ab.txt), so the headline runs without it
-                self.kw["row_width"] = self.W
             self.flop_per_eval = FLOP_BOTH if fi else FLOP_SCENE
             self.evals_rank = float(self.n_local) * (self.S + (self.S + self.I if self.I > 0 else 0))
             self.nominal_evals_rank = self.evals_rank

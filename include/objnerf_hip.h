@@ -184,14 +184,7 @@ typedef struct {
   const float* points;
   const float* lat_x; const float* lat_y; const float* lat_z;
   int32_t lat_n[3];
-  /* fused form, optional hint (ABI 7): the rays are an image in row-major pixel order, row_width rays per row.  Work is then
-   * ordered in column strips (each XCD walks its rows strip by strip, top to bottom) instead of along whole image rows, so
-   * that the voxel-table rows a pixel shares with the pixel BELOW it are requested while they are still in the XCD's L2 --
-   * fewer memory-side requests, identical results (only the order in which rays are visited changes).  Applied when n_rays
-   * is a multiple of 8 * row_width and a strip of (workgroups per XCD) * 128 / S rays divides row_width; ignored otherwise
-   * and with ray_index.  0 = no hint.  _strip_*: reserved (set by the library), must be 0. */
-  int32_t row_width;
-  int32_t _strip_w, _strip_rows;
+  int32_t _pad_lat;
 } objnerf_mlp_args;
 #define OBJNERF_RAY_BIAS_FLOATS 448
 /* out: objnerf_ray_bias_floats(n_rays) = n_rays * OBJNERF_RAY_BIAS_FLOATS floats -- the vectors for
@@ -374,8 +367,6 @@ typedef struct {
   /* 0 (default): the passes take the per-ray constant terms from objnerf_ray_bias (objnerf_mlp_args.ray_bias;
    * 1792 B of workspace per ray); 1: every term contracted per sample point as in round 2 (A/B switch) */
   int32_t no_hoist;
-  /* optional hint: the rays are whole image rows of this many pixels, row-major (objnerf_mlp_args.row_width); 0 = none */
-  int32_t row_width;
 } objnerf_render_cfg;
 
 typedef struct {

@@ -51,7 +51,7 @@ class MlpArgs(C.Structure):
         ("comp_w", C.c_void_p), ("comp_rec", C.c_void_p), ("comp_last_delta", C.c_float), ("comp_inst_weights", C.c_int32),
         ("ray_bias", C.c_void_p),
         ("points", C.c_void_p), ("lat_x", C.c_void_p), ("lat_y", C.c_void_p), ("lat_z", C.c_void_p), ("lat_n", C.c_int32 * 3),
-        ("row_width", C.c_int32), ("_strip_w", C.c_int32), ("_strip_rows", C.c_int32),
+        ("_pad_lat", C.c_int32),
     ]
 
 
@@ -121,7 +121,7 @@ class RenderCfg(C.Structure):
         ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32),
         ("forward_instance", C.c_int32), ("is_eval", C.c_int32), ("use_zero_as_last_delta", C.c_int32),
         ("frustum_bound_th", C.c_float), ("rays_in_bbox", C.c_int32), ("mfma_bf16x3", C.c_int32),
-        ("separate_composite", C.c_int32), ("no_hoist", C.c_int32), ("row_width", C.c_int32),
+        ("separate_composite", C.c_int32), ("no_hoist", C.c_int32),
     ]
 
 

@@ -269,17 +269,6 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   const long ntiles = (P + 127) / 128;
   const unsigned grid = mlp_grid(ntiles);
   hipStream_t s = (hipStream_t)stream;
-  // row_width hint: column-strip order when the sizes allow it (see objnerf_hip.h); never with a ray subset / the point forms
-  objnerf_mlp_args local = *a;
-  local._strip_w = local._strip_rows = 0;
-  if (fused && !query && !a->ray_index && a->row_width > 0 && (grid & 7) == 0 && ntiles >= (long)grid) {
-    const long W = a->row_width, per_step = (long)(grid >> 3) * 128;
-    if (a->n_rays % (8 * W) == 0 && per_step % a->S == 0) {
-      const long B = per_step / a->S;
-      if (B >= 1 && W % B == 0) { local._strip_w = (int32_t)B; local._strip_rows = (int32_t)(a->n_rays / (8 * W)); }
-    }
-  }
-  a = &local;
 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool timing;
@@ -371,7 +360,6 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
     m.blob = blob; m.aux = aux; m.mfma_bf16x3 = cfg->mfma_bf16x3;
     m.rays = in->rays + lo * 8; m.z_vals = z; m.n_rays = N; m.S = S;
     m.codes = in->codes + lo * in->code_stride; m.code_stride = in->code_stride; m.grid = in->grid;
-    m.row_width = (lo == 0 && N == in->n_rays) ? cfg->row_width : 0;      // the hint describes the whole batch, not a slab of it
     if (hoists(cfg)) {
       const int rc = objnerf_ray_bias(&m, rb, stream);
       if (rc) return rc;

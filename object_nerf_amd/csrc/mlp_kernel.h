@@ -898,16 +898,8 @@ struct TilePrologue {
       rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = 0.f;
       return;
     }
-    long slot = pc / a.S;
+    const long slot = pc / a.S;
     sidx = (int)(pc - slot * a.S);                                   // the point's sample index inside its ray
-    if (a._strip_w > 0) {      // uniform: image-ordered rays visited in column strips (objnerf_mlp_args.row_width)
-      const long band = (long)a.row_width * a._strip_rows;          // rays of one XCD's eighth = whole image rows
-      const long b = slot / band, vb = slot - b * band;
-      const long sh = (long)a._strip_w * a._strip_rows;             // rays of one strip
-      const long st_ = vb / sh, rem = vb - st_ * sh;
-      const long y = rem / a._strip_w;
-      slot = b * band + y * a.row_width + st_ * a._strip_w + (rem - y * a._strip_w);
-    }
     // ray subset (objnerf_mlp_args.ray_index): tiles walk the listed rays only; p stays the point's index in the
     // full (n_rays, S) arrays, so depths are read and results written in place
     ray = a.ray_index ? (long)a.ray_index[slot] : slot;

@@ -281,9 +281,7 @@ def render_rays(
         forward_instance=int(bool(forward_instance)), is_eval=int(is_eval),
         use_zero_as_last_delta=int(use_zero_as_last_delta), frustum_bound_th=float(frustum_bound_th),
         rays_in_bbox=int(bool(rays_in_bbox)), mfma_bf16x3=int(mfma_mode() == "bf16x3"),
-        separate_composite=int(composite_mode() == "separate"), no_hoist=int(not hoist_enabled()),
-        # optional hint (reaches the reference as an ignored **kwarg): the rays are whole image rows of this many pixels
-        row_width=max(0, int(dummy_kwargs.get("row_width", 0) or 0)))
+        separate_composite=int(composite_mode() == "separate"), no_hoist=int(not hoist_enabled()))
     l = _lib.lib()
     ws = torch.empty(l.objnerf_render_workspace_bytes(C.byref(cfg), n), dtype=torch.uint8, device=dev)
 

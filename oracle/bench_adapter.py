@@ -42,7 +42,6 @@ class OracleRenderer:
     def render_rays(self, sc, rays, **kw):
         pc, pf, grid, _ = self._scene(sc)
         kw = dict(kw)
-        kw.pop("row_width", None)          # a scheduling hint of the HIP renderer (ignored by the reference as a **kwarg)
         kw["embedding_instance"] = kw["embedding_instance"].cpu()
         if rays.shape[0] == 0:
             # an idle rank of a sharded frame: the reference (and so its restatement) cannot take an empty batch

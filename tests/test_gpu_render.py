@@ -242,25 +242,6 @@ def test_render_rays_multi_bench_edit_demo_matches_reference():
     assert psnr(r["rgb_fine"].cpu(), g["rgb_fine"]) >= 60.0
 
 
-def test_row_width_hint_changes_the_visiting_order_only():
-    """render_rays(..., row_width=W): image-ordered rays visited in column strips (objnerf_mlp_args.row_width) -- every one of
-    the 16 result tensors bit-equal to the unhinted render; sizes the strips do not divide fall back silently"""
-    sc = cases.scene_for(A, "voxel", device=DEV)
-    W, Hh = 640, 64                                   # 40,960 rays = 8 x 8 rows: strips of 64 (coarse) and 32 (fine) rays
-    rays = synth.camera_rays(640, 480)[: W * Hh].contiguous().to(DEV)
-    n = rays.shape[0]
-    with torch.no_grad():
-        codes = sc.code_library({"instance_ids": synth.per_ray_ids(n).to(DEV)})["embedding_instance"].contiguous()
-        kw = dict(N_samples=64, N_importance=64, perturb=0, noise_std=0, embedding_instance=codes, is_eval=True)
-        plain = A.render_rays(sc.models, sc.embeddings, rays, **kw)
-        hinted = A.render_rays(sc.models, sc.embeddings, rays, row_width=W, **kw)
-        odd = A.render_rays(sc.models, sc.embeddings, rays[: W * 9], row_width=W, **dict(kw, embedding_instance=codes[: W * 9]))
-        odd_plain = A.render_rays(sc.models, sc.embeddings, rays[: W * 9], **dict(kw, embedding_instance=codes[: W * 9]))
-    for k in plain:
-        assert torch.equal(hinted[k], plain[k]), k
-        assert torch.equal(odd[k], odd_plain[k]), k      # 9 rows: not a multiple of 8 -> the hint is ignored
-
-
 def test_full_frame_properties():
     """640x480 (BASELINE size): properties that need no reference + a strided sample against the oracle"""
     sc = cases.scene_for(A, "voxel", device=DEV)
