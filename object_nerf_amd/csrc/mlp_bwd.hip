@@ -72,13 +72,43 @@ __device__ __forceinline__ void sign_bits(const RawTiles& raw, MaskBits<NT>& bit
   }
 }
 // h = leaky'(act) . acc      (leaky_relu backward on sign(output) = sign(input))
+#ifndef OBJ_BWD_CARRY_MASK
+#define OBJ_BWD_CARRY_MASK 1
+#endif
 template <int NT>
 __device__ __forceinline__ void mask_tiles(const f32x16 (&acc)[NT], const MaskBits<NT>& bits, f32x16 (&h)[NT]) {
+#if OBJ_BWD_CARRY_MASK
+  // The mask word is consumed from its top bit down: `m + m` shifts it left and leaves the bit that fell out in VCC, which the
+  // select reads directly -- one VALU instruction where "extract bit, compare" took two (this kernel carries 1.17 VALU
+  // instructions per MFMA and fp32 MFMA shares the SIMD's ALUs with them, profiles/r04_train_pmc.md).  Same selects, same
+  // products: the results are bit-equal.
+#pragma unroll
+  for (int wd = 0; wd < NT / 2; ++wd) {
+    unsigned m = bits.w[wd];
+#pragma unroll
+    for (int tt = 1; tt >= 0; --tt) {
+      const int t = 2 * wd + tt;
+#pragma unroll
+      for (int r = 15; r >= 0; r -= 2) {
+        const f32x2 v = {acc[t][r - 1], acc[t][r]};
+        const f32x2 sl = v * 0.01f;                  // v_pk_mul_f32
+        float o1, o0;
+        asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, %3, vcc"
+                     : "+v"(m), "=v"(o1) : "v"(sl[1]), "v"(v[1]) : "vcc");
+        asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, %3, vcc"
+                     : "+v"(m), "=v"(o0) : "v"(sl[0]), "v"(v[0]) : "vcc");
+        h[t][r] = o1;
+        h[t][r - 1] = o0;
+      }
+    }
+  }
+#else
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       h[t][r] = ((bits.w[t / 2] >> (16 * (t & 1) + r)) & 1u) ? acc[t][r] : 0.01f * acc[t][r];
+#endif
 }
 // after-barrier hook of one backward layer: chunk 0 stores the layer's input gradient (the previous layer's result)
 // and fetches the first four activation tiles of the mask of ITS result; chunks 1, 2 reduce them to bits / fetch the rest
