@@ -66,7 +66,6 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOP per MLP evaluation of one sample point (GEMM FLOP only, 2 x MAC)
 FLOP_BOTH, FLOP_SCENE, FLOP_OBJECT = 1_776_128, 1_399_808, 376_320
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16; the split-bf16 mode spends 6 bf16 products per fp32 product
 
 
 def log(msg):
@@ -89,8 +88,6 @@ def parse(argv=None):
     ap.add_argument("--cpu-rays", type=int, default=4096,
                     help="rays in the CPU baseline sample (BASELINE.md §3: a 4096-ray slab, one warm-up + 3 timed repetitions, "
                          "median; 0 = skip)")
-    ap.add_argument("--split-bf16-steps", type=int, default=2,
-                    help="extra, separately reported frames in the opt-in split-bf16 arithmetic mode (0 = skip)")
     ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
                     help="collect roofline.traffic with two rocprofv3 --pmc passes of this workload (auto: N = 1 and rocprofv3 on PATH)")
     ap.add_argument("--shard", choices=["auto", "contiguous", "cyclic"], default="auto",
@@ -452,11 +449,6 @@ def run(args, renderer=None, backend="nccl", argv=None):
         R.sync()
         gather_alone_ms = allreduce((time.perf_counter() - tg) / 10 * 1e3, "MAX")
 
-    # ---- opt-in split-bf16 arithmetic mode, reported beside the fp32 headline (never part of `value`) ----
-    extra = None
-    if on_gpu and args.split_bf16_steps > 0:
-        extra = split_bf16_leg(wl, args, lib, fence, allreduce, evals_job)
-
     # ---- BASELINE configs[3] beside a default N > 1 line: one frame over the N ranks + its same-run N = 1 anchor ----
     strong = None
     if dist is not None and world > 1 and cfg_id in (0, 1, 2) and args.strong_steps > 0 and args.as_rank is None:
@@ -521,8 +513,6 @@ def run(args, renderer=None, backend="nccl", argv=None):
                                 "gather_bytes_per_rank": 5 * 4 * (wl.shards.per if wl.shards is not None else wl.n_local),
                                 "note": "gather_ms_incl_wait = the all-gather as seen by the rank's stream: the collective plus the "
                                         "wait for the slowest rank's render; gather_alone_ms = the same collective after a barrier"}
-        if extra is not None:
-            res["split_bf16_mode"] = extra
         if strong is not None:
             res["strong_scaling"] = strong
         if train is not None:
@@ -689,46 +679,6 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def split_bf16_leg(wl, args, lib, fence, allreduce, evals_job):
-    """The same steps in the opt-in split-bf16 arithmetic mode (OBJNERF_MFMA=bf16x3: the fp32 contraction carried out on
-    the bf16 matrix pipe with exactly split operands) with ITS roofline: 6 bf16 MFMA products per
-    fp32 product, so the fp32-equivalent ceiling is 2500 / 6 = 416.7 TFLOP/s."""
-    key = wl.gather_keys[0]
-    ref_rgb = wl.last[key].clone()
-    os.environ["OBJNERF_MFMA"] = "bf16x3"
-    try:
-        wl.step()
-        fence()
-        lib.objnerf_timing_enable(1)
-        tb0 = time.perf_counter()
-        for _ in range(args.split_bf16_steps):
-            wl.step()
-        fence()
-        tb1 = time.perf_counter()
-        bl, bms = C.c_int64(0), C.c_double(0.0)
-        lib.objnerf_timing_read(C.byref(bl), C.byref(bms))
-        lib.objnerf_timing_enable(0)
-        eb = allreduce(tb1 - tb0, "MAX")
-        mse = ((wl.last[key].double() - ref_rgb.double()) ** 2).mean().item()
-        eq = wl.flop_rank * args.split_bf16_steps / (bms.value / 1e3) / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-        return {"value": evals_job * args.split_bf16_steps / eb, "unit": "ray-samples/s",
-                "ms_per_step": 1e3 * eb / args.split_bf16_steps, "steps": args.split_bf16_steps,
-                "dtype": "f32 operands split exactly into 3 x bf16, 6 of 9 products on the bf16 matrix pipe, f32 accumulate",
-                "roofline": {"bound": "mfma", "achieved": eq, "peak": peak, "unit": "TFLOP/s (fp32-equivalent: bf16 MFMA rate / 6 products)",
-                             "frac": eq / peak, "launches": int(bl.value), "avg_launch_ms": bms.value / max(1, bl.value)},
-                "psnr_vs_f32_mfma_path_db": -10.0 * math.log10(max(mse, 1e-30)),
-                "max_abs_diff_vs_f32_mfma_path": (wl.last[key] - ref_rgb).abs().max().item()}
-    except Exception as e:      # the optional mode must never cost the headline line
-        try:
-            lib.objnerf_timing_enable(0)
-        except Exception:
-            pass
-        return {"error": "%s: %s" % (type(e).__name__, e)}
-    finally:
-        os.environ.pop("OBJNERF_MFMA", None)
-
-
 # ---------------------------------------------------------------------------------------------------------------------
 # roofline.traffic: HBM bytes per launch of the MLP kernel from PMC counters
 # ---------------------------------------------------------------------------------------------------------------------
@@ -748,7 +698,7 @@ def pmc_traffic(args, cfg_id, live):
             base = tempfile.mkdtemp(prefix="objnerf_pmc_", dir="/tmp")
             child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg_id), "--width", str(args.width),
                      "--height", str(args.height), "--max-voxels", str(args.max_voxels), "--steps", "1", "--warmup", "1",
-                     "--cpu-rays", "0", "--split-bf16-steps", "0", "--train-steps", "0", "--pmc", "off", "--pmc-child"]
+                     "--cpu-rays", "0", "--train-steps", "0", "--pmc", "off", "--pmc-child"]
             tot = {}
             t0 = time.perf_counter()
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

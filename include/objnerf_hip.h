@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 8
+#define OBJNERF_ABI_VERSION 9
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -58,26 +58,12 @@ int objnerf_pack_index(int use_voxel, uint32_t* h_blob_idx, uint32_t* h_aux_idx)
 int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx,
                          const float* const* h_param_ptrs, float* blob, float* aux, void* stream);
 
-/* Optional arithmetic mode of the fused form (objnerf_mlp_args.mfma_bf16x3): the same fp32 contraction carried out on
- * the bf16 matrix pipe with every operand split exactly into three bf16 pieces and 6 of the 9 cross products (dropped
- * terms <= 2^-23 relative), fp32 accumulation.  Needs its own packing of the weights (aux is shared):
- * idx has objnerf_blob_floats() entries, the blob objnerf_b3_blob_bytes() bytes. */
-int64_t objnerf_b3_blob_bytes(int use_voxel);
-int objnerf_pack_index_b3(int use_voxel, uint32_t* h_blob_idx);
-int objnerf_pack_weights_b3(int use_voxel, const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob,
-                            void* stream);
-
 /* Training only: the transposed weight stream of the hidden-to-hidden blocks, consumed by the fused backward of the
  * hidden chain (objnerf_train_args.blob_bwd).  Same tile/chunk format as the forward stream with rows = input
  * features and k = output features; the gradients w.r.t. the embeddings are not part of it. */
 int64_t objnerf_bwd_blob_floats(void);
 int objnerf_pack_index_bwd(int use_voxel, uint32_t* h_blob_idx);
 int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream);
-/* the same stream for the split-bf16 mode (objnerf_train_args.mfma_bf16x3): idx has objnerf_bwd_blob_floats() entries,
- * the blob 6 bytes per entry */
-int objnerf_pack_index_bwd_b3(int use_voxel, uint32_t* h_blob_idx);
-int objnerf_pack_weights_bwd_b3(const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob, void* stream);
-
 /* ---- stage entry points ---- */
 
 /* coarse depths: models/rendering.py:260-277.  z_steps = torch.linspace(0,1,S) (S floats, device).
@@ -138,8 +124,6 @@ typedef struct {
    * tools/extract_mesh.py:85-108): the final / direction / rgb layers are skipped (scene branch: 597,760 instead of
    * 699,904 MAC per point).  Memory form: as ObjectNeRF.forward gets its inputs; fused form: see `points` below */
   int32_t sigma_only;
-  /* fused form only: `blob` is an objnerf_pack_weights_b3() stream and the MLP runs in the split-bf16 mode above */
-  int32_t mfma_bf16x3;
   /* fused form only, optional (both or neither): evaluate a SUBSET of the rays.  ray_index: int32 ray numbers,
    * ascending or not; n_active: DEVICE pointer to how many of them are valid -- read by the kernel, so the count can
    * be produced on the stream (objnerf_compact_rays) without a host round trip.  Points of unlisted rays are neither
@@ -358,7 +342,6 @@ typedef struct {
   int32_t use_zero_as_last_delta;
   float frustum_bound_th;
   int32_t rays_in_bbox;
-  int32_t mfma_bf16x3;       /* blob_coarse / blob_fine are objnerf_pack_weights_b3() streams (see objnerf_mlp_args) */
   /* 0 (default): a pass without occlusion mask and noise whose sample count is a multiple of 32 composites in the MLP
    * kernel's epilogue (objnerf_mlp_args.comp_*: sigma / rgb never reach memory, workspace 2 B instead of 32 B per sample);
    * 1: always the two-kernel form (MLP kernel -> sigma / rgb in the workspace -> objnerf_composite).  Results are
@@ -411,7 +394,6 @@ typedef struct {
   float perturb;             /* != 0: the importance samples use u_rand instead of linspace (multi_rendering.py:276) */
   float noise_std;
   int32_t white_back;
-  int32_t mfma_bf16x3;
   int32_t no_hoist;          /* as objnerf_render_cfg.no_hoist */
 } objnerf_render_multi_cfg;
 
@@ -490,10 +472,6 @@ typedef struct {
   const float* rays; const float* z_vals; int64_t n_rays; int32_t S; int32_t _pad;
   const float* codes; int64_t code_stride;
   objnerf_voxel_grid grid;
-  /* blob / blob_bwd are split-bf16 streams (objnerf_pack_weights_b3 / objnerf_pack_weights_bwd_b3): the fused forward
-   * (fused inputs required) and the fused dgrad chain run in the split-bf16 arithmetic mode; the GEMMs stay fp32 */
-  int32_t mfma_bf16x3;
-  int32_t _pad2;
   /* optional (ABI 8), read by objnerf_mlp_train_backward only, voxel mode: the sample positions (P,3) the embeddings were
    * taken at and the feature table's gradient (n_rows, 24; accumulated into).  When both are given the call also does
    * objnerf_voxel_embed_backward's work for this pass -- the scatter of d_emb_xyz / d_obj_voxel into the table -- right

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 8     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 9     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -46,7 +46,7 @@ class MlpArgs(C.Structure):
         ("emb_xyz", C.c_void_p), ("emb_dir", C.c_void_p), ("obj_voxel", C.c_void_p), ("obj_code", C.c_void_p),
         ("n_points", C.c_int64),
         ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
-        ("sigma_only", C.c_int32), ("mfma_bf16x3", C.c_int32),
+        ("sigma_only", C.c_int32),
         ("ray_index", C.c_void_p), ("n_active", C.c_void_p),
         ("comp_w", C.c_void_p), ("comp_rec", C.c_void_p), ("comp_last_delta", C.c_float), ("comp_inst_weights", C.c_int32),
         ("ray_bias", C.c_void_p),
@@ -98,7 +98,6 @@ class TrainArgs(C.Structure):
         ("rays", C.c_void_p), ("z_vals", C.c_void_p), ("n_rays", C.c_int64), ("S", C.c_int32), ("_pad", C.c_int32),
         ("codes", C.c_void_p), ("code_stride", C.c_int64),
         ("grid", VoxelGrid),
-        ("mfma_bf16x3", C.c_int32), ("_pad2", C.c_int32),
         ("scatter_xyz", C.c_void_p), ("scatter_table_grad", C.c_void_p),
     ]
 
@@ -120,7 +119,7 @@ class RenderCfg(C.Structure):
         ("use_voxel", C.c_int32), ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("use_disp", C.c_int32),
         ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32),
         ("forward_instance", C.c_int32), ("is_eval", C.c_int32), ("use_zero_as_last_delta", C.c_int32),
-        ("frustum_bound_th", C.c_float), ("rays_in_bbox", C.c_int32), ("mfma_bf16x3", C.c_int32),
+        ("frustum_bound_th", C.c_float), ("rays_in_bbox", C.c_int32),
         ("separate_composite", C.c_int32), ("no_hoist", C.c_int32),
     ]
 
@@ -148,7 +147,7 @@ class RenderIn(C.Structure):
 class RenderMultiCfg(C.Structure):
     _fields_ = [
         ("use_voxel", C.c_int32), ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("use_disp", C.c_int32),
-        ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32), ("mfma_bf16x3", C.c_int32),
+        ("perturb", C.c_float), ("noise_std", C.c_float), ("white_back", C.c_int32),
         ("no_hoist", C.c_int32),
     ]
 
@@ -185,14 +184,9 @@ SIGNATURES = {
     "objnerf_param_numel": (C.c_int64, [C.c_int, C.c_int]),
     "objnerf_pack_index": (C.c_int, [C.c_int, _VP, _VP]),
     "objnerf_pack_weights": (C.c_int, [C.c_int, _VP, _VP, C.POINTER(_VP), _VP, _VP, _VP]),
-    "objnerf_b3_blob_bytes": (C.c_int64, [C.c_int]),
-    "objnerf_pack_index_b3": (C.c_int, [C.c_int, _VP]),
-    "objnerf_pack_weights_b3": (C.c_int, [C.c_int, _VP, C.POINTER(_VP), _VP, _VP]),
     "objnerf_bwd_blob_floats": (C.c_int64, []),
     "objnerf_pack_index_bwd": (C.c_int, [C.c_int, _VP]),
     "objnerf_pack_weights_bwd": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),
-    "objnerf_pack_index_bwd_b3": (C.c_int, [C.c_int, _VP]),
-    "objnerf_pack_weights_bwd_b3": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),
     "objnerf_sample_coarse": (C.c_int, [_VP, _VP, _VP, C.c_float, C.c_int, C.c_int64, C.c_int, _VP, _VP]),
     "objnerf_pos_encode": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
     "objnerf_pos_encode_freqs": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP, _VP]),

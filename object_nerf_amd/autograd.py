@@ -68,8 +68,8 @@ def _composite_args(meta, ps, outs=None):
 def _train_args(meta, ps, params, packed=None, rays=None, codes=None):
     a = _lib.TrainArgs()
     if packed is not None:
-        blob, aux, blob_bwd, b3 = packed
-        a.aux, a.mfma_bf16x3 = aux.data_ptr(), int(b3)
+        blob, aux, blob_bwd = packed
+        a.aux = aux.data_ptr()
         if blob is not None:
             a.blob = blob.data_ptr()
         if blob_bwd is not None:

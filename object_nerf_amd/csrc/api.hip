@@ -129,39 +129,6 @@ int objnerf_pack_index(int use_voxel, uint32_t* blob_idx, uint32_t* aux_idx) {
   return 0;
 }
 
-int64_t objnerf_b3_blob_bytes(int use_voxel) { return (int64_t)total_chunks(use_voxel != 0) * kB3ChunkBytes; }
-
-// one entry per weight position, in the element order of plane 0:
-//   e = chunk * 8192 + ((s_local * nt + m) * 64 + lane) * 8 + j      (16 sub-tiles (s, m) per chunk for every nt)
-int objnerf_pack_index_b3(int use_voxel, uint32_t* blob_idx) {
-  if (!blob_idx) return set_error(-1, "pack_index_b3: null output");
-  const bool vox = use_voxel != 0;
-  const long n = objnerf_blob_floats(use_voxel);
-  for (long i = 0; i < n; ++i) blob_idx[i] = kPackZero;
-  for (int l = 0; l < L_COUNT; ++l) {
-    const int nt = layer_nt(l), spc = b3_steps_per_chunk(nt), ks_n = layer_ks(vox, l), ns = b3_steps(vox, l);
-    if ((ns + spc - 1) / spc != layer_chunks(vox, l)) return set_error(-3, "pack_index_b3: chunk count self-check failed");
-    const int p = layer_param(l);
-    const ParamShape sh = param_shape(vox, p);
-    const long base = (long)layer_chunk_start(vox, l) * kChunkFloats;
-    for (int s = 0; s < ns; ++s) {
-      const int chunk = s / spc, sl = s % spc;
-      for (int m = 0; m < nt; ++m)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            const int ks = 8 * s + j;
-            if (ks >= ks_n) continue;                                 // zero padding up to a whole s-step
-            const int row = 32 * m + (lane & 31);
-            const int col = layer_kcol(vox, l, ks, lane >> 5);
-            if (row >= sh.out || col < 0) continue;
-            if (col >= sh.in) return set_error(-3, "pack_index_b3: column out of range");
-            blob_idx[base + (long)chunk * kChunkFloats + ((long)(sl * nt + m) * 64 + lane) * 8 + j] = enc(2 * p, (long)row * sh.in + col);
-          }
-    }
-  }
-  return 0;
-}
-
 int64_t objnerf_bwd_blob_floats(void) { return (int64_t)bwd_total_chunks() * kChunkFloats; }
 
 int objnerf_pack_index_bwd(int use_voxel, uint32_t* blob_idx) {
@@ -185,33 +152,6 @@ int objnerf_pack_index_bwd(int use_voxel, uint32_t* blob_idx) {
           const long o = base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j;
           blob_idx[o] = enc(2 * p, (long)out_feat * sh.in + in_feat);
         }
-    }
-  }
-  return 0;
-}
-
-int objnerf_pack_index_bwd_b3(int use_voxel, uint32_t* blob_idx) {
-  if (!blob_idx) return set_error(-1, "pack_index_bwd_b3: null output");
-  const bool vox = use_voxel != 0;
-  const long n = objnerf_bwd_blob_floats();
-  for (long i = 0; i < n; ++i) blob_idx[i] = kPackZero;
-  for (int l = 0; l < BL_COUNT; ++l) {
-    const int nt = bwd_nt(l), spc = b3_steps_per_chunk(nt), ks_n = bwd_ks(l), ns = ks_n / 8;
-    if (ks_n % 8 != 0 || (ns + spc - 1) / spc != bwd_chunks(l)) return set_error(-3, "pack_index_bwd_b3: layout self-check failed");
-    const int p = bwd_param(l);
-    const ParamShape sh = param_shape(vox, p);
-    const int col0 = bwd_col0(vox, l);
-    const long base = (long)bwd_chunk_start(l) * kChunkFloats;
-    for (int s = 0; s < ns; ++s) {
-      const int chunk = s / spc, sl = s % spc;
-      for (int m = 0; m < nt; ++m)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            const int in_feat = col0 + 32 * m + (lane & 31);
-            const int out_feat = hid_feat(8 * s + j, lane >> 5);
-            blob_idx[base + (long)chunk * kChunkFloats + ((long)(sl * nt + m) * 64 + lane) * 8 + j] =
-                enc(2 * p, (long)out_feat * sh.in + in_feat);
-          }
     }
   }
   return 0;
@@ -242,7 +182,6 @@ int objnerf_mlp_eval(const objnerf_mlp_args* a, void* stream) {
   long P;
   if (query) {
     if (a->do_scene && a->do_object) return set_error(-1, "mlp_eval(points, sigma_only): one branch per call (contiguous stream window)");
-    if (a->mfma_bf16x3) return set_error(-1, "mlp_eval(points, sigma_only): the split-bf16 mode evaluates every layer");
     if (a->n_points < 0) return set_error(-1, "mlp_eval(points, sigma_only): negative n_points");
     if (!a->points) {
       if (!a->lat_x || !a->lat_y || !a->lat_z) return set_error(-1, "mlp_eval(sigma_only, fused): needs points or the three lattice axes");
@@ -357,7 +296,7 @@ static int render_pass(const objnerf_render_cfg* cfg, const objnerf_render_in* i
     objnerf_mlp_args m;
     memset(&m, 0, sizeof(m));
     m.use_voxel = cfg->use_voxel; m.do_scene = 1; m.do_object = cfg->forward_instance;
-    m.blob = blob; m.aux = aux; m.mfma_bf16x3 = cfg->mfma_bf16x3;
+    m.blob = blob; m.aux = aux;
     m.rays = in->rays + lo * 8; m.z_vals = z; m.n_rays = N; m.S = S;
     m.codes = in->codes + lo * in->code_stride; m.code_stride = in->code_stride; m.grid = in->grid;
     if (hoists(cfg)) {
@@ -517,7 +456,7 @@ int objnerf_render_rays_multi(const objnerf_render_multi_cfg* cfg, const objnerf
       const int oid = in->h_obj_ids[k];
       objnerf_mlp_args m;
       memset(&m, 0, sizeof(m));
-      m.use_voxel = cfg->use_voxel; m.mfma_bf16x3 = cfg->mfma_bf16x3;
+      m.use_voxel = cfg->use_voxel;
       m.blob = blob; m.aux = aux;
       m.rays = in->h_rays[k]; m.z_vals = z; m.n_rays = N; m.S = Sp; m.grid = in->grid;
       m.ray_index = w.idx(k); m.n_active = w.count(K, k);

@@ -12,14 +12,11 @@ int check_launch(const char* what);
 // MLP kernel launchers, one translation unit per input form (compile time)
 // save_ws != nullptr: training forward, every layer's activations are also written to the train.hip workspace
 int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
-int launch_mlp_fused_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws);   // mfma_bf16x3
 int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);                // ray_bias
-int launch_mlp_fused_b3_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);             // ray_bias + mfma_bf16x3
 int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
-int launch_mlp_memory_b3(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);                  // mfma_bf16x3
 // training: fused dgrad chain through the hidden layers (mlp_bwd.hip); act / dz in the workspace layout of train.hip
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,
-                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, bool split_bf16, hipStream_t s);
+                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, hipStream_t s);
 // persistent grid of the MLP kernel: one workgroup per CU
 unsigned mlp_grid(long ntiles);
 }  // namespace objnerf

@@ -224,18 +224,6 @@ constexpr int kRayBiasFloats = 448;
 constexpr int kRbGroups = kRayBiasFloats / 16;                  // 28: O1 8 | O3 8 | SD 8 | OD 4
 constexpr int kRbMatFloats = kRbGroups * 64 * 16 + kRbGroups * 16;
 
-// ---- split-bf16 weight stream (OBJNERF_MFMA=bf16x3, fused inference kernel) --------------------------
-// fp32 products on the bf16 matrix pipe: w = w_hi + w_mid + w_lo with three 8-bit-mantissa pieces (truncation splits
-// are EXACT for a 24-bit mantissa), likewise the activations, and 6 of the 9 cross products (everything down to 2^-16
-// relative; the dropped ones are <= 2^-23).  v_mfma_f32_32x32x16_bf16 contracts 16 k per instruction: lane (row, h)
-// supplies the 8 k of sub-block h, i.e. 8 consecutive fp32 k-steps of this lane half -- "s-step" s covers the fp32
-// k-steps 8 s .. 8 s + 7, so the K order (layer_kcol) and the D-tile -> B-operand identity carry over unchanged.
-// A chunk holds the same 128 (k-step, out-tile) pairs as an fp32 chunk = 16 sub-tiles (s, m) x 3 planes x 1 KiB:
-// [s][m][plane][lane][8 x bf16], 48 KiB; same chunk count per layer, k padded with zeros to whole s-steps.
-constexpr int kB3ChunkBytes = kChunkBytes / 2 * 3;
-OBJ_HD constexpr int b3_steps(bool voxel, int l) { return (layer_ks(voxel, l) + 7) / 8; }
-OBJ_HD constexpr int b3_steps_per_chunk(int nt) { return kChunkTiles / nt / 8; }
-
 // ---- backward weight stream (training: dgrad of the hidden chain, mlp_bwd_kernel.h) ------------------
 // d(input of layer) = W^T * d(pre-activation output): the same A-tile/chunk format with the roles swapped --
 // tile row = INPUT feature 32 m + (lane & 31) of the streamed column block, k-step (ks, half) = OUTPUT feature

@@ -157,9 +157,9 @@ __device__ __forceinline__ void add_head(f32x16 (&acc)[NT], const float* w, int 
   }
 }
 
-template <bool DO_OBJ, bool B3 = false>
+template <bool DO_OBJ>
 __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const long ntiles) {
-  constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // B3: split-bf16 arithmetic (layout.h), same chunk schedule
+  constexpr int kCB = kChunkBytes;
   __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kCB + kAuxFloats * 4 + kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -270,18 +270,13 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
 }
 
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,
-                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, bool split_bf16, hipStream_t s) {
+                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, hipStream_t s) {
   static_assert(bwd_scene_chunks() == 68 || kChunkTiles != 128, "backward stream layout");
   const BwdArgs a{blob_bwd, aux, P, act, dz, d_sigma, t2, d_isigma, t2i};
   const long ntiles = (P + 127) / 128;
   const unsigned grid = mlp_grid(ntiles);
-  if (split_bf16) {
-    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
-    else hipLaunchKernelGGL((mlp_bwd_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
-  } else {
-    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, a, ntiles);
-    else hipLaunchKernelGGL((mlp_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, a, ntiles);
-  }
+  if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  else hipLaunchKernelGGL((mlp_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, a, ntiles);
   return check_launch("mlp_train_backward(fused)");
 }
 

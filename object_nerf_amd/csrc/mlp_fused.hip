@@ -1,5 +1,5 @@
-// mlp_fused.hip -- fp32-MFMA instantiations of the fused (embed-in-registers) MLP kernel; the split-bf16 ones live in
-// mlp_fused_b3.hip (separate translation unit: they compile in parallel).
+// mlp_fused.hip -- instantiations of the fused (embed-in-registers) MLP kernel (the hoisted ones live in mlp_fused_hoist.hip:
+// separate translation units compile in parallel).
 #include "mlp_kernel.h"
 #include "host_api.h"
 
@@ -23,7 +23,6 @@ static void launch_save(const objnerf_mlp_args& a, long ntiles, unsigned grid, h
 #endif
 
 int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws) {
-  if (a.mfma_bf16x3) return launch_mlp_fused_b3(a, ntiles, grid, s, save_ws);
   if (a.ray_bias && !save_ws) return launch_mlp_fused_hoist(a, ntiles, grid, s);      // (incl. the hoisted object density query)
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
 #ifdef OBJ_TUNE_ONLY_MAIN

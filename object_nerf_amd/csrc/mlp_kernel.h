@@ -23,7 +23,7 @@
 //
 // Template variants of the same kernel: FUSED = false reads pre-embedded rows (ObjectNeRF.forward /
 // forward_instance), SIGMA_ONLY stops after the density head, SAVE is the training forward (every layer's
-// output also written to memory), B3 is the opt-in split-bf16 arithmetic mode (layout.h).
+// output also written to memory).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -61,19 +61,7 @@
                              // (round 4, measured: the counter's fetch per launch 4.8 -> 9.2 GB, time equal -- rejected)
 #endif
 #ifndef OBJ_SPREAD_DMA
-#define OBJ_SPREAD_DMA 1     // fp32 stream: weight DMA pieces issued between the MFMA groups instead of as a burst
-#endif
-#ifndef OBJ_B3_SPREAD_DMA
-#define OBJ_B3_SPREAD_DMA 1  // split-bf16 mode: weight DMA pieces issued between the MFMA groups instead of as a burst
-#endif
-#ifndef OBJ_B3_GROUP
-#define OBJ_B3_GROUP 2       // split-bf16 mode: out tiles whose products are interleaved (no back-to-back dependent MFMAs)
-#endif
-#ifndef OBJ_B3_SPLIT_SPREAD
-#define OBJ_B3_SPLIT_SPREAD 0   // split-bf16 mode: the next s-step's operand split is spread over all MFMA groups of the s-step
-#endif
-#ifndef OBJ_B3_ADEPTH
-#define OBJ_B3_ADEPTH 1      // split-bf16 mode: MFMA groups between the LDS read of an A tile and its first use
+#define OBJ_SPREAD_DMA 1     // weight DMA pieces issued between the MFMA groups instead of as a burst
 #endif
 #ifndef OBJ_NT_OUT
 #define OBJ_NT_OUT 1         // sigma / rgb output stores carry the non-temporal hint
@@ -165,10 +153,9 @@ struct WeightStreamT {
 #endif
     next = (next + 1 == nchunks) ? 0 : next + 1;
   }
-  // Spread mode (split-bf16 stream): next_chunk() only selects the chunk; its kPieces DMA instructions are then issued
-  // one at a time between the MFMA groups of the chunk being consumed (layer_mac_b3).  Issued as one burst, the 4 waves'
-  // 48 KiB take ~770 cycles to drain through the 64 B/clk vector-memory path and stall the issuing waves for that long
-  // every ~3000-cycle chunk.
+  // Spread mode: next_chunk() only selects the chunk; its kPieces DMA instructions are then issued one at a time
+  // between the MFMA groups of the chunk being consumed (layer_mac).  Issued as one burst, the 4 waves' 32 KiB take
+  // ~500 cycles to drain through the 64 B/clk vector-memory path and stall the issuing waves for that long.
   static constexpr int kPieces = CB / 4 / 1024;       // per wave and chunk
   lds_char* pend_dst;
   int pend_soff;
@@ -201,7 +188,7 @@ struct WeightStreamT {
 #endif
       cur ^= 1;
 #ifndef OBJ_ABL_DMA         // timing ablation only: weights never refreshed
-      if constexpr ((CB == kB3ChunkBytes && OBJ_B3_SPREAD_DMA) || (CB == kChunkBytes && OBJ_SPREAD_DMA)) select(cur ^ 1);
+      if constexpr (OBJ_SPREAD_DMA) select(cur ^ 1);
       else issue(cur ^ 1);
 #endif
     } else {
@@ -216,15 +203,14 @@ struct WeightStreamT {
       // slot of the chunk consumed before the current one.  Spread mode: only selected here, its pieces are issued
       // between this chunk's MFMA groups; at the NEXT barrier they are the newest CB/4096 VMEM operations of the wave
       // (or older than later prologue loads), which is exactly what the counted vmcnt above leaves in flight
-      if constexpr (CB == kChunkBytes && OBJ_SPREAD_DMA) select(cur == 0 ? 2 : cur - 1);
+      if constexpr (OBJ_SPREAD_DMA) select(cur == 0 ? 2 : cur - 1);
       else issue(cur == 0 ? 2 : cur - 1);
     }
     rd = ring + cur * CB + (tid & 63) * 16;
   }
 };
 
-using WeightStream = WeightStreamT<kChunkBytes>;        // fp32 stream
-using WeightStreamB3 = WeightStreamT<kB3ChunkBytes>;   // split-bf16 stream (1.5x the bytes)
+using WeightStream = WeightStreamT<kChunkBytes>;
 
 __device__ __forceinline__ f32x4 lds_read16(const lds_char* p) {
   return *(const __attribute__((address_space(3))) f32x4*)p;
@@ -261,19 +247,12 @@ struct NoHook {
 // accumulators need no initialisation pass).
 template <int A, int B> struct SkipGroups { static constexpr int k0 = A, k1 = B; };
 using NoSkip = SkipGroups<0, 0>;
-template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream, class SkipT>
-__device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier);
-
 // SK0, SK1: the 4-k-step groups [SK0, SK1) of the layer are SKIPPED -- no A reads, no MFMAs -- while the weight stream
 // keeps its schedule (their chunks are opened and the next chunk's DMA pieces issued as usual).  Used when the terms of
 // those k-steps are constant along a ray and arrive through objnerf_mlp_args.ray_bias instead (HOIST, see mlp_kernel).
 template <int NT, int KS, class Src, class Hook = NoHook, bool ZERO = false, class Stream = WeightStream, class SkipT = NoSkip>
 __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier = Hook{}, SkipT = SkipT{}) {
   constexpr int SK0 = SkipT::k0, SK1 = SkipT::k1;
-  if constexpr (Stream::kBytes == kB3ChunkBytes) {
-    layer_mac_b3<NT, KS, Src, Hook, ZERO, Stream, SkipT>(acc, st, src, after_barrier);
-    return;
-  }
   static_assert(SK0 == SK1 || SK0 > 0, "group 0 is never skipped");
   constexpr int NG4 = (KS + 3) / 4;
   constexpr int KG = kChunkTiles / NT;
@@ -351,179 +330,6 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 #endif
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
-// ---------------------------------------------------------------------------------------------
-// split-bf16 contraction (layout.h "split-bf16 weight stream"): per s-step (8 fp32 k-steps) the lane's 8 B values are
-// split exactly into (hi, mid, lo) bf16 triples, each out tile reads its three A planes (3 x ds_read_b128) and issues
-// the 6 products with |term| >= 2^-16, smallest first.  The split of step s + 1 is computed in the same scheduling
-// region as the MFMAs of step s: on the bf16 pipe (unlike fp32 MFMA) VALU work runs beside the matrix instructions.
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct B3Operand { u32x4 hi, mid, lo; };
-
-__device__ __forceinline__ unsigned bf16_trunc(float x) { return __float_as_uint(x) & 0xffff0000u; }
-
-// SkipT (layer_mac): the k-steps [4 k0, 4 k1) arrive per ray instead (HOIST).  Here an s-step covers 8 k-steps: s-steps made
-// only of hoisted (or padding) k-steps are skipped -- no A reads, no MFMAs, the stream keeps its schedule --, the hoisted
-// k-steps of a partly covered s-step enter as zeros.
-template <int KS, int HK0, int HK1>
-constexpr bool b3_skip_step(int s) {
-  for (int j = 0; j < 8; ++j) {
-    const int k = 8 * s + j;
-    if (k < KS && !(k >= HK0 && k < HK1)) return false;
-  }
-  return true;
-}
-template <int NT, int KS, class Src, class Hook, bool ZERO, class Stream, class SkipT>
-__device__ __forceinline__ void layer_mac_b3(f32x16 (&acc)[NT], Stream& st, Src& src, Hook after_barrier) {
-  constexpr int HK0 = 4 * SkipT::k0, HK1 = 4 * SkipT::k1;
-  constexpr int NS = (KS + 7) / 8;
-  constexpr int SPC = kChunkTiles / NT / 8;      // s-steps per chunk
-  constexpr int G = OBJ_B3_GROUP < NT ? OBJ_B3_GROUP : NT;      // out tiles whose products are interleaved
-  constexpr int NGRP = NT / G;
-  // DMA pieces per MFMA group (spread mode): front-loaded into the first half of the chunk's groups, so that the last
-  // piece has half a chunk to land before the (early) barrier that opens its chunk
-  constexpr int PPI = (Stream::kPieces + SPC * NGRP / 2 - 1) / (SPC * NGRP / 2);
-  // pairs [J0, J0 + NJ) of the four (k0, k1) pairs of an s-step
-  auto split_part = [&](auto S_, B3Operand& b, auto J0_, auto NJ_) __attribute__((always_inline)) {
-    constexpr int s = decltype(S_)::value;
-    static_for<decltype(NJ_)::value>([&](auto J) __attribute__((always_inline)) {
-      constexpr int jj = decltype(J0_)::value + decltype(J)::value;
-      constexpr int k0 = 8 * s + 2 * jj, k1 = k0 + 1;
-      float x0 = 0.f, x1 = 0.f;
-      if constexpr (k0 < KS && !(k0 >= HK0 && k0 < HK1)) x0 = src.template get<k0>();
-      if constexpr (k1 < KS && !(k1 >= HK0 && k1 < HK1)) x1 = src.template get<k1>();
-      const unsigned h0 = bf16_trunc(x0), h1 = bf16_trunc(x1);
-      const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
-      const unsigned m0 = bf16_trunc(r0), m1 = bf16_trunc(r1);
-      const float t0 = r0 - __uint_as_float(m0), t1 = r1 - __uint_as_float(m1);
-      b.hi[jj] = (h0 >> 16) | h1;
-      b.mid[jj] = (m0 >> 16) | m1;
-      b.lo[jj] = (bf16_trunc(t0) >> 16) | bf16_trunc(t1);
-    });
-  };
-  auto split = [&](auto S_, B3Operand& b) __attribute__((always_inline)) {
-    split_part(S_, b, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-  };
-  auto load_a = [&](u32x4 (&a)[G][3], int sl, int grp) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < G; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[t][pl] = *(const __attribute__((address_space(3))) u32x4*)(st.rd + ((sl * NT + grp * G + t) * 3 + pl) * 1024);
-  };
-  B3Operand bop[2];
-  constexpr int AD = OBJ_B3_ADEPTH;              // A tiles are fetched AD groups ahead of their MFMAs (ring of AD + 1 buffers)
-  constexpr int GPCH = SPC * NGRP;               // groups per chunk
-  constexpr int NGTOT = NS * NGRP;               // groups in the layer
-  static_assert(AD >= 1 && AD < GPCH, "prefetch distance must stay inside one chunk");
-  u32x4 abuf[AD + 1][G][3];
-  // buffer index of group gi is gi % (AD + 1); (s-step inside its chunk, tile group) of group gi
-  auto load_group_a = [&](auto GI) __attribute__((always_inline)) {
-    constexpr int gi = decltype(GI)::value;
-#ifdef OBJ_ABL_B3_ALOAD    // timing ablation only: A tiles read from LDS once per layer
-    if constexpr (gi <= AD) load_a(abuf[gi % (AD + 1)], 0, 0);
-#else
-    if constexpr (gi < NGTOT) {
-      if constexpr (!b3_skip_step<KS, HK0, HK1>(gi / NGRP)) load_a(abuf[gi % (AD + 1)], (gi / NGRP) % SPC, gi % NGRP);
-    }
-#endif
-  };
-  split(std::integral_constant<int, 0>{}, bop[0]);
-  static_for<NS>([&](auto S_) __attribute__((always_inline)) {
-    constexpr int s = decltype(S_)::value;
-    constexpr int sl = s % SPC;
-    constexpr bool skipped = b3_skip_step<KS, HK0, HK1>(s);
-    static_assert(!(skipped && s == 0), "the first s-step is never skipped");
-    // The layer's first chunk is opened here; every later one is opened EARLY, in front of the MFMAs of the previous
-    // chunk's last group (below): by then that group's A tiles sit in registers, so the barrier may recycle the slot,
-    // and the next chunk's first A tiles are fetched under those MFMAs instead of behind an idle barrier.
-    if constexpr (s == 0) {
-      st.next_chunk();
-      after_barrier(std::integral_constant<int, 0>{});
-      static_for<AD>([&](auto D) __attribute__((always_inline)) { load_group_a(D); });     // groups 0 .. AD-1 (same chunk: AD < GPCH)
-    }
-    const B3Operand& b = bop[s & 1];
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bm = __builtin_bit_cast(bf16x8, b.mid), bl = __builtin_bit_cast(bf16x8, b.lo);
-    static_for<NGRP>([&](auto GR) __attribute__((always_inline)) {
-      constexpr int grp = decltype(GR)::value;
-      constexpr int it = sl * NGRP + grp;                 // group index inside the chunk
-      // A tiles are double-buffered across all groups of the layer: group number gi uses abuf[gi & 1]
-      constexpr int gi = s * NGRP + grp;
-      u32x4 (&a)[G][3] = abuf[gi % (AD + 1)];
-      // the group fetched now, gi + AD, opens a new chunk when it is that chunk's first group: by then the A tiles of
-      // every remaining group of the old chunk (gi .. gi + AD - 1) sit in registers, so the barrier may recycle the slot
-      constexpr bool opens = (gi + AD < NGTOT) && ((gi + AD) % GPCH == 0);
-      constexpr bool last_of_chunk = opens;               // (name kept: this group issues no DMA pieces, see below)
-      if constexpr (opens) {
-        st.next_chunk();
-        after_barrier(std::integral_constant<int, (gi + AD) / GPCH>{});
-      }
-      load_group_a(std::integral_constant<int, gi + AD>{});
-      // this chunk's share of the NEXT chunk's DMA: PPI 1-KiB pieces per wave in front of each MFMA group (the group
-      // that opened the next chunk has already selected the chunk after it: its pieces start with that group's successor)
-      // (pieces belong to the chunk selected by the most recent next_chunk(): group `it` of a chunk carries pieces
-      // it * PPI .. of the chunk after it, and only groups in front of the opening one do: it < GPCH - AD)
-      if constexpr (OBJ_B3_SPREAD_DMA && !last_of_chunk && it < GPCH - AD)
-        static_for<PPI>([&](auto Q) __attribute__((always_inline)) { st.template piece_now<it * PPI + decltype(Q)::value>(); });
-      after_barrier.template group<gi>();
-      // keep the loads above the MFMAs below (the compiler otherwise sinks them to their first use: exposed LDS latency)
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef OBJ_ABL_B3_SPLIT     // timing ablation only: the B operand is split once per layer
-      if constexpr (grp == 0 && s == 0) split(std::integral_constant<int, 0>{}, bop[1]);
-#elif OBJ_B3_SPLIT_SPREAD
-      // the next s-step's operand split, a share per MFMA group of this s-step (4 / NGRP of its four pairs): a filler
-      // stream of ~2 VALU per MFMA gap everywhere instead of ~6 in the first group and none in the others
-      if constexpr (s + 1 < NS)
-        split_part(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1], std::integral_constant<int, grp * (4 / NGRP)>{},
-                   std::integral_constant<int, 4 / NGRP>{});
-#else
-      if constexpr (grp == 0 && s + 1 < NS) {
-        if constexpr (!b3_skip_step<KS, HK0, HK1>(s + 1)) split(std::integral_constant<int, s + 1>{}, bop[(s + 1) & 1]);
-      }
-#endif
-      if constexpr (!skipped) {
-      bf16x8 ah[G], am[G], al[G];
-#pragma unroll
-      for (int t = 0; t < G; ++t) {
-        ah[t] = __builtin_bit_cast(bf16x8, a[t][0]);
-        am[t] = __builtin_bit_cast(bf16x8, a[t][1]);
-        al[t] = __builtin_bit_cast(bf16x8, a[t][2]);
-      }
-      // 6 products per tile, smallest terms first; the G tiles alternate so that no MFMA waits for its predecessor
-#pragma unroll
-      for (int t = 0; t < G; ++t) {
-        if constexpr (ZERO && s == 0) {
-          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, zero, 0, 0, 0);
-        } else {
-          acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[grp * G + t], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[grp * G + t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bm, acc[grp * G + t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bh, acc[grp * G + t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bm, acc[grp * G + t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < G; ++t) acc[grp * G + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[grp * G + t], 0, 0, 0);
-      }
-    });
-    // last s-step of the layer: the pieces the (shorter) last chunk had no MFMA group for
-    if constexpr (OBJ_B3_SPREAD_DMA && s == NS - 1) {
-      constexpr int ng = (sl + 1) * NGRP;                                       // groups of the layer's last chunk
-      constexpr int done = (ng < GPCH - AD ? ng : GPCH - AD) * PPI;            // pieces its groups have issued
-      static_for<Stream::kPieces>([&](auto I) __attribute__((always_inline)) {
-        if constexpr (decltype(I)::value >= done) st.template piece_now<decltype(I)::value>();
-      });
-    }
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -1133,13 +939,12 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 // quantities the reference repeats over the samples (rendering.py:89-94) -- are not contracted per sample: their k-steps
 // are skipped (340 of 13,876 MFMAs per 32 points, 2.45 %) and  bias + W[:, those columns] . x  arrives once per ray from
 // ray_bias_kernel (objnerf_ray_bias), added in the layer's epilogue.  Same sums in another association: fp32-roundoff class.
-template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool B3 = false, bool HOIST = false>
+template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool HOIST = false>
 __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr) {
-  static_assert(!B3 || !SIGMA_ONLY, "split-bf16 mode: every layer (no density-only variant)");
   // (with SIGMA_ONLY: the object-branch density query, whose ONE code is constant over all points -- its share of
   // instance_encoding_1 / _3 arrives as a single vector at ray_bias, every point reads "ray" 0)
   static_assert(!HOIST || (FUSED && !SAVE && (!SIGMA_ONLY || (DO_OBJ && !DO_SCENE))), "hoisting: inference form of the fused kernel");
-  constexpr int kCB = B3 ? kB3ChunkBytes : kChunkBytes;       // bytes per weight chunk
+  constexpr int kCB = kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");
   // ONE __shared__ object (a second one makes hipcc drain vmcnt before every ds_read of a glds

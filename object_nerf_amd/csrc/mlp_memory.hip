@@ -27,10 +27,6 @@ int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hip
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
   if (sc && ob) return set_error(-1, "mlp_eval(memory): one branch per call (forward or forward_instance)");
   if (save_ws && a.sigma_only) return set_error(-1, "mlp_eval(memory): the training forward needs every layer");
-  if (a.mfma_bf16x3) {
-    if (save_ws || a.sigma_only) return set_error(-1, "mlp_eval(memory): the split-bf16 mode evaluates every layer, inference only");
-    return launch_mlp_memory_b3(a, ntiles, grid, s);
-  }
   if (a.use_voxel) {
     if (sc) launch<true, true, false>(a, ntiles, grid, s, save_ws);
     else launch<true, false, true>(a, ntiles, grid, s, save_ws);

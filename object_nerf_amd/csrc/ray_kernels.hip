@@ -907,20 +907,9 @@ __device__ __forceinline__ float blob_weight(const float* blob, bool vox, int l,
   const int chunk = ks / kg, kl = ks % kg, g4 = kl / 4, j = kl % 4, m = row >> 5, lane = (row & 31) + 32 * half;
   return blob[base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j];
 }
-// the same element of the split-bf16 stream: hi + mid + lo of the three planes (exactly the fp32 weight)
-__device__ __forceinline__ float blob_weight_b3(const void* blob, bool vox, int l, int ks, int half, int row) {
-  const int nt = layer_nt(l), spc = b3_steps_per_chunk(nt);
-  const int s = ks >> 3, j = ks & 7, chunk = s / spc, sl = s % spc, m = row >> 5, lane = (row & 31) + 32 * half;
-  const uint16_t* p = (const uint16_t*)((const char*)blob + ((long)layer_chunk_start(vox, l) + chunk) * kB3ChunkBytes +
-                                        (long)((sl * nt + m) * 3) * 1024 + lane * 16 + j * 2);
-  const float hi = __uint_as_float((uint32_t)p[0] << 16), mid = __uint_as_float((uint32_t)p[512] << 16),
-              lo = __uint_as_float((uint32_t)p[1024] << 16);
-  return (hi + mid) + lo;
-}
 // Step 1 (one workgroup per input column): the hoisted weight columns as a compact matrix wm[group][c][16] + bias[group][16], group = 16
 // consecutive floats of the per-ray vector (one (layer, out tile, lane half) of the MLP kernel's D layout), c = input
 // column (64 code columns or 27 direction columns) -- read from the packed stream by the packer's own layout arithmetic.
-template <bool B3>
 __global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs a, float* __restrict__ wm) {
   const int o = threadIdx.x;                  // position in the per-ray vector
   const int c = blockIdx.x;                   // input column (0..63 of the code, 0..26 of the direction embedding)
@@ -933,13 +922,13 @@ __global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs
   float w = 0.f;
   if (o < 256) {
     const int ks0 = ks_emb(vox) + (vox ? kKsObjVox : 0);        // first code k-step of the object input list (layout.h)
-    w = B3 ? blob_weight_b3(a.blob, vox, l, ks0 + (c & 31), c >> 5, row) : blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
+    w = blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
   } else if (c < kDirC) {
     const int nh = l == L_SD ? 128 : 64;
     // slot (i, h) of the direction list that holds column c (layout.h::dir_slot_col)
     for (int i = 0; i < kKsDir; ++i)
       for (int h = 0; h < 2; ++h)
-        if (dir_slot_col(i, h) == c) w = B3 ? blob_weight_b3(a.blob, vox, l, nh + i, h, row) : blob_weight(a.blob, vox, l, nh + i, h, row);
+        if (dir_slot_col(i, h) == c) w = blob_weight(a.blob, vox, l, nh + i, h, row);
   }
   wm[((long)g * 64 + c) * 16 + j] = w;
   if (c == 0) wm[kRbGroups * 64 * 16 + o] = a.aux[aux_bias_off(l) + q];
@@ -1102,26 +1091,6 @@ __global__ void pack_kernel(const uint32_t* __restrict__ idx, long n, const Para
   if (i >= n) return;
   const uint32_t e = idx[i];
   out[i] = e == kPackZero ? 0.f : pp.p[e >> 24][e & 0xFFFFFFu];
-}
-
-// split-bf16 packer: gather, split exactly into three bf16 pieces (truncation), scatter to the three planes
-__global__ void pack_b3_kernel(const uint32_t* __restrict__ idx, long n, const ParamPtrs pp, uint16_t* __restrict__ out) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const uint32_t ix = idx[e];
-  const float w = ix == kPackZero ? 0.f : pp.p[ix >> 24][ix & 0xFFFFFFu];
-  const uint32_t hi = __float_as_uint(w) & 0xffff0000u;
-  const float r1 = w - __uint_as_float(hi);
-  const uint32_t mid = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mid);
-  const uint32_t lo = __float_as_uint(r2) & 0xffff0000u;            // r2 has <= 8 significant bits: exact
-  const long chunk = e / kChunkFloats;
-  const int r = (int)(e - chunk * kChunkFloats);
-  const int q = r >> 9, lane = (r >> 3) & 63, j = r & 7;
-  uint16_t* o = out + (chunk * kB3ChunkBytes + (long)(q * 3) * 1024 + lane * 16 + j * 2) / 2;
-  o[0] = (uint16_t)(hi >> 16);
-  o[512] = (uint16_t)(mid >> 16);
-  o[1024] = (uint16_t)(lo >> 16);
 }
 
 }  // namespace objnerf
@@ -1433,37 +1402,10 @@ int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t
   hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, pp, blob);
   hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(na, 256)), dim3(256), 0, (hipStream_t)stream, aux_idx, na, pp, aux);
   // behind the aux block: the hoisted weight columns as the compact matrix objnerf_ray_bias reads (once per parameter
-  // version instead of once per call; the split-bf16 stream holds the same values, so the matrix serves both modes)
+  // version instead of once per call)
   RayBiasArgs a{blob, aux, nullptr, nullptr, 0, 0, use_voxel, 1, 1, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(ray_bias_weights_kernel<false>, dim3(64), dim3(448), 0, (hipStream_t)stream, a, aux + kAuxFloats);
+  hipLaunchKernelGGL(ray_bias_weights_kernel, dim3(64), dim3(448), 0, (hipStream_t)stream, a, aux + kAuxFloats);
   return check_launch("pack_weights");
-}
-
-int objnerf_pack_weights_b3(int use_voxel, const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob,
-                            void* stream) {
-  if (!blob_idx || !h_param_ptrs || !blob) return set_error(-1, "pack_weights_b3: bad arguments");
-  ParamPtrs pp;
-  for (int i = 0; i < kNumParamPtrs; ++i) {
-    if (!h_param_ptrs[i]) return set_error(-1, "pack_weights_b3: null parameter pointer");
-    pp.p[i] = h_param_ptrs[i];
-  }
-  const long n = objnerf_blob_floats(use_voxel);
-  hipLaunchKernelGGL(pack_b3_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, n, pp,
-                     (uint16_t*)blob);
-  return check_launch("pack_weights_b3");
-}
-
-int objnerf_pack_weights_bwd_b3(const uint32_t* blob_idx, const float* const* h_param_ptrs, void* blob, void* stream) {
-  if (!blob_idx || !h_param_ptrs || !blob) return set_error(-1, "pack_weights_bwd_b3: bad arguments");
-  ParamPtrs pp;
-  for (int i = 0; i < kNumParamPtrs; ++i) {
-    if (!h_param_ptrs[i]) return set_error(-1, "pack_weights_bwd_b3: null parameter pointer");
-    pp.p[i] = h_param_ptrs[i];
-  }
-  const long n = objnerf_bwd_blob_floats();
-  hipLaunchKernelGGL(pack_b3_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, n, pp,
-                     (uint16_t*)blob);
-  return check_launch("pack_weights_bwd_b3");
 }
 
 int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream) {

@@ -164,8 +164,7 @@ int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
     objnerf_mlp_args m;
     memset(&m, 0, sizeof(m));
     m.use_voxel = a->use_voxel;
-    m.blob = a->blob; m.aux = a->aux; m.mfma_bf16x3 = a->mfma_bf16x3;
-    if (a->mfma_bf16x3 && !a->rays) return set_error(-1, "mlp_train_forward: the split-bf16 mode needs the fused inputs (rays, z_vals)");
+    m.blob = a->blob; m.aux = a->aux;
     m.emb_xyz = a->emb_xyz; m.emb_dir = a->emb_dir; m.obj_voxel = a->obj_voxel; m.obj_code = a->obj_code;
     m.n_points = P;
     m.sigma = a->sigma; m.rgb = a->rgb; m.inst_sigma = a->inst_sigma; m.inst_rgb = a->inst_rgb;
@@ -262,7 +261,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   c.rc = check_launch("sigmoid_bwd");
   if (a->blob_bwd) {
     // one persistent MFMA kernel, gradient tiles stay in registers from layer to layer (mlp_bwd.hip)
-    if (!c.rc) c.rc = launch_mlp_bwd(a->blob_bwd, a->aux, P, a->workspace, scratch, d_sigma, t2, d_inst_sigma, t2i, obj, a->mfma_bf16x3 != 0, c.s);
+    if (!c.rc) c.rc = launch_mlp_bwd(a->blob_bwd, a->aux, P, a->workspace, scratch, d_sigma, t2, d_inst_sigma, t2i, obj, c.s);
   } else {
     // layer by layer: dX = dY W as a GEMM with the LeakyReLU backward in its epilogue
     lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, d.dirh(), 128, 0, w.dirh());

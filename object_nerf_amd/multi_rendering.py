@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .bbox import pack_boxes
 from .embedding_helper import EmbeddingVoxel
-from .rendering import _linspace, hoist_enabled, mfma_mode
+from .rendering import _linspace, hoist_enabled
 
 __all__ = ["render_rays_multi"]
 
@@ -107,10 +107,9 @@ def render_rays_multi(
                             "rgb_fine": of["rgb"], "depth_fine": of["depth"]})
         return results
 
-    b3 = mfma_mode() == "bf16x3"
     cfg = _lib.RenderMultiCfg(use_voxel=int(use_voxel), N_samples=S, N_importance=I, use_disp=int(bool(use_disp)),
                               perturb=float(perturb), noise_std=float(noise_std), white_back=int(bool(white_back)),
-                              mfma_bf16x3=int(b3), no_hoist=int(not hoist_enabled()))
+                              no_hoist=int(not hoist_enabled()))
     ws = torch.empty(l.objnerf_render_multi_workspace_bytes(C.byref(cfg), K, n), dtype=torch.uint8, device=dev)
     rin = _lib.RenderMultiIn()
     rin.n_rays, rin.K = n, K
@@ -119,11 +118,11 @@ def render_rays_multi(
     rin.h_rays, rin.h_obj_ids = h_rays, h_ids
     if table is not None:
         rin.code_table = table.data_ptr()
-    bc, ac = coarse.packed(split_bf16=b3)
+    bc, ac = coarse.packed()
     rin.blob_coarse, rin.aux_coarse = bc.data_ptr(), ac.data_ptr()
     keep = [rays_c, table, ws, bc, ac, boxes]
     if I > 0:
-        bf, af = models["fine"].packed(split_bf16=b3)
+        bf, af = models["fine"].packed()
         rin.blob_fine, rin.aux_fine = bf.data_ptr(), af.data_ptr()
         rin.u_det = _linspace(I, dev).data_ptr()
         keep += [bf, af]

@@ -19,6 +19,7 @@ inference only, slower, still no PyTorch arithmetic.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -35,13 +36,26 @@ _index_cache = {}   # (use_voxel, device) -> (blob_idx, aux_idx) uint32 device t
 
 # Parameter updates that do not bump `Tensor._version`: torch's FUSED optimizers (`Adam(fused=True)` writes the parameters
 # inside one multi-tensor kernel; measured: `_version` stays put, torch 2.10) -- the cached weight streams would go stale
-# silently.  Every torch.optim.Optimizer.step() therefore advances a process-wide epoch that is part of the cache key
-# (a re-gather costs a few microseconds of device time per model).
-_optimizer_epoch = [0]
+# silently.  A step of a torch.optim.Optimizer therefore advances the epoch of every live ObjectNeRF THAT OPTIMIZER OWNS A
+# PARAMETER OF (the epoch is part of the module's cache key; a re-gather costs a few microseconds of device time).  Steps of
+# optimizers that hold none of a module's parameters leave its cache alone (round 4 bumped one process-wide counter).
+_live_models = weakref.WeakSet()
+_optimizer_param_ids = weakref.WeakKeyDictionary()      # optimizer -> (number of parameters, frozenset of their ids)
 
 
-def _on_optimizer_step(*_args, **_kwargs):
-    _optimizer_epoch[0] += 1
+def _on_optimizer_step(optimizer, *_args, **_kwargs):
+    try:
+        n = sum(len(g["params"]) for g in optimizer.param_groups)
+        cached = _optimizer_param_ids.get(optimizer)
+        if cached is None or cached[0] != n:
+            cached = (n, frozenset(id(p) for g in optimizer.param_groups for p in g["params"]))
+            _optimizer_param_ids[optimizer] = cached
+        ids = cached[1]
+    except Exception:                   # an optimizer we cannot introspect: be safe, invalidate every model
+        ids = None
+    for m in list(_live_models):
+        if ids is None or not ids.isdisjoint(m._param_ids()):
+            m._opt_epoch += 1
 
 
 try:
@@ -63,23 +77,12 @@ def _pack_index(use_voxel, device):
     return _index_cache[key]
 
 
-def _pack_index_b3(use_voxel, device):
-    key = ("b3", bool(use_voxel), str(device))
-    if key not in _index_cache:
-        l = _lib.lib()
-        bi = torch.empty(l.objnerf_blob_floats(int(use_voxel)), dtype=torch.int32)
-        _lib.check(l.objnerf_pack_index_b3(int(use_voxel), C.c_void_p(bi.data_ptr())), "pack_index_b3")
-        _index_cache[key] = bi.to(device)
-    return _index_cache[key]
-
-
-def _pack_index_bwd(use_voxel, device, b3=False):
-    key = ("bwd_b3" if b3 else "bwd", bool(use_voxel), str(device))
+def _pack_index_bwd(use_voxel, device):
+    key = ("bwd", bool(use_voxel), str(device))
     if key not in _index_cache:
         l = _lib.lib()
         bi = torch.empty(l.objnerf_bwd_blob_floats(), dtype=torch.int32)
-        fn = l.objnerf_pack_index_bwd_b3 if b3 else l.objnerf_pack_index_bwd
-        _lib.check(fn(int(use_voxel), C.c_void_p(bi.data_ptr())), "pack_index_bwd")
+        _lib.check(l.objnerf_pack_index_bwd(int(use_voxel), C.c_void_p(bi.data_ptr())), "pack_index_bwd")
         _index_cache[key] = bi.to(device)
     return _index_cache[key]
 
@@ -147,8 +150,9 @@ class ObjectNeRF(nn.Module):
         self._packed_key = None
         self._packed_bwd = None
         self._packed_bwd_key = None
-        self._packed_b3 = None
-        self._packed_b3_key = None
+        self._opt_epoch = 0                 # advanced by steps of optimizers that own one of this module's parameters
+        self._param_id_cache = None
+        _live_models.add(self)
 
     # ---- weight stream ---------------------------------------------------------------------
     def invalidate_packed(self):
@@ -161,7 +165,7 @@ class ObjectNeRF(nn.Module):
         reduction + host read per parameter set and call: a debugging aid, not for production)."""
         self._packed = self._packed_key = None
         self._packed_bwd = self._packed_bwd_key = None
-        self._packed_b3 = self._packed_b3_key = None
+        self._param_id_cache = None
 
     def _load_from_state_dict(self, *args, **kwargs):
         self.invalidate_packed()
@@ -171,8 +175,14 @@ class ObjectNeRF(nn.Module):
         self.invalidate_packed()
         return super()._apply(fn, *args, **kwargs)
 
+    def _param_ids(self):
+        if self._param_id_cache is None:
+            self._param_id_cache = frozenset(id(p) for p in self.parameters())
+        return self._param_id_cache
+
     def _pack_key(self, params):
-        key = tuple((p.data_ptr(), p._version) for p in params) + (_optimizer_epoch[0],)
+        _live_models.add(self)          # (also modules that were unpickled / deep-copied: __init__ did not run for them)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (getattr(self, "_opt_epoch", 0),)
         if os.environ.get("OBJNERF_PACK_CHECK") == "1":
             with torch.no_grad():
                 key += (float(sum(p.detach().double().sum() for p in params)),)
@@ -189,25 +199,11 @@ class ObjectNeRF(nn.Module):
             out += [m.weight, m.bias]
         return out
 
-    def packed(self, split_bf16=False):
+    def packed(self):
         """(blob, aux) device tensors for the kernel; re-gathered when any parameter changed
-        (optimizer step, load_state_dict, .to()) -- keyed on (data_ptr, _version).
-        split_bf16: the blob of the split-bf16 arithmetic mode (rendering.mfma_mode()); aux is shared."""
+        (optimizer step, load_state_dict, .to()) -- keyed on (data_ptr, _version) + the module's optimizer-step epoch."""
         params = self._param_list()
         key = self._pack_key(params)
-        if split_bf16:
-            _, aux = self.packed()
-            if self._packed_b3 is None or key != self._packed_b3_key:
-                l = _lib.lib()
-                uv = int(self.use_voxel_embedding)
-                dev = params[0].device
-                srcs = [_lib.as_f32(p.detach()) for p in params]
-                idx = _pack_index_b3(uv, dev)
-                blob = torch.empty(l.objnerf_b3_blob_bytes(uv) // 4, dtype=torch.float32, device=dev)
-                table = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
-                _lib.check(l.objnerf_pack_weights_b3(uv, _lib.ptr(idx), table, _lib.ptr(blob), _lib.stream_ptr()), "pack_weights_b3")
-                self._packed_b3, self._packed_b3_key = blob, key
-            return self._packed_b3, aux
         if self._packed is not None and key == self._packed_key:
             return self._packed
         dev = params[0].device
@@ -231,24 +227,13 @@ class ObjectNeRF(nn.Module):
         self._packed, self._packed_key = (blob, aux), key
         return self._packed
 
-    def packed_bwd(self, split_bf16=False):
+    def packed_bwd(self):
         """Training only: device tensor with the transposed hidden-block weight stream of the fused backward
-        (objnerf_pack_weights_bwd[_b3]), re-gathered like `packed()` when a parameter changed."""
+        (objnerf_pack_weights_bwd), re-gathered like `packed()` when a parameter changed."""
         params = self._param_list()
-        key = (bool(split_bf16),) + self._pack_key(params)
+        key = self._pack_key(params)
         if self._packed_bwd is not None and key == self._packed_bwd_key:
             return self._packed_bwd
-        if split_bf16:
-            dev = params[0].device
-            _lib.require_cuda(params[0], "ObjectNeRF parameters")
-            l = _lib.lib()
-            srcs = [_lib.as_f32(p.detach()) for p in params]
-            idx = _pack_index_bwd(int(self.use_voxel_embedding), dev, b3=True)
-            blob = torch.empty(l.objnerf_bwd_blob_floats() * 6 // 4, dtype=torch.float32, device=dev)
-            table = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
-            _lib.check(l.objnerf_pack_weights_bwd_b3(_lib.ptr(idx), table, _lib.ptr(blob), _lib.stream_ptr()), "pack_weights_bwd_b3")
-            self._packed_bwd, self._packed_bwd_key = blob, key
-            return blob
         dev = params[0].device
         _lib.require_cuda(params[0], "ObjectNeRF parameters")
         l = _lib.lib()
@@ -288,16 +273,11 @@ class ObjectNeRF(nn.Module):
             return (sg, c) if scene else (isg, ic)
         if emb_dir is None:   # sigma_only callers may omit it (tools/extract_mesh.py:85-108)
             emb_dir = torch.zeros(n, self.in_channels_dir, device=dev)
-        # OBJNERF_MFMA=bf16x3: the split-bf16 arithmetic mode also for these stand-alone forwards (the density-only variant
-        # stays on the fp32 kernel: it exists for extract_mesh.py's grid query, where the mode is not offered)
-        from .rendering import mfma_mode
-        b3 = mfma_mode() == "bf16x3" and not sigma_only
-        blob, aux = self.packed(split_bf16=b3)
+        blob, aux = self.packed()
         a = _lib.MlpArgs()
         a.use_voxel = int(self.use_voxel_embedding)
         a.do_scene, a.do_object = (1, 0) if scene else (0, 1)
         a.sigma_only = int(bool(sigma_only))
-        a.mfma_bf16x3 = int(b3)
         a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
         exyz, edir = _lib.as_f32(emb_xyz), _lib.as_f32(emb_dir)
         a.emb_xyz, a.emb_dir, a.n_points = exyz.data_ptr(), edir.data_ptr(), n

@@ -76,16 +76,6 @@ def _out_struct(o):
     return s
 
 
-def mfma_mode():
-    """Arithmetic of the fused inference MLP kernel: "f32" (default; v_mfma_f32_32x32x2_f32) or "bf16x3" (the same fp32
-    contraction on the bf16 matrix pipe: operands split exactly into three bf16 pieces, 6 of 9 cross products, fp32
-    accumulation; include/objnerf_hip.h).  Selected per call by the environment variable OBJNERF_MFMA."""
-    m = os.environ.get("OBJNERF_MFMA", "f32")
-    if m not in ("f32", "bf16x3"):
-        raise RuntimeError("OBJNERF_MFMA must be 'f32' or 'bf16x3', got %r" % m)
-    return m
-
-
 def composite_mode():
     """Where a pass without occlusion mask / noise composites: "fused" (default; in the MLP kernel's epilogue, sigma / rgb
     never written, include/objnerf_hip.h objnerf_mlp_args.comp_*) or "separate" (MLP kernel, then objnerf_composite).
@@ -97,7 +87,7 @@ def composite_mode():
 
 
 def hoist_enabled():
-    """fp32 inference passes take the terms that are constant along a ray (the object code's and the direction embedding's
+    """Inference passes take the terms that are constant along a ray (the object code's and the direction embedding's
     share of four layers) from per-ray vectors instead of contracting them per sample point (include/objnerf_hip.h,
     objnerf_mlp_args.ray_bias).  OBJNERF_HOIST=0 switches that off (A/B timing, tolerance tests)."""
     m = os.environ.get("OBJNERF_HOIST", "1")
@@ -131,8 +121,6 @@ def _train_packs(coarse, fine):
     if mode == "1":
         return None
 
-    b3 = mfma_mode() == "bf16x3"      # split-bf16 arithmetic in the two fused kernels (the GEMMs stay fp32 MFMA)
-
     # a training call never trusts the cache: whatever updated the parameters since the last call (a fused or third-party
     # optimizer, `.data` writes) may not have bumped `_version`, and the weights change every step anyway
     for m in {id(m): m for m in (coarse, fine) if m is not None}.values():
@@ -141,8 +129,8 @@ def _train_packs(coarse, fine):
     def one(m):
         if m is None:
             return None
-        blob, aux = m.packed(split_bf16=b3)
-        return (None if mode == "fwd" else blob, aux, None if mode == "bwd" else m.packed_bwd(split_bf16=b3), b3)
+        blob, aux = m.packed()
+        return (None if mode == "fwd" else blob, aux, None if mode == "bwd" else m.packed_bwd())
     return (one(coarse), one(fine))
 
 
@@ -280,7 +268,7 @@ def render_rays(
         perturb=float(perturb), noise_std=float(noise_std), white_back=int(bool(white_back)),
         forward_instance=int(bool(forward_instance)), is_eval=int(is_eval),
         use_zero_as_last_delta=int(use_zero_as_last_delta), frustum_bound_th=float(frustum_bound_th),
-        rays_in_bbox=int(bool(rays_in_bbox)), mfma_bf16x3=int(mfma_mode() == "bf16x3"),
+        rays_in_bbox=int(bool(rays_in_bbox)),
         separate_composite=int(composite_mode() == "separate"), no_hoist=int(not hoist_enabled()))
     l = _lib.lib()
     ws = torch.empty(l.objnerf_render_workspace_bytes(C.byref(cfg), n), dtype=torch.uint8, device=dev)
@@ -293,10 +281,10 @@ def render_rays(
         ptm = pass_through_mask.reshape(n).to(torch.uint8).contiguous()
         rin.pass_through_mask = ptm.data_ptr()
         keep.append(ptm)
-    bc, ac = coarse.packed(split_bf16=bool(cfg.mfma_bf16x3))
+    bc, ac = coarse.packed()
     rin.blob_coarse, rin.aux_coarse = bc.data_ptr(), ac.data_ptr()
     if I > 0:
-        bf, af = models["fine"].packed(split_bf16=bool(cfg.mfma_bf16x3))
+        bf, af = models["fine"].packed()
         rin.blob_fine, rin.aux_fine = bf.data_ptr(), af.data_ptr()
     if use_voxel:
         rin.grid = emb_xyz.grid_struct()

@@ -9,4 +9,3 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
-    config.addinivalue_line("markers", "single_mode: GPU test that does not depend on OBJNERF_MFMA (run once, not per mode)")

@@ -77,7 +77,6 @@ def fine_pass_on_reference_depths(sc, case, g, device="cuda"):
     import ctypes as C
     import cases
     from object_nerf_amd import _lib
-    from object_nerf_amd.rendering import mfma_mode
     c = cases.RENDER_CASES[case]
     use_voxel = cases.SCENES[c["scene"]][0]
     rays, ids, ptm, _ = cases.render_inputs(case)
@@ -88,11 +87,10 @@ def fine_pass_on_reference_depths(sc, case, g, device="cuda"):
         codes = sc.code_library({"instance_ids": ids.to(device)})["embedding_instance"].contiguous()
     z = g["z_vals_fine"].to(device).contiguous()
     rays_d = rays.to(device)
-    b3 = mfma_mode() == "bf16x3"
-    blob, aux = sc.models["fine"].packed(split_bf16=b3)
+    blob, aux = sc.models["fine"].packed()
     buf = {k: torch.empty(n, S, *sh, device=device) for k, sh in dict(sigma=(), rgb=(3,), isig=(), irgb=(3,)).items()}
     a = _lib.MlpArgs()
-    a.use_voxel, a.do_scene, a.do_object, a.mfma_bf16x3 = int(use_voxel), 1, 1, int(b3)
+    a.use_voxel, a.do_scene, a.do_object = int(use_voxel), 1, 1
     a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
     a.rays, a.z_vals, a.n_rays, a.S = rays_d.data_ptr(), z.data_ptr(), n, S
     a.codes, a.code_stride = codes.data_ptr(), 64
@@ -136,22 +134,6 @@ def moved_rays(z_ours, z_ref, z_coarse, frac=0.25):
 def rel_l2(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
-
-
-import pytest  # noqa: E402
-
-MFMA_MODES = ["f32", "bf16x3"]
-
-
-@pytest.fixture(autouse=True, params=MFMA_MODES)
-def mfma_mode(request, monkeypatch):
-    """GPU test modules import this autouse fixture: every test in them runs once per arithmetic mode of the fused MLP
-    kernels (OBJNERF_MFMA: fp32 MFMA, and the opt-in split-bf16 mode), same tolerances.  Tests that never reach those
-    kernels are marked `single_mode` and run once."""
-    if request.node.get_closest_marker("single_mode") is not None and request.param != "f32":
-        pytest.skip("mode-independent test")
-    monkeypatch.setenv("OBJNERF_MFMA", request.param)
-    return request.param
 
 
 # ---- image-scale cases (cases.FRAME_CASES): the HIP path on a whole 160x120 frame against the reference's frame ----------

@@ -60,20 +60,9 @@ def test_pack_index_is_a_bijection(use_voxel):
 
 
 @pytest.mark.parametrize("use_voxel", [1, 0])
-def test_other_weight_streams_reference_the_right_elements(use_voxel):
-    """split-bf16 stream: the same multiset of weight elements as the fp32 stream (it is the same weights in another
-    order, three planes each); backward stream: exactly the hidden-to-hidden blocks, each element once."""
+def test_backward_weight_stream_references_the_right_elements(use_voxel):
+    """backward stream: exactly the hidden-to-hidden blocks, each element once."""
     l = _lib.lib()
-    nb, na = l.objnerf_blob_floats(use_voxel), l.objnerf_aux_floats()
-    bi, ai = torch.empty(nb, dtype=torch.int32), torch.empty(na, dtype=torch.int32)
-    _lib.check(l.objnerf_pack_index(use_voxel, C.c_void_p(bi.data_ptr()), C.c_void_p(ai.data_ptr())), "pack_index")
-    b3 = torch.empty(nb, dtype=torch.int32)
-    _lib.check(l.objnerf_pack_index_b3(use_voxel, C.c_void_p(b3.data_ptr())), "pack_index_b3")
-    assert l.objnerf_b3_blob_bytes(use_voxel) == nb * 6                 # 3 planes x 2 bytes per element
-    a, b = bi.numpy().view("uint32"), b3.numpy().view("uint32")
-    assert (np.sort(a[a != 0xFFFFFFFF]) == np.sort(b[b != 0xFFFFFFFF])).all()
-    assert (a != 0xFFFFFFFF).sum() == (b != 0xFFFFFFFF).sum() > 500_000
-
     nbw = l.objnerf_bwd_blob_floats()
     bw = torch.empty(nbw, dtype=torch.int32)
     _lib.check(l.objnerf_pack_index_bwd(use_voxel, C.c_void_p(bw.data_ptr())), "pack_index_bwd")
@@ -90,10 +79,6 @@ def test_other_weight_streams_reference_the_right_elements(use_voxel):
             "xyz_encoding_5.0", "xyz_encoding_4.0", "xyz_encoding_3.0", "xyz_encoding_2.0", "inst_dir_encoding.0",
             "instance_encoding_final.0", "instance_encoding_4.0", "instance_encoding_3.0", "instance_encoding_2.0"}
     assert ids == {2 * names.index(n) for n in want}
-    # its split-bf16 layout streams the same elements
-    bw3 = torch.empty(nbw, dtype=torch.int32)
-    _lib.check(l.objnerf_pack_index_bwd_b3(use_voxel, C.c_void_p(bw3.data_ptr())), "pack_index_bwd_b3")
-    assert (np.sort(bw3.numpy().view("uint32")) == np.sort(w)).all()
 
 
 def test_module_types_and_state_dict_names():
@@ -196,8 +181,6 @@ def test_c_abi_argument_validation():
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * (128 // 32) * _lib.SEG_REC_FLOATS + 256
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64)
-    assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * (1000 * (128 // 32) * _lib.SEG_REC_FLOATS + rb_total) + 256
-    cfg = _lib.RenderCfg(N_samples=64, N_importance=64, mfma_bf16x3=1)            # the split-bf16 mode hoists as well
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * (1000 * (128 // 32) * _lib.SEG_REC_FLOATS + rb_total) + 256
     for kw in (dict(noise_std=1.0), dict(is_eval=0, frustum_bound_th=0.025)):        # noise / occlusion mask: two-kernel form
         c2 = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1, **kw)

@@ -17,7 +17,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ARGV = ["--steps", "2", "--warmup", "1", "--width", "12", "--height", "9", "--max-voxels", "120000", "--cpu-rays", "0",
-        "--split-bf16-steps", "0", "--pmc", "off"]
+        "--pmc", "off"]
 
 
 def _free_port():

@@ -17,7 +17,6 @@ import torch
 
 import cases
 import helpers as H
-from helpers import mfma_mode  # noqa: F401  (autouse: both arithmetic modes)
 import object_nerf_amd as A
 from object_nerf_amd.multi_rendering import render_rays_multi
 
@@ -191,7 +190,6 @@ def test_editable_renderer_chunk_loops(scene, gold, scenario, prefix, n_sets):
     H.grade_multi(out, g, scenario, f64, all_sets, n_samples=calls[0]["scalars"]["N_samples"])
 
 
-@pytest.mark.single_mode
 def test_editor_ray_generation_on_the_device(gold):
     """Row f2 through the reference's unchanged caller: in the build container EditableRenderer.render_edit /
     render_origin ran over dropin/datasets/ray_utils.py and dropin/utils/bbox_utils.py (the host slab test of
@@ -245,7 +243,6 @@ def test_editor_ray_generation_on_the_device(gold):
         assert torch.equal((got[:, 7] > 0).cpu(), want[:, 7] > 0) and H.normwise(got, want) < 2e-6
 
 
-@pytest.mark.single_mode
 def test_stagewise_ray_generation_equals_the_fused_kernel():
     """640x480: get_ray_directions + get_rays + ray_bbox_intersections (the stages the reference's caller issues) are
     bit-equal to the one-kernel objnerf_generate_rays (same device functions), and the row-subset form writes exactly the

@@ -14,7 +14,6 @@ import torch
 
 import cases
 import helpers as H
-from helpers import mfma_mode  # noqa: F401  (autouse: both arithmetic modes)
 import object_nerf_amd as A
 from object_nerf_amd import checkpoint
 from object_nerf_amd.multi_rendering import render_rays_multi
@@ -69,7 +68,6 @@ def test_reference_checkpoint_renders_multi_like_the_reference():
     assert H.psnr(r["rgb_fine"], g["rgb_fine"]) >= 60.0
 
 
-@pytest.mark.single_mode
 def test_export_reloads_strictly_and_renders_bit_equal():
     ckpt, sc = load()
     sd = ckpt["state_dict"]

@@ -17,7 +17,7 @@ from object_nerf_amd.distributed import GradientSync
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "3", "--warmup", "1", "--width", "320", "--height", "240", "--max-voxels", "120000", "--cpu-rays", "0",
-         "--split-bf16-steps", "0", "--pmc", "off", "--train-steps", "0"]
+         "--pmc", "off", "--train-steps", "0"]
 
 
 def _bench(extra, env=None):
@@ -72,7 +72,6 @@ def test_bench_default_line_carries_cpu_baseline():
     small[i + 1] = "96"
     small[small.index("--train-steps") + 1] = "8"
     e = dict(os.environ)
-    e.pop("OBJNERF_MFMA", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, env=e, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])

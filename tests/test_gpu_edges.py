@@ -5,7 +5,6 @@ import torch
 
 import cases
 import helpers as H
-from helpers import mfma_mode  # noqa: F401  (autouse: every test below runs in both arithmetic modes)
 import object_nerf_amd as A
 from object_nerf_amd import synth
 from object_nerf_amd.multi_rendering import render_rays_multi
@@ -62,7 +61,6 @@ def test_single_ray_and_empty_batch():
     assert e["rgb_fine"].shape == (0, 3) and e["weights_fine"].shape == (0, 128)
 
 
-@pytest.mark.single_mode
 def test_too_many_samples_is_an_error_not_a_crash():
     sc = scene("plain")
     rays = H.test_rays(2).to(DEV)
@@ -115,7 +113,6 @@ def test_non_contiguous_and_float64_inputs_are_accepted():
         assert a[k].dtype == torch.float32 and torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.single_mode
 def test_ray_sets_of_other_widths_are_rejected():
     """8 columns, or 10 with the fine-depth clip of multi_rendering.py:277-285 (tests/test_gpu_render.py grades that one
     against the reference); anything else is an error, never a silent truncation"""
@@ -148,7 +145,6 @@ def test_random_inputs_in_other_dtypes_are_kept_alive_and_used():
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.single_mode
 def test_invalidate_packed_after_data_writes():
     """in-place writes through `.data` do not bump `_version`: the cached weight stream is stale until
     invalidate_packed() (or OBJNERF_PACK_CHECK=1) -- documented contract of nerf_model.ObjectNeRF.packed()"""

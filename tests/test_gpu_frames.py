@@ -18,7 +18,6 @@ import torch
 
 import cases
 import helpers as H
-from helpers import mfma_mode  # noqa: F401  (autouse: both arithmetic modes)
 import object_nerf_amd as A
 
 pytestmark = pytest.mark.gpu
@@ -78,7 +77,6 @@ def test_full_size_frame_matches_the_reference_frame():
     assert dl2 <= H.FLOOR_FACTOR * float(small["_floor_l2_depth_fine"]), dl2
 
 
-@pytest.mark.single_mode
 def test_edit_demo_frame_from_device_generated_rays():
     """the same configs[4] frame with the three ray sets written by objnerf_generate_rays (row f2) instead of the
     reference's CPU ray / box code: identical hit masks, rays within 2e-6, and the frame still matches the reference's"""

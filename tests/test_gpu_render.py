@@ -6,8 +6,8 @@ Tolerances.  Coarse-pass keys are held to the BASELINE contract, 1e-4 normwise; 
 the oracle run in float64 on the same inputs).  Fine-pass keys sit on the importance-sampling noise
 floor: the reference's own fp32 result moves by 1e-4..1e-1 (normwise, weights_/z_vals_/depth_) when
 the same code runs in fp64, so end to end they are graded against that floor:
-error vs the fp32 reference <= 3x floor in BOTH arithmetic modes (measured worst ratios 1.84 fp32 MFMA and 2.49
-split-bf16, profiles/r02_parity.md; round 1 needed 20x because its sampler
+error vs the fp32 reference <= 3x floor (measured worst ratio 1.84, profiles/r02_parity.md; round 1 needed 20x
+because its sampler
 summed the cdf in fp32 where the reference's CPU cumsum accumulates in float64 -- DESIGN.md §3.3),
 plus: no more rays whose importance samples MOVED (helpers.moved_rays) than the float64 oracle
 itself has + 1, PSNR(ours, reference) >= 60 dB and |dPSNR| <= 0.1 dB against a fixed synthetic
@@ -21,7 +21,6 @@ import torch
 
 import cases
 import helpers as H
-from helpers import mfma_mode  # noqa: F401  (autouse: every test below runs in both arithmetic modes)
 import object_nerf_amd as A
 from object_nerf_amd import synth
 from object_nerf_amd.multi_rendering import render_rays_multi
@@ -104,7 +103,6 @@ def test_fine_pass_teacher_forced(case):
         assert err <= 1e-4, "%s/%s teacher-forced: %.3e" % (case, gk, err)
 
 
-@pytest.mark.single_mode
 @pytest.mark.parametrize("case", ["voxel_eval", "plain_eval", "voxel_imp128", "plain_odd_sizes", "voxel_random"])
 def test_sample_pdf_merge_teacher_forced(case):
     """inverse-CDF sampling + merge on the REFERENCE's coarse weights / depths"""
@@ -291,34 +289,6 @@ def test_full_frame_properties():
     assert psnr(r["rgb_fine"][idx].cpu(), ro["rgb_fine"]) >= 60.0
 
 
-@pytest.mark.single_mode
-def test_split_bf16_mode_matches_f32_mfma_mode(monkeypatch):
-    """OBJNERF_MFMA=bf16x3 (the fp32 contraction on the bf16 matrix pipe: operands split exactly into three bf16 pieces,
-    6 of 9 products, fp32 accumulation) against the default fp32-MFMA kernel on a batch where every workgroup loops over
-    several tiles, and against the reference's golden outputs through the ordinary parity test of one case."""
-    sc = cases.scene_for(A, "voxel", device=DEV)
-    rays = synth.camera_rays(160, 120).to(DEV)
-    n = rays.shape[0]
-    ids = synth.per_ray_ids(n).to(DEV)
-    with torch.no_grad():
-        codes = sc.code_library({"instance_ids": ids})["embedding_instance"].contiguous()
-        kw = dict(N_samples=64, N_importance=64, perturb=0, noise_std=0, embedding_instance=codes, is_eval=True)
-        monkeypatch.delenv("OBJNERF_MFMA", raising=False)
-        r32 = A.render_rays(sc.models, sc.embeddings, rays, **kw)
-        monkeypatch.setenv("OBJNERF_MFMA", "bf16x3")
-        rb3 = A.render_rays(sc.models, sc.embeddings, rays, **kw)
-        rb3_again = A.render_rays(sc.models, sc.embeddings, rays, **kw)
-    for k in r32:
-        assert torch.isfinite(rb3[k]).all(), k
-        assert torch.equal(rb3[k], rb3_again[k]), "non-deterministic: " + k
-        if k.endswith("coarse"):
-            assert H.normwise(rb3[k], r32[k]) < 2e-5, k          # measured ~2e-6: fp32-roundoff class
-    assert psnr(rb3["rgb_fine"].cpu(), r32["rgb_fine"].cpu()) >= 70.0     # fine pass: sampler sensitivity, see above
-    monkeypatch.setenv("OBJNERF_MFMA", "fp16")
-    with pytest.raises(RuntimeError), torch.no_grad():
-        A.render_rays(sc.models, sc.embeddings, rays[:8].contiguous(), **dict(kw, embedding_instance=codes[:8]))
-
-
 @pytest.mark.parametrize("multi", [False, True])
 def test_a_whole_call_is_capturable_in_a_hip_graph(multi):
     """the library only enqueues on the caller's stream, never allocates and never synchronises, so a whole render_rays /
@@ -488,6 +458,6 @@ def test_batches_beyond_one_slab_are_walked_in_slabs():
             rs = A.render_rays(sc.models, sc.embeddings, rays[lo:hi].contiguous(), embedding_instance=codes[lo:hi].contiguous(), **kw)
             for k in r:
                 assert torch.equal(r[k][lo:hi], rs[k]), "slab-dependent: %s at rays [%d, %d)" % (k, lo, hi)
-    cfg = _lib.RenderCfg(N_samples=32, N_importance=32, is_eval=1, mfma_bf16x3=int(os.environ.get("OBJNERF_MFMA") == "bf16x3"))
+    cfg = _lib.RenderCfg(N_samples=32, N_importance=32, is_eval=1)
     l = _lib.lib()
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), n) == l.objnerf_render_workspace_bytes(C.byref(cfg), 1 << 20)

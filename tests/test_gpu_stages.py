@@ -68,12 +68,9 @@ def test_voxel_embed_matches_reference(sname):
     assert s[4, :16].abs().max().item() == 0 and o[5, :8].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("sname", ["voxel", "plain"])
-def test_mlp_branches_match_reference(sname, mode, monkeypatch):
-    """ObjectNeRF.forward / forward_instance on identical pre-embedded inputs (memory-form kernel), in both arithmetic modes
-    of the MLP kernel at the SAME tolerance: fp32 MFMA, and the split-bf16 mode (the fp32 contraction on the bf16 matrix pipe)"""
-    monkeypatch.setenv("OBJNERF_MFMA", mode)
+def test_mlp_branches_match_reference(sname):
+    """ObjectNeRF.forward / forward_instance on identical pre-embedded inputs (memory-form kernel)"""
     g = cases.load_golden("stage_mlp_" + sname)
     m = scene(sname).models["coarse"]
     i = {k: (v.to(DEV) if v is not None else None) for k, v in cases.mlp_inputs(sname == "voxel").items()}
@@ -82,14 +79,9 @@ def test_mlp_branches_match_reference(sname, mode, monkeypatch):
         oi = m.forward_instance(i)
         so = m({"emb_xyz": i["emb_xyz"]}, sigma_only=True)
         soi = m.forward_instance(i, sigma_only=True)
-    # sigma_only launches the density-only kernel variant (skips final/dir/rgb layers): same values (that variant is
-    # fp32-MFMA in either mode, so in the split-bf16 mode it agrees to roundoff instead of bit for bit)
+    # sigma_only launches the density-only kernel variant (skips final/dir/rgb layers): same values, bit for bit
     assert list(so) == ["sigma"] and list(soi) == ["inst_sigma"]
-    if mode == "f32":
-        assert torch.equal(so["sigma"], o["sigma"]) and torch.equal(soi["inst_sigma"], oi["inst_sigma"])
-    else:
-        check(so["sigma"], o["sigma"], 1e-5, "sigma_only vs split-bf16 sigma")
-        check(soi["inst_sigma"], oi["inst_sigma"], 1e-5, "sigma_only vs split-bf16 inst_sigma")
+    assert torch.equal(so["sigma"], o["sigma"]) and torch.equal(soi["inst_sigma"], oi["inst_sigma"])
     assert o["sigma"].shape == (200, 1) and o["rgb"].shape == (200, 3)
     for a, k in ((o["sigma"], "sigma"), (o["rgb"], "rgb"), (oi["inst_sigma"], "inst_sigma"), (oi["inst_rgb"], "inst_rgb")):
         check(a, g[k], 1e-5, "mlp/%s/%s" % (sname, k))
@@ -378,19 +370,17 @@ def test_compact_rays_matches_nonzero(n):
 def test_mlp_eval_on_a_ray_subset(branch):
     """objnerf_mlp_args.ray_index / n_active: the listed rays get exactly the values of a full evaluation, the other
     rays' outputs are not touched; an empty list launches and writes nothing"""
-    from object_nerf_amd.rendering import mfma_mode
     sc = scene("voxel")
     rays = H.test_rays(97, stride=31).to(DEV)
     n, S = rays.shape[0], 24
     z = (rays[:, 6:7] + (rays[:, 7:8] - rays[:, 6:7]) * torch.linspace(0, 1, S, device=DEV)).contiguous()
-    b3 = mfma_mode() == "bf16x3"
-    blob, aux = sc.models["coarse"].packed(split_bf16=b3)
+    blob, aux = sc.models["coarse"].packed()
     code = sc.code_library.embedding_instance.weight.detach()[4].contiguous()
     l = _lib.lib()
 
     def run(index, count, sigma, rgb):
         a = _lib.MlpArgs()
-        a.use_voxel, a.mfma_bf16x3 = 1, int(b3)
+        a.use_voxel = 1
         a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
         a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), z.data_ptr(), n, S
         a.grid = sc.embeddings["xyz"].grid_struct()
@@ -417,7 +407,6 @@ def test_mlp_eval_on_a_ray_subset(branch):
         assert (sub_s[~on] == 123.0).all() and (sub_c[~on] == 123.0).all()
 
 
-@pytest.mark.single_mode
 @pytest.mark.parametrize("K,S,where", [(20, 128, "LDS beyond the default 64 KiB"), (3, 2100, "global staging"), (40, 150, "global staging, 40 sets")])
 def test_composite_multi_has_no_sample_limit(K, S, where):
     """the reference sorts any K*S (multi_rendering.py:112); until round 3 the kernel refused K*S > 2340 and K > 16.  Now:
@@ -456,7 +445,6 @@ def test_composite_multi_has_no_sample_limit(K, S, where):
         check(own[i], ref["weights"][ref["obj_ids"] == i].view(n, S), 5e-5, "own weights %d" % i)
 
 
-@pytest.mark.single_mode
 @pytest.mark.parametrize("variant", ["ascending_with_ties", "one_set_descending", "noise_white"])
 def test_composite_multi_matches_oracle(variant):
     """objnerf_composite_multi (joint stable depth sort + compositing, multi_rendering.py:96-157) against the oracle:
@@ -502,14 +490,12 @@ def test_composite_multi_matches_oracle(variant):
         check(own[i], want, 2e-5, "own weights %d" % i)
 
 
-@pytest.mark.parametrize("b3", [False, True])
 @pytest.mark.parametrize("sname", ["voxel", "plain"])
-def test_hoisted_per_ray_terms_match_the_per_sample_contraction(sname, b3):
+def test_hoisted_per_ray_terms_match_the_per_sample_contraction(sname):
     """objnerf_ray_bias + objnerf_mlp_args.ray_bias (the object code's and the direction embedding's share of four layers
     computed once per ray, their k-steps skipped in the MLP kernel: 2.45 % fewer MFMAs) against the same kernel contracting
     every term per sample point -- same sums in another association: sigma / rgb of both branches within 2e-6 (normwise), on a
-    batch whose rays straddle waves (S = 40) and on one with S = 64; per-ray codes; fp32-MFMA and split-bf16 arithmetic
-    (there whole 8-k-step groups are skipped and the hoisted k-steps of a partly covered group enter as zeros)."""
+    batch whose rays straddle waves (S = 40) and on one with S = 64; per-ray codes."""
     sc = cases.scene_for(A, sname, device=DEV)
     use_voxel = cases.SCENES[sname][0]
     l = _lib.lib()
@@ -518,12 +504,12 @@ def test_hoisted_per_ray_terms_match_the_per_sample_contraction(sname, b3):
         n = rays.shape[0]
         z = (rays[:, 6:7] + (rays[:, 7:8] - rays[:, 6:7]) * torch.linspace(0, 1, S, device=DEV)).contiguous()
         codes = sc.code_library({"instance_ids": synth.per_ray_ids(n, seed=9).to(DEV)})["embedding_instance"].detach().contiguous()
-        blob, aux = sc.models["coarse"].packed(split_bf16=b3)
+        blob, aux = sc.models["coarse"].packed()
         outs = []
         for hoist in (False, True):
             buf = {k: torch.empty(n, S, *sh, device=DEV) for k, sh in dict(sigma=(), rgb=(3,), isig=(), irgb=(3,)).items()}
             a = _lib.MlpArgs()
-            a.use_voxel, a.do_scene, a.do_object, a.mfma_bf16x3 = int(use_voxel), 1, 1, int(b3)
+            a.use_voxel, a.do_scene, a.do_object = int(use_voxel), 1, 1
             a.blob, a.aux = blob.data_ptr(), aux.data_ptr()
             a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), z.data_ptr(), n, S
             a.codes, a.code_stride = codes.data_ptr(), 64

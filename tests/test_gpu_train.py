@@ -9,7 +9,6 @@ import torch
 
 import cases
 import helpers as H
-from helpers import mfma_mode  # noqa: F401  (autouse: every test below runs in both arithmetic modes)
 import object_nerf_amd as A
 from object_nerf_amd import _lib, synth
 from oracle import objnerf_oracle as O
@@ -23,7 +22,6 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.single_mode
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 0), (0, 1)])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 271), (1000, 3, 128), (1, 256, 5000), (257, 129, 33), (64, 527, 70000)])
 def test_gemm_matches_torch(akc, bkc, M, N, K):
@@ -79,9 +77,6 @@ def test_render_rays_gradients_match_oracle_autograd(case):
         "voxel_random": dict(scene="voxel", kw=dict(is_eval=False, frustum_bound_th=0.025, perturb=1.0, noise_std=1.0), rnd=True),
     }
     c = cfgs[case]
-    if c.get("sizes", (0, 0, 0))[2] > 24 and os.environ.get("OBJNERF_MFMA", "f32") != "f32":
-        pytest.skip("three 393k-point autograd passes of the CPU oracle: run once (the fused kernels' split-bf16 mode is "
-                    "covered by the other cases and test_gradients_in_split_bf16_mode)")
     S, I, n = c.get("sizes", (16, 16, 24))
     sc = cases.scene_for(A, c["scene"], device=DEV)
     use_voxel = cases.SCENES[c["scene"]][0]
@@ -263,7 +258,6 @@ def _stage_inputs(sc, use_voxel, n, S, seed=3):
                 code_pts=codes.repeat_interleave(S, 0), grid=grid)
 
 
-@pytest.mark.single_mode
 @pytest.mark.parametrize("sname,fi", [("voxel", True), ("plain", True), ("voxel", False)])
 def test_training_kernels_against_layerwise_gemms(sname, fi):
     """C ABI level, 1500 rays x 128 depths = 1500 tiles of 128 points on 256 workgroups (every workgroup loops over
@@ -357,7 +351,6 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
     print(sname, fi, "fused dgrad chain vs GEMM chain: worst rel L2 %.2e" % worst)
 
 
-@pytest.mark.single_mode
 @pytest.mark.parametrize("S", [128, 192])
 def test_composite_backward_opaque_surface(S):
     """objnerf_composite_backward at fine-pass sample counts with an OPAQUE slab in the middle of every ray (alpha rounds
@@ -401,7 +394,6 @@ def test_composite_backward_opaque_surface(S):
         assert err < 2e-5, "%s: %.3e" % (name, err)
 
 
-@pytest.mark.single_mode
 def test_parameter_gradients_are_reproducible_run_to_run():
     """The weight / bias gradients of all 20 layers come from ONE grouped launch whose partial tiles are added in a fixed
     order (csrc/wgrad.h: stream-K with ordered slots; round 2 accumulated split-K tiles with fp32 atomics): two backward

@@ -65,7 +65,7 @@ if have("trace_bench_kernel_stats.md") and have("bench.json"):
                                                                       bytes_ / 1e6, rate / 1e9, rate / 8e12, note))
     roof = b["roofline"]
     open(os.path.join(P, TAG + "_kernel_stats.md"), "w").write(
-        "# %s -- rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --warmup 1 --cpu-rays 0 --split-bf16-steps 0 --pmc off "
+        "# %s -- rocprofv3 --kernel-trace --stats of `python bench.py --steps 3 --warmup 1 --cpu-rays 0 --pmc off "
         "--train-steps 0` (1x MI355X, `tools/gpu_session.sh %s trace`)\n\n"
         "bench.py line of the same session (`profiles/%s_bench.json`): %.2f M ray-samples/s, %.1f ms per step; HIP-event average of an MLP launch "
         "in the JSON's roofline block %.2f ms (%.3f of the fp32-MFMA peak on ALGORITHMIC FLOP); rocprof average of the same kernel below: %.2f ms -> "

@@ -9,7 +9,7 @@ for t in "$@"; do
   L=$R/object_nerf_amd/tune/libobjnerf_$t.so; [ $t = ship ] && L=$R/object_nerf_amd/libobjnerf_hip.so
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/f_$t
-    OBJNERF_LIB=$L rocprofv3 --pmc $c --output-format csv -d /tmp/f_$t -o pmc -- python $R/bench.py --steps 1 --warmup 0 --cpu-rays 0 --split-bf16-steps 0 > /dev/null 2>&1
+    OBJNERF_LIB=$L rocprofv3 --pmc $c --output-format csv -d /tmp/f_$t -o pmc -- python $R/bench.py --steps 1 --warmup 0 --cpu-rays 0 > /dev/null 2>&1
     python - "$t" "$c" <<'PY'
 import csv, glob, sys
 t, c = sys.argv[1], sys.argv[2]

@@ -44,7 +44,7 @@ for step in "$@"; do
     trace) case "$arg" in
              train) TRAIN_BENCH_FREE_STEPS=16 trace train python $R/tools/train_bench.py ;;
              mesh)  trace mesh python $R/tools/mesh_query_bench.py 256 ;;
-             *)     trace bench python $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --split-bf16-steps 0 --pmc off --train-steps 0 ;;
+             *)     trace bench python $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --pmc off --train-steps 0 ;;
            esac ;;
     pmc)   timeout 900 bash tools/pmc_run.sh $O > $O/pmc.log 2>&1; echo "pmc rc=$?"; tail -5 $O/pmc.log ;;
     *) echo "unknown step $step" ;;

@@ -83,8 +83,7 @@ def multi_section():
              # round 4: training mode with the injected draws of cases.multi_randoms()
              ("multi_train_random", "voxel", lambda: cases.multi_inputs(), m["obj_ids"], dict(N_importance=64, perturb=1.0, noise_std=1.0), True)]
     scenes = {}
-    for mode in ("f32", "bf16x3"):
-        os.environ["OBJNERF_MFMA"] = mode
+    for mode in ("f32",):
         for gname, sname, inputs, ids, kw, use_boxes in specs + [("multi_bench_edit_demo", "scannet_800k", None, cases.BENCH_MULTI["obj_ids"], dict(N_importance=64), True)]:
             if sname not in scenes:
                 scenes[sname] = cases.scene_for(A, sname, device=DEV)
@@ -126,9 +125,8 @@ def main(out_path):
              "(real reference, fp32, CPU). 48 rays per case. `err`/`floor` max-norm, `_l2` relative L2, `tf` = teacher-forced "
              "(fine pass on the reference's depths), see the tool's docstring.", ""]
     summary = []
-    for mode in ("f32", "bf16x3"):
-        os.environ["OBJNERF_MFMA"] = mode
-        lines += ["## OBJNERF_MFMA=%s" % mode, ""]
+    for mode in ("f32",):
+        lines += ["## arithmetic: %s" % mode, ""]
         for case in sorted(cases.RENDER_CASES):
             c = cases.RENDER_CASES[case]
             if c["scene"] not in scenes:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Quick PMC look at the MLP kernel of one bench frame (clock, matrix-pipe busy, wait split).  Honors OBJNERF_MFMA / OBJNERF_LIB.
+# Quick PMC look at the MLP kernel of one bench frame (clock, matrix-pipe busy, wait split).  Honors OBJNERF_LIB.
 # Usage (GPU box): bash tools/pmc_quick.sh
 R=${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp
@@ -9,7 +9,7 @@ i=0
 for grp in "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d /tmp/pq/pass$i -o pmc -- python $R/bench.py --steps 1 --warmup 0 --cpu-rays 0 --split-bf16-steps 0 > /tmp/pq/log$i 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d /tmp/pq/pass$i -o pmc -- python $R/bench.py --steps 1 --warmup 0 --cpu-rays 0 > /tmp/pq/log$i 2>&1
 done
 python - <<'PY'
 import csv, glob

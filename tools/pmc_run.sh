@@ -16,7 +16,7 @@ for grp in "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -o pmc -- \
-      python $R/bench.py --steps 1 --warmup 1 --cpu-rays 0 --split-bf16-steps 0 --train-steps 0 --pmc off > "$OUT/pass$i.log" 2>&1
+      python $R/bench.py --steps 1 --warmup 1 --cpu-rays 0 --train-steps 0 --pmc off > "$OUT/pass$i.log" 2>&1
   echo "pass $i ($grp): rc=$?"
 done
 cd $R

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout 600 python $R/bench.py --steps 3 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python $R/bench.py --steps 2 --warmup 1 --cpu-rays 0 --split-bf16-steps 0 > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python $R/bench.py --steps 2 --warmup 1 --cpu-rays 0 > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
 cd $R
 bash tools/pmc_run.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1; echo "pmc rc=$?"
 tail -c 600 "$OUT/bench.json"

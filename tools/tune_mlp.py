@@ -36,10 +36,9 @@ def main(tags, n_rays=76800, S=128, rounds=5):
     out = [torch.empty(n_rays, S, device=dev), torch.empty(n_rays, S, 3, device=dev),
            torch.empty(n_rays, S, device=dev), torch.empty(n_rays, S, 3, device=dev)]
     grid = sc.embeddings["xyz"].grid_struct()
-    libs, packs, b3 = {}, {}, {}
+    libs, packs = {}, {}
     for t in tags:
-        b3[t] = t.endswith("+b3")             # "<tag>+b3": the split-bf16 arithmetic mode of that library
-        l = load(t[:-3] if b3[t] else t)
+        l = load(t)
         nb, na = l.objnerf_blob_floats(1), l.objnerf_aux_floats()
         bi, ai = torch.empty(nb, dtype=torch.int32), torch.empty(na, dtype=torch.int32)
         assert l.objnerf_pack_index(1, C.c_void_p(bi.data_ptr()), C.c_void_p(ai.data_ptr())) == 0
@@ -47,17 +46,11 @@ def main(tags, n_rays=76800, S=128, rounds=5):
         blob, aux = torch.empty(nb, device=dev), torch.empty(na, device=dev)
         table = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
         assert l.objnerf_pack_weights(1, _lib.ptr(bi), _lib.ptr(ai), table, _lib.ptr(blob), _lib.ptr(aux), _lib.stream_ptr()) == 0
-        if b3[t]:
-            bi3 = torch.empty(nb, dtype=torch.int32)
-            assert l.objnerf_pack_index_b3(1, C.c_void_p(bi3.data_ptr())) == 0
-            bi3 = bi3.to(dev)
-            blob = torch.empty(l.objnerf_b3_blob_bytes(1) // 4, device=dev)
-            assert l.objnerf_pack_weights_b3(1, _lib.ptr(bi3), table, _lib.ptr(blob), _lib.stream_ptr()) == 0
         libs[t], packs[t] = l, (blob, aux)
 
     def args_for(t):
         a = _lib.MlpArgs()
-        a.use_voxel, a.do_scene, a.do_object, a.mfma_bf16x3 = 1, 1, 1, int(b3[t])
+        a.use_voxel, a.do_scene, a.do_object = 1, 1, 1
         a.blob, a.aux = packs[t][0].data_ptr(), packs[t][1].data_ptr()
         a.rays, a.z_vals, a.n_rays, a.S = rays.data_ptr(), z.data_ptr(), n_rays, S
         a.codes, a.code_stride, a.grid = codes.data_ptr(), 0, grid
