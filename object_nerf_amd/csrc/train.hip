@@ -308,7 +308,8 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   // ---- phase B: weight / bias gradients dW = dY^T X.  All products of the pass go into ONE work list and one persistent,
   // deterministic stream-K launch (wgrad.h); OBJNERF_WGRAD=atomic keeps round 2's one split-K launch with atomic
   // accumulation per product (developer A/B switch) ----
-  static const bool atomic_wgrad = [] { const char* e = getenv("OBJNERF_WGRAD"); return e && !strcmp(e, "atomic"); }();
+  // (read on every call, not cached: tests/test_gpu_train.py switches it inside one process to cross-check the two paths)
+  const bool atomic_wgrad = [] { const char* e = getenv("OBJNERF_WGRAD"); return e && !strcmp(e, "atomic"); }();
   WgradBatch batch;
   auto wgrad = [&](const float* dY, long lddy, const float* Xo, long ldx, long /*P*/, int out, int in, float* dW, long ldw, float* db = nullptr) {
     if (atomic_wgrad) { lin_wgrad(c, dY, lddy, Xo, ldx, P, out, in, dW, ldw, db); return; }

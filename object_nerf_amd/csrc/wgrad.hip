@@ -91,6 +91,13 @@ __device__ __forceinline__ void wgrad_tail_piece(const WgProduct& pr, const WgTi
 #ifndef OBJ_ABL
 #define OBJ_ABL 0
 #endif
+// 16-byte load at (uniform base) + (per-lane 32-bit byte offset) inside the branch-free k loops.  The empty asm only keeps the
+// zero-extension of the offset from being hoisted out of the loop as a 64-bit register pair (the address would then need a
+// 64-bit VALU add per load); it emits no instruction and hides nothing from the wait-count pass.
+__device__ __forceinline__ f32x4 steady_load(const char* base, unsigned& off) {
+  asm volatile("" : "+v"(off));
+  return gload4u((const float*)(base + off));
+}
 constexpr int WTILE = GBK * GLDR;                // floats per staged operand tile (16 KB), [k][128] with permuted columns
 #ifndef OBJ_WG_WAVES
 #define OBJ_WG_WAVES 2
@@ -212,15 +219,16 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
       // at the head of the k tile, the workgroups' 32 KiB each queue at the CU's 64 B/clk vector-memory path and the issuing
       // waves stall behind it: +17 % kernel time even with every load hitting in cache (profiles/r03_wgrad_ablations.md)
       if constexpr (STEADY) {
-        // the loads are opaque to the compiler (its wait-count pass would make the first copy of a k tile wait for ALL eight
-        // loads in flight, vmcnt(0), the youngest of them one MFMA group old); loads return in order, so with eight in flight
-        // "at most six outstanding" = the two issued for this piece one k tile ago have landed
-        if (!(OBJ_ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // Compiler-visible loads (round 5; rounds 3-4 issued them from inline asm into "=v" outputs and waited with a hand-counted
+        // s_waitcnt one k tile later -- a copy inserted between issue and wait would have read stale registers).  The compiler's
+        // own wait-count pass finds the exact count in this branch-free body: eight loads in flight, in-order return, so the copy
+        // of piece s4 waits with vmcnt(6) for the two loads issued for it one k tile ago (checked in the ISA).  steady_load keeps
+        // the scalar-base addressing form (global_load_dwordx4 v, v_off, s[base:base+1]): no per-load VALU address arithmetic.
         opa.put_piece(s4, An, tid);
         opb.put_piece(s4, Bn, tid);
         if (!(OBJ_ABL & 1)) {
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opa.v[s4]) : "v"(opa.off[s4]), "s"(opa.base) : "memory");
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opb.v[s4]) : "v"(opb.off[s4]), "s"(opb.base) : "memory");
+          opa.v[s4] = steady_load(opa.base, opa.off[s4]);
+          opb.v[s4] = steady_load(opb.base, opb.off[s4]);
         }
       } else if (krem > GBK) {           // uniform
         opa.put_piece(s4, An, tid);
@@ -263,7 +271,6 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
   if ((opa.fast || opa.over) && (opb.fast || opb.over) && krem >= steady_min) {       // uniform
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the second tile is in registers (and the compiler knows it)
     for (; krem >= steady_min; krem -= GBK) k_tile(std::true_type{}, krem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   for (; krem > 0; krem -= GBK) k_tile(std::false_type{}, krem);
   __syncthreads();                       // the row-sum exchange below reuses the LDS buffers
@@ -388,13 +395,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     for (int q = 0; q < 16; ++q) {       // MFMA step q = 4 s4 + s of lane half h contracts k = 16 h + q
       // staging piece q (A pieces 0..7 on the even steps, B pieces on the odd ones)
       if constexpr (STEADY) {
-        asm volatile("s_waitcnt vmcnt(15)" ::: "memory");      // sixteen loads in flight, in-order return: this piece's has landed
+        // sixteen loads in flight, in-order return: the compiler waits with vmcnt(15) for this piece's (see wgrad_full_piece)
         if ((q & 1) == 0) {
           opa.put_piece(q >> 1, An, tid);
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opa.v[q >> 1]) : "v"(opa.off[q >> 1]), "s"(opa.base) : "memory");
+          opa.v[q >> 1] = steady_load(opa.base, opa.off[q >> 1]);
         } else {
           opb.put_piece(q >> 1, Bn, tid);
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opb.v[q >> 1]) : "v"(opb.off[q >> 1]), "s"(opb.base) : "memory");
+          opb.v[q >> 1] = steady_load(opb.base, opb.off[q >> 1]);
         }
       } else if (krem > GBK) {           // uniform
         if ((q & 1) == 0) {
@@ -427,7 +434,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   if (krem >= 3 * GBK) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the second tile is in registers (and the compiler knows it)
     for (; krem >= 3 * GBK; krem -= GBK) k_tile(std::true_type{}, krem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   for (; krem > 0; krem -= GBK) k_tile(std::false_type{}, krem);
 

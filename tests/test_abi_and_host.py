@@ -288,3 +288,27 @@ def test_weight_stream_cache_key_sees_fused_optimizer_steps():
         assert m._pack_key(params) != k0
         if fused and params[0]._version == v0:
             assert m._pack_key(params)[:-1] == k0[:-1]      # ... and only the step hook saw it
+
+
+def test_optimizer_steps_invalidate_only_the_models_they_own():
+    """the step hook is scoped (round 5): an optimizer that holds none of a module's parameters leaves that module's cache key
+    alone -- also when the module was deep-copied / unpickled (no __init__) and when parameters join the optimizer later"""
+    import copy
+    a, b = A.ObjectNeRF(A.default_model_config()), A.ObjectNeRF(A.default_model_config())
+    c = copy.deepcopy(a)
+    other = torch.nn.Linear(4, 4)
+    pa, pb, pc = a._param_list(), b._param_list(), c._param_list()
+    ka, kb, kc = a._pack_key(pa), b._pack_key(pb), c._pack_key(pc)
+    opt_other = torch.optim.SGD(other.parameters(), lr=0.1)
+    other.weight.grad = torch.ones_like(other.weight); other.bias.grad = torch.ones_like(other.bias)
+    opt_other.step()
+    assert a._pack_key(pa) == ka and b._pack_key(pb) == kb and c._pack_key(pc) == kc
+    opt_a = torch.optim.SGD([a.sigma.weight], lr=0.0)          # one parameter of `a` is enough
+    a.sigma.weight.grad = torch.zeros_like(a.sigma.weight)
+    opt_a.step()
+    assert a._pack_key(pa) != ka and b._pack_key(pb) == kb and c._pack_key(pc) == kc
+    opt_a.add_param_group({"params": [c.sigma.bias]})         # joins later: the cached id set is rebuilt
+    c.sigma.bias.grad = torch.zeros_like(c.sigma.bias)
+    kc0 = c._pack_key(pc)
+    opt_a.step()
+    assert c._pack_key(pc) != kc0 and b._pack_key(pb) == kb
