@@ -659,10 +659,39 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
         dt = allreduce(time.perf_counter() - t0, "MAX") / args.train_steps
         host /= args.train_steps
         l1 = loss.item()
+        # per-phase budget: the same loop once more with the library's HIP-event marks at the phase boundaries of the training
+        # calls (objnerf_train_timing_*; forward = the two fused MLP forwards of a step, dgrad = the two chains, ...); "other" is
+        # what the step spends outside those spans: sampling, compositing forward / backward, embeddings, per-ray sums, the loss's
+        # element-wise kernels, zero fills, weight re-packing, gradient exchange and the optimizer
+        phases = None
+        try:
+            from object_nerf_amd import _lib
+            lib = _lib.lib()
+            n_ph = 8
+            fence()
+            lib.objnerf_train_timing_enable(1)
+            tp = time.perf_counter()
+            for _ in range(n_ph):
+                step()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - tp) / n_ph * 1e3
+            ms = (C.c_double * 5)()
+            cnt = (C.c_int64 * 5)()
+            lib.objnerf_train_timing_read(ms, cnt)
+            lib.objnerf_train_timing_enable(0)
+            names = ("forward", "dgrad", "dx", "scatter", "wgrad")
+            phases = {k: ms[i] / n_ph for i, k in enumerate(names)}
+            phases["other"] = wall - sum(phases.values())
+            phases = {"ms": phases, "steps": n_ph, "step_ms_with_marks": wall,
+                      "spans_per_step": {k: cnt[i] / n_ph for i, k in enumerate(names)},
+                      "note": "HIP events on the launch stream at the phase boundaries inside objnerf_mlp_train_forward / _backward, "
+                              "both passes (coarse + fine) of a step summed; other = step - sum"}
+        except Exception as e:
+            phases = {"error": "%s: %s" % (type(e).__name__, e)}
         evals = float(n_rays) * 192 * world
         tflops = evals * FLOP_BOTH * 3.0 / dt / 1e12
         return {"ms_per_step": 1e3 * dt, "steps": args.train_steps, "rays_per_rank": n_rays, "n_gpus": world,
-                "host_enqueue_ms_per_step": 1e3 * host,
+                "host_enqueue_ms_per_step": 1e3 * host, "phases_ms": phases,
                 "value": evals / dt, "unit": "ray-samples/s (forward + backward + Adam)",
                 "workload": "train.py:147-180 batch: %d rays x (64 coarse + 64 fine), perturb 1, noise_std 1, scene + object "
                             "branches, occlusion mask, voxel embedding, ScanNet-like scene, Adam on both MLPs + codes + voxel table"

@@ -591,6 +591,14 @@ int objnerf_repeat_rows(const float* src, int64_t lds, int64_t n_rows, int C, in
  * synchronises those events and returns {launch count, total ms} since the last reset. */
 int objnerf_timing_enable(int on);
 int objnerf_timing_read(int64_t* launches, double* total_ms);
+/* The same for the training calls: when enabled, objnerf_mlp_train_forward / _backward bracket their phases with hipEvents
+ * on `stream`; objnerf_train_timing_read synchronises them and returns, per phase, the summed milliseconds and the number
+ * of spans since the last reset (both arrays OBJNERF_TRAIN_PHASES long).  Phases: 0 forward (fused MLP forward that keeps the
+ * activations), 1 dgrad (the chain through the hidden layers), 2 dX (gradients w.r.t. the embeddings), 3 voxel-table scatter,
+ * 4 weight gradients. */
+#define OBJNERF_TRAIN_PHASES 5
+int objnerf_train_timing_enable(int on);
+int objnerf_train_timing_read(double* ms_by_phase, int64_t* spans_by_phase);
 
 #ifdef __cplusplus
 }

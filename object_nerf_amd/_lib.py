@@ -241,6 +241,8 @@ SIGNATURES = {
     "objnerf_repeat_rows": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, _VP, C.c_int64, _VP]),
     "objnerf_timing_enable": (C.c_int, [C.c_int]),
     "objnerf_timing_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "objnerf_train_timing_enable": (C.c_int, [C.c_int]),
+    "objnerf_train_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

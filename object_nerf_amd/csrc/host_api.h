@@ -11,12 +11,17 @@ int check_launch(const char* what);
 
 // MLP kernel launchers, one translation unit per input form (compile time)
 // save_ws != nullptr: training forward, every layer's activations are also written to the train.hip workspace
-int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
+// mask_ws: (training forward only) where the LeakyReLU sign masks of the saved activations go (mlp_kernel.h), or nullptr
+int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr,
+                     unsigned* mask_ws = nullptr);
 int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);                // ray_bias
-int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr);
+int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr,
+                      unsigned* mask_ws = nullptr);
 // training: fused dgrad chain through the hidden layers (mlp_bwd.hip); act / dz in the workspace layout of train.hip
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,
-                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, hipStream_t s);
+                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, const unsigned* masks, hipStream_t s);
+// floats of the mask area behind the activation matrices of a training workspace (mlp_kernel.h: train_mask_floats)
+long train_mask_floats_host(long n_points);
 // persistent grid of the MLP kernel: one workgroup per CU
 unsigned mlp_grid(long ntiles);
 }  // namespace objnerf

@@ -3,6 +3,11 @@
 //
 //   d(pre-activation of layer l-1) = leaky'(A_{l-1}) . ( W_l[:, hidden block]^T  d(pre-activation of layer l) )
 //
+// MASKS = true (round 5): leaky' comes from the sign masks the training forward packed in this very register layout
+// (mlp_kernel.h "LeakyReLU masks": one 16-byte load per lane and layer) instead of from the re-read activation matrices
+// (MASKS = false: 1.1 GB per launch through the wave's LDS patch; kept for a forward that ran layer by layer on the GEMMs
+// and left no masks).  Same bits either way: identical gradients.
+//
 // Same machine as the forward (mlp_kernel.h): 256 workgroups x 4 waves, a wave owns 32 sample points, the transposed
 // weight blocks stream through the 2-slot LDS ring (layout.h: "backward weight stream"), and the D tile of one layer
 // -- the gradient, features x points in registers -- is the B operand of the next, so the chain never leaves the
@@ -25,15 +30,18 @@ struct BwdArgs {
   const float* t2;      // (P,3) gradient w.r.t. the rgb head's pre-sigmoid output
   const float* d_isigma;
   const float* t2i;
+  const unsigned* masks; // MASKS: the forward's sign masks (mlp_kernel.h layout)
 };
+#ifndef OBJ_BWD_SPREAD_SAVE
+#define OBJ_BWD_SPREAD_SAVE 1   // MASKS: a layer's input-gradient tiles are stored one per MFMA group (the registers the raw
+                                // activation tiles needed are free) instead of as one burst behind the layer's first barrier
+#endif
 
 // Saved activations come back the way save_tiles wrote them: 8 consecutive lanes read one 128-byte line of a point.
 // Only their signs are needed (LeakyReLU mask), and registers are tight (gradient in + gradient out = 256 of 512),
 // so a layer fetches them four tiles at a time behind one chunk barrier and, behind the next one, turns them into
 // the D layout through the wave's LDS patch and keeps one bit per value.
 struct RawTiles { f32x4 v[4][4]; };          // 4 tiles x 4 row groups, as fetched (lane = (row q, piece k))
-template <int NT>
-struct MaskBits { unsigned w[NT / 2]; };     // tile t -> bits 16 (t & 1) .. + 15 of w[t / 2]
 template <int N>
 __device__ __forceinline__ void fetch_tiles(RawTiles& raw, const float* mat, long ld, int t0, const Stage& sg) {
   const int q = sg.lane >> 3, k = sg.lane & 7;
@@ -112,21 +120,29 @@ __device__ __forceinline__ void mask_tiles(const f32x16 (&acc)[NT], const MaskBi
 }
 // after-barrier hook of one backward layer: chunk 0 stores the layer's input gradient (the previous layer's result)
 // and fetches the first four activation tiles of the mask of ITS result; chunks 1, 2 reduce them to bits / fetch the rest
-template <int NTIN, int NTOUT>
+template <int NTIN, int NTOUT, bool MASKS>
 struct BwdHook {
   const f32x16 (&hin)[NTIN];
   float* save_mat; long save_ld;
-  const float* act_mat; long act_ld;        // nullptr: the layer's result is not masked
+  const float* act_mat; long act_ld;        // MASKS = false: the saved output whose signs mask the layer's result (nullptr: not masked)
+  const unsigned* mrow;                     // MASKS = true: this lane's 16 bytes of that mask (nullptr: not masked)
   RawTiles& raw;
   MaskBits<NTOUT>& bits;
   const Stage& sg;
-  // (per-group spreading of the stores, as the forward's SaveHook does, overflows this kernel's register budget:
-  // gradient in + gradient out + raw activation tiles leave no room for the store temporaries mid-layer)
+  // MASKS = false: per-group spreading of the stores, as the forward's SaveHook does, overflows the register budget (gradient
+  // in + gradient out + raw activation tiles leave no room for the store temporaries mid-layer)
   template <int GI>
-  __device__ __forceinline__ void group() const {}
+  __device__ __forceinline__ void group() const {
+    if constexpr (MASKS && OBJ_BWD_SPREAD_SAVE && GI < NTIN) save_tile<NTIN>(hin, GI, save_mat, save_ld, sg);
+  }
   template <int C>
   __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {
-    if constexpr (C == 0) {
+    if constexpr (MASKS) {
+      if constexpr (C == 0) {
+        if constexpr (!OBJ_BWD_SPREAD_SAVE) save_tiles<NTIN>(hin, save_mat, save_ld, sg);
+        if (mrow) load_masks<NTOUT>(bits, mrow);
+      }
+    } else if constexpr (C == 0) {
       save_tiles<NTIN>(hin, save_mat, save_ld, sg);
       if (act_mat) fetch_tiles<4>(raw, act_mat, act_ld, 0, sg);
     } else if constexpr (C == 1) {
@@ -157,7 +173,7 @@ __device__ __forceinline__ void add_head(f32x16 (&acc)[NT], const float* w, int 
   }
 }
 
-template <bool DO_OBJ>
+template <bool DO_OBJ, bool MASKS>
 __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const long ntiles) {
   constexpr int kCB = kChunkBytes;
   __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kCB + kAuxFloats * 4 + kStageBytes];
@@ -186,6 +202,10 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
     // after-barrier hooks of the layer that consumes the former (layer_mac): they then have a chunk of MFMAs to land
     // instead of being drained by the very next barrier.
     RawTiles raw;
+    // this lane's 16 bytes of mask group grp of the wave's 32 points
+    auto mrow_of = [&](int grp) __attribute__((always_inline)) {
+      return MASKS ? a.masks + (sg_scene.p0 >> 5) * kMaskDwordsPerWave + ((long)grp * 64 + lane) * 4 : nullptr;
+    };
     // ---------------- scene branch ----------------
     {
       const Stage& sg = sg_scene;
@@ -195,23 +215,24 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
         // d(dir hidden) = t2 (P,3) * W_rgb (3,128), masked by the dir layer's LeakyReLU
         f32x16 hd[4];
         MaskBits<4> bd;
-        fetch_tiles<4>(raw, act.sdirh(), 128, 0, sg);
+        if constexpr (MASKS) load_masks<4>(bd, mrow_of(kMaskGrpSD));
+        else fetch_tiles<4>(raw, act.sdirh(), 128, 0, sg);
         zero_tiles<4>(hd);
 #pragma unroll
         for (int c = 0; c < 3; ++c) add_head<4>(hd, aux + kAuxSRgb + c * 4 * 32, half, a.t2[p * 3 + c]);
-        sign_bits<4, 4, 0>(raw, bd, sg);
+        if constexpr (!MASKS) sign_bits<4, 4, 0>(raw, bd, sg);
         mask_tiles<4>(hd, bd, hd);
         // BL_SD: -> d(xyz_encoding_final output), no activation there
         {
           HidSrc<4> s{hd};
-          layer_mac<8, bwd_ks(BL_SD), HidSrc<4>, BwdHook<4, 8>, true>(acc, st, s, {hd, dz.sdirh(), 128, nullptr, 0, raw, bits, sg});
+          layer_mac<8, bwd_ks(BL_SD), HidSrc<4>, BwdHook<4, 8, MASKS>, true>(acc, st, s, {hd, dz.sdirh(), 128, nullptr, 0, nullptr, raw, bits, sg});
         }
       }
       finish<8, false>(acc, h);
       // BL_SF: -> dA8, plus the density head's contribution, then layer 8's mask
       {
         HidSrc<8> s{h};
-        layer_mac<8, 128, HidSrc<8>, BwdHook<8, 8>, true>(acc, st, s, {h, dz.sfinal(), 256, act.A(8), 256, raw, bits, sg});
+        layer_mac<8, 128, HidSrc<8>, BwdHook<8, 8, MASKS>, true>(acc, st, s, {h, dz.sfinal(), 256, act.A(8), 256, mrow_of(kMaskGrpA + 7), raw, bits, sg});
       }
       add_head<8>(acc, aux + kAuxSSig, half, a.d_sigma[p]);
       mask_tiles<8>(acc, bits, h);
@@ -220,7 +241,7 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
       for (int l = 8; l >= 2; --l) {
         {
           HidSrc<8> s{h};
-          layer_mac<8, 128, HidSrc<8>, BwdHook<8, 8>, true>(acc, st, s, {h, dz.A(l), 256, act.A(l - 1), 256, raw, bits, sg});
+          layer_mac<8, 128, HidSrc<8>, BwdHook<8, 8, MASKS>, true>(acc, st, s, {h, dz.A(l), 256, act.A(l - 1), 256, mrow_of(kMaskGrpA + l - 2), raw, bits, sg});
         }
         mask_tiles<8>(acc, bits, h);
       }
@@ -238,21 +259,22 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
       {
         f32x16 hd[2];
         MaskBits<2> bd;
-        fetch_tiles<2>(raw, act.odirh(), 64, 0, sg);
+        if constexpr (MASKS) load_masks<2>(bd, mrow_of(kMaskGrpOD));
+        else fetch_tiles<2>(raw, act.odirh(), 64, 0, sg);
         zero_tiles<2>(hd);
 #pragma unroll
         for (int c = 0; c < 3; ++c) add_head<2>(hd, aux + kAuxORgb + c * 2 * 32, half, a.t2i[p * 3 + c]);
-        sign_bits<2, 2, 0>(raw, bd, sg);
+        if constexpr (!MASKS) sign_bits<2, 2, 0>(raw, bd, sg);
         mask_tiles<2>(hd, bd, hd);
         {
           HidSrc<2> s{hd};
-          layer_mac<4, bwd_ks(BL_OD), HidSrc<2>, BwdHook<2, 4>, true>(acc, st, s, {hd, dz.odirh(), 64, nullptr, 0, raw, bits, sg});
+          layer_mac<4, bwd_ks(BL_OD), HidSrc<2>, BwdHook<2, 4, MASKS>, true>(acc, st, s, {hd, dz.odirh(), 64, nullptr, 0, nullptr, raw, bits, sg});
         }
       }
       finish<4, false>(acc, h);
       {
         HidSrc<4> s{h};
-        layer_mac<4, 64, HidSrc<4>, BwdHook<4, 4>, true>(acc, st, s, {h, dz.ofinal(), 128, act.B(4), 128, raw, bits, sg});
+        layer_mac<4, 64, HidSrc<4>, BwdHook<4, 4, MASKS>, true>(acc, st, s, {h, dz.ofinal(), 128, act.B(4), 128, mrow_of(kMaskGrpB + 3), raw, bits, sg});
       }
       add_head<4>(acc, aux + kAuxOSig, half, a.d_isigma[p]);
       mask_tiles<4>(acc, bits, h);
@@ -260,7 +282,7 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
       for (int l = 4; l >= 2; --l) {
         {
           HidSrc<4> s{h};
-          layer_mac<4, 64, HidSrc<4>, BwdHook<4, 4>, true>(acc, st, s, {h, dz.B(l), 128, act.B(l - 1), 128, raw, bits, sg});
+          layer_mac<4, 64, HidSrc<4>, BwdHook<4, 4, MASKS>, true>(acc, st, s, {h, dz.B(l), 128, act.B(l - 1), 128, mrow_of(kMaskGrpB + l - 2), raw, bits, sg});
         }
         mask_tiles<4>(acc, bits, h);
       }
@@ -269,14 +291,21 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
   }
 }
 
+long train_mask_floats_host(long n_points) { return train_mask_floats(n_points); }
+
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,
-                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, hipStream_t s) {
+                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, const unsigned* masks, hipStream_t s) {
   static_assert(bwd_scene_chunks() == 68 || kChunkTiles != 128, "backward stream layout");
-  const BwdArgs a{blob_bwd, aux, P, act, dz, d_sigma, t2, d_isigma, t2i};
+  const BwdArgs a{blob_bwd, aux, P, act, dz, d_sigma, t2, d_isigma, t2i, masks};
   const long ntiles = (P + 127) / 128;
   const unsigned grid = mlp_grid(ntiles);
-  if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, a, ntiles);
-  else hipLaunchKernelGGL((mlp_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  if (masks) {
+    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  } else {
+    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  }
   return check_launch("mlp_train_backward(fused)");
 }
 

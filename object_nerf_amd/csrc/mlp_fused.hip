@@ -7,22 +7,22 @@ namespace objnerf {
 
 template <bool VOXEL, bool SC, bool OB>
 static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr, nullptr);
 }
 #ifndef OBJ_TUNE_ONLY_MAIN
 // density query on points / a lattice (objnerf_mlp_args.points, lat_*): one branch, stops after the sigma head
 template <bool VOXEL, bool SC>
 static void launch_query(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, !SC, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, !SC, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr, nullptr);
 }
 // training forward: scene (+ object) branch, every layer's activations also written to save_ws
 template <bool VOXEL, bool OB>
-static void launch_save(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws) {
-  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, true, OB, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, save_ws);
+static void launch_save(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws, unsigned* mask_ws) {
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, true, OB, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, save_ws, mask_ws);
 }
 #endif
 
-int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws) {
+int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws, unsigned* mask_ws) {
   if (a.ray_bias && !save_ws) return launch_mlp_fused_hoist(a, ntiles, grid, s);      // (incl. the hoisted object density query)
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
 #ifdef OBJ_TUNE_ONLY_MAIN
@@ -37,8 +37,8 @@ int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipS
   }
   if (save_ws) {
     if (!sc) return set_error(-1, "mlp_eval(fused, training): the scene branch is always evaluated");
-    if (a.use_voxel) { if (ob) launch_save<true, true>(a, ntiles, grid, s, save_ws); else launch_save<true, false>(a, ntiles, grid, s, save_ws); }
-    else { if (ob) launch_save<false, true>(a, ntiles, grid, s, save_ws); else launch_save<false, false>(a, ntiles, grid, s, save_ws); }
+    if (a.use_voxel) { if (ob) launch_save<true, true>(a, ntiles, grid, s, save_ws, mask_ws); else launch_save<true, false>(a, ntiles, grid, s, save_ws, mask_ws); }
+    else { if (ob) launch_save<false, true>(a, ntiles, grid, s, save_ws, mask_ws); else launch_save<false, false>(a, ntiles, grid, s, save_ws, mask_ws); }
     return check_launch("mlp_train_forward(fused)");
   }
 #endif

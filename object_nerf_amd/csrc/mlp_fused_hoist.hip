@@ -8,7 +8,7 @@ namespace objnerf {
 
 template <bool VOXEL, bool SC, bool OB>
 static void launch(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB, false, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+  hipLaunchKernelGGL((mlp_kernel<VOXEL, true, SC, OB, false, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr, nullptr);
 }
 
 int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s) {
@@ -16,8 +16,8 @@ int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid
 #ifndef OBJ_TUNE_ONLY_MAIN
   if (a.sigma_only) {        // object-branch density query on points / a lattice with the code's terms hoisted
     if (sc || !ob) return set_error(-1, "mlp_eval(points, sigma_only): ray_bias serves the object query only");
-    if (a.use_voxel) hipLaunchKernelGGL((mlp_kernel<true, true, false, true, true, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
-    else hipLaunchKernelGGL((mlp_kernel<false, true, false, true, true, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr);
+    if (a.use_voxel) hipLaunchKernelGGL((mlp_kernel<true, true, false, true, true, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr, nullptr);
+    else hipLaunchKernelGGL((mlp_kernel<false, true, false, true, true, false, true>), dim3(grid), dim3(256), 0, s, a, ntiles, nullptr, nullptr);
     return check_launch("mlp_eval(points, sigma_only, hoisted)");
   }
 #endif

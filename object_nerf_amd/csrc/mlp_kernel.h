@@ -844,6 +844,60 @@ struct PrefetchHook {
 };
 
 // ---------------------------------------------------------------------------------------------
+// LeakyReLU masks of the training forward (round 5).  The dgrad chain (mlp_bwd.hip) needs only the SIGN of every saved hidden
+// activation, in the D layout its gradient tiles have -- which is the layout the forward holds them in.  Rounds 3-4 re-read the
+// row-major activation matrices (1.1 GB per launch), turned them around through the wave's LDS patch and compared; now the
+// forward packs the signs of each lane's own registers (one v_cmp + one v_addc per value: the carry shifts the bit in) and
+// stores 16 bytes per lane and layer, and the chain loads them back with one 16-byte load per layer.
+// Word w[wd] of a layer: bit 16 (t & 1) + r = (h[t][r] > 0) for the tiles t = 2 wd, 2 wd + 1 -- the order mask_tiles consumes.
+// Memory: [wave tile = point / 32][group][lane][4 dwords], groups A1..A8 | dir hidden | B1..B4 | object dir hidden.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaskGroups = 14;
+constexpr int kMaskGrpA = 0, kMaskGrpSD = 8, kMaskGrpB = 9, kMaskGrpOD = 13;
+constexpr long kMaskDwordsPerWave = (long)kMaskGroups * 64 * 4;           // 14 KiB per 32 points = 448 B per point
+OBJ_HD constexpr long train_mask_floats(long n_points) { return ((n_points + 127) / 128) * 4 * kMaskDwordsPerWave; }
+template <int NT>
+struct MaskBits { unsigned w[NT / 2]; };     // tile t -> bits 16 (t & 1) .. + 15 of w[t / 2]
+// word WD of the mask of h: tiles 2 WD + 1 (first: it ends in the upper half) and 2 WD, registers 15 .. 0
+template <int NT, int WD>
+__device__ __forceinline__ void sign_word(const f32x16 (&h)[NT], MaskBits<NT>& b) {
+  unsigned m = 0;
+#pragma unroll
+  for (int tt = 1; tt >= 0; --tt)
+#pragma unroll
+    for (int r = 15; r >= 0; --r)
+      asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(h[2 * WD + tt][r]) : "vcc");
+  b.w[WD] = m;
+}
+template <int NT>
+__device__ __forceinline__ unsigned* mask_row(unsigned* mask_ws, long p0, int grp, int lane) {
+  return mask_ws + (p0 >> 5) * kMaskDwordsPerWave + ((long)grp * 64 + lane) * 4;
+}
+template <int NT>
+__device__ __forceinline__ void store_masks(const MaskBits<NT>& b, unsigned* row) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (NT == 8) __builtin_nontemporal_store(u32x4{b.w[0], b.w[1], b.w[2], b.w[3]}, (u32x4*)row);
+  else if constexpr (NT == 4) __builtin_nontemporal_store(u32x2{b.w[0], b.w[1]}, (u32x2*)row);
+  else __builtin_nontemporal_store(b.w[0], row);
+}
+template <int NT>
+__device__ __forceinline__ void load_masks(MaskBits<NT>& b, const unsigned* row) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (NT == 8) { const u32x4 v = __builtin_nontemporal_load((const u32x4*)row); b.w[0] = v[0]; b.w[1] = v[1]; b.w[2] = v[2]; b.w[3] = v[3]; }
+  else if constexpr (NT == 4) { const u32x2 v = __builtin_nontemporal_load((const u32x2*)row); b.w[0] = v[0]; b.w[1] = v[1]; }
+  else b.w[0] = __builtin_nontemporal_load(row);
+}
+// all words at once (the two direction layers, whose output is stored right behind their epilogue)
+template <int NT>
+__device__ __forceinline__ void sign_store_all(const f32x16 (&h)[NT], unsigned* row) {
+  MaskBits<NT> b;
+  static_for<NT / 2>([&](auto W) __attribute__((always_inline)) { sign_word<NT, decltype(W)::value>(h, b); });
+  store_masks<NT>(b, row);
+}
+
+// ---------------------------------------------------------------------------------------------
 // training forward (SAVE): every layer's output also goes to the row-major (P x width) activation matrices the
 // layer-wise backward reads (train.hip, struct Ws).  h[t][4g..4g+3] of lane half hf are features
 // 32 t + 8 g + 4 hf .. + 3 of one point.
@@ -900,12 +954,21 @@ struct SaveHook {      // layer_mac after-barrier hook: write h (the layer's inp
   float* mat;
   long ld;
   const Stage& sg;
+  unsigned* mrow;      // this lane's 16 bytes of h's LeakyReLU mask (nullptr: h is not the output of an activated layer)
+  MaskBits<NT>& mb;
   template <int C>
   __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {}
-  // one tile per MFMA group (a burst of all NT tiles' stores stalls the issuing wave like a burst of DMA pieces does)
+  // one tile per MFMA group (a burst of all NT tiles' stores stalls the issuing wave like a burst of DMA pieces does); the
+  // mask word of a tile pair behind the pair's second tile, the mask store behind the last one
   template <int GI>
   __device__ __forceinline__ void group() const {
-    if constexpr (ON && GI < NT) save_tile<NT>(h, GI, mat, ld, sg);
+    if constexpr (ON && GI < NT) {
+      save_tile<NT>(h, GI, mat, ld, sg);
+      if (mrow) {
+        if constexpr (GI & 1) sign_word<NT, GI / 2>(h, mb);
+        if constexpr (GI == NT - 1) store_masks<NT>(mb, mrow);
+      }
+    }
   }
 };
 // saved-activation matrices, floats per point: scene 8 x 256 | final 256 | dir hidden 128 | (4 unused) |
@@ -940,7 +1003,8 @@ __device__ __forceinline__ void out_store(float* p, float v) {
 // are skipped (340 of 13,876 MFMAs per 32 points, 2.45 %) and  bias + W[:, those columns] . x  arrives once per ray from
 // ray_bias_kernel (objnerf_ray_bias), added in the layer's epilogue.  Same sums in another association: fp32-roundoff class.
 template <bool VOXEL, bool FUSED, bool DO_SCENE, bool DO_OBJ, bool SIGMA_ONLY = false, bool SAVE = false, bool HOIST = false>
-__global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr) {
+__global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, const long ntiles_arg, float* const save_ws = nullptr,
+                                                     unsigned* const mask_ws = nullptr) {
   // (with SIGMA_ONLY: the object-branch density query, whose ONE code is constant over all points -- its share of
   // instance_encoding_1 / _3 arrives as a single vector at ray_bias, every point reads "ray" 0)
   static_assert(!HOIST || (FUSED && !SAVE && (!SIGMA_ONLY || (DO_OBJ && !DO_SCENE))), "hoisting: inference form of the fused kernel");
@@ -1110,23 +1174,27 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       finish<8, true>(acc, h);
       // SAVE: a layer's output is written by the NEXT layer's after-barrier hook (see layer_mac); h is that layer's
       // input and stays live anyway
-      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 8>{h, mat, 256, stg}; };
+      // (grp: the mask group of h, or -1 when h is not the output of an activated layer)
+      MaskBits<8> mb;
+      auto save_h = [&](float* mat, int grp) __attribute__((always_inline)) {
+        return SaveHook<SAVE, 8>{h, mat, 256, stg, (SAVE && mask_ws && grp >= 0) ? mask_row<8>(mask_ws, stg.p0, grp, lane) : nullptr, mb};
+      };
       // xyz_encoding_2..4
 #pragma unroll 1
       for (int l = L_S2; l <= L_S4; ++l) {
         load_bias<8>(acc, aux, l, half);
-        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(l - L_S1))); }
+        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(l - L_S1), kMaskGrpA + l - L_S1 - 1)); }
         finish<8, true>(acc, h);
       }
       // xyz_encoding_5 (skip: cat([emb, h]))
       src.launder();
       load_bias<8>(acc, aux, L_S5, half);
-      { EmbThenHid<Src, NE, 8> s{src, h}; layer_mac<8, NE + 128>(acc, st, s, save_h(ws.A(4))); }
+      { EmbThenHid<Src, NE, 8> s{src, h}; layer_mac<8, NE + 128>(acc, st, s, save_h(ws.A(4), kMaskGrpA + 3)); }
       finish<8, true>(acc, h);
 #pragma unroll 1
       for (int l = L_S6; l <= L_S8; ++l) {
         load_bias<8>(acc, aux, l, half);
-        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(l - L_S1))); }
+        { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(l - L_S1), kMaskGrpA + l - L_S1 - 1)); }
         finish<8, true>(acc, h);
       }
       // sigma head (no activation, nerf_model.py:108)
@@ -1136,7 +1204,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
       } else {
       // xyz_encoding_final (no activation)
       load_bias<8>(acc, aux, L_SF, half);
-      { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(8))); }
+      { HidSrc<8> s{h}; layer_mac<8, 128>(acc, st, s, save_h(ws.A(8), kMaskGrpA + 7)); }
       finish<8, false>(acc, h);
       // dir_encoding: cat([final, dir]) -> W/2, LeakyReLU
       f32x16 acc4[4], hd[4];
@@ -1144,15 +1212,18 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
         // bias + W[:, 256:283] . PE(dir) comes per ray; the 14 direction k-steps (groups 32..35) are skipped
         load_rb<4>(hd, rbp + kRbSD);
         zero_acc<4>(acc4);
-        { HidSrc<8> s{h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal()), SkipGroups<32, (128 + kKsDir + 3) / 4>{}); }
+        { HidSrc<8> s{h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal(), -1), SkipGroups<32, (128 + kKsDir + 3) / 4>{}); }
         finish_add<4, true>(acc4, hd, hd);
       } else {
         src.launder();
         load_bias<4>(acc4, aux, L_SD, half);
-        { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal())); }
+        { HidThenDir<Src, 128, 8> s{src, h}; layer_mac<4, 128 + kKsDir>(acc4, st, s, save_h(ws.sfinal(), -1)); }
         finish<4, true>(acc4, hd);
       }
-      if constexpr (SAVE) save_tiles<4>(hd, ws.sdirh(), 128, stg);
+      if constexpr (SAVE) {
+        save_tiles<4>(hd, ws.sdirh(), 128, stg);
+        if (mask_ws) sign_store_all<4>(hd, mask_row<4>(mask_ws, stg.p0, kMaskGrpSD, lane));
+      }
       float col[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -1184,10 +1255,13 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
         { ObjInOnly<Src> s{src}; layer_mac<4, NO>(acc, st, s); }
         finish<4, true>(acc, h);
       }
-      auto save_h = [&](float* mat) __attribute__((always_inline)) { return SaveHook<SAVE, 4>{h, mat, 128, stg}; };
+      MaskBits<4> mb;
+      auto save_h = [&](float* mat, int grp) __attribute__((always_inline)) {
+        return SaveHook<SAVE, 4>{h, mat, 128, stg, (SAVE && mask_ws && grp >= 0) ? mask_row<4>(mask_ws, stg.p0, grp, lane) : nullptr, mb};
+      };
       if constexpr (PREFETCH) pre.stage_b(a.grid);
       load_bias<4>(acc, aux, L_O2, half);
-      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(1))); }
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(1), kMaskGrpB)); }
       finish<4, true>(acc, h);
       if constexpr (PREFETCH) pre.template stage_rows<0>(a.grid, half);
       src.launder();
@@ -1195,16 +1269,16 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
         f32x16 t3[4];                              // h is this layer's input: the ray vector waits in registers of its own
         load_rb<4>(t3, rbp + kRbO3);
         zero_acc<4>(acc);
-        { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2)), SkipCode{}); }
+        { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2), kMaskGrpB + 1), SkipCode{}); }
         finish_add<4, true>(acc, t3, h);
       } else {
         load_bias<4>(acc, aux, L_O3, half);
-        { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2))); }
+        { ObjInThenHid<Src, NO, 4> s{src, h}; layer_mac<4, NO + 64>(acc, st, s, save_h(ws.B(2), kMaskGrpB + 1)); }
         finish<4, true>(acc, h);
       }
       if constexpr (PREFETCH) { pre.template stage_acc<0>(); pre.template stage_rows<1>(a.grid, half); }
       load_bias<4>(acc, aux, L_O4, half);
-      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(3))); }
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(3), kMaskGrpB + 2)); }
       finish<4, true>(acc, h);
       const float sg = head_dot<4>(h, aux + kAuxOSig, half) + aux[kAuxOSig + 4 * 32];
       if constexpr (PREFETCH) pre.template stage_acc<1>();
@@ -1212,21 +1286,24 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
         if (valid && half == 0) out_store(a.inst_sigma + p, sg);
       } else {
       load_bias<4>(acc, aux, L_OF, half);
-      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(4))); }
+      { HidSrc<4> s{h}; layer_mac<4, 64>(acc, st, s, save_h(ws.B(4), kMaskGrpB + 3)); }
       finish<4, false>(acc, h);
       f32x16 acc2[2], hd[2];
       if constexpr (HOIST) {
         load_rb<2>(hd, rbp + kRbOD);
         zero_acc<2>(acc2);
-        { HidSrc<4> s{h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal()), SkipGroups<16, (64 + kKsDir + 3) / 4>{}); }
+        { HidSrc<4> s{h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal(), -1), SkipGroups<16, (64 + kKsDir + 3) / 4>{}); }
         finish_add<2, true>(acc2, hd, hd);
       } else {
         src.launder();
         load_bias<2>(acc2, aux, L_OD, half);
-        { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal())); }
+        { HidThenDir<Src, 64, 4> s{src, h}; layer_mac<2, 64 + kKsDir>(acc2, st, s, save_h(ws.ofinal(), -1)); }
         finish<2, true>(acc2, hd);
       }
-      if constexpr (SAVE) save_tiles<2>(hd, ws.odirh(), 64, stg);
+      if constexpr (SAVE) {
+        save_tiles<2>(hd, ws.odirh(), 64, stg);
+        if (mask_ws) sign_store_all<2>(hd, mask_row<2>(mask_ws, stg.p0, kMaskGrpOD, lane));
+      }
       float col[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)

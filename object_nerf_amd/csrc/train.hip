@@ -15,8 +15,39 @@
 #include "gemm.h"
 #include "wgrad.h"
 #include "host_api.h"
+#include <mutex>
+#include <vector>
 
 namespace objnerf {
+
+// ---- measurement hook (bench.py train_step.phases_ms): HIP events at the phase boundaries of the training calls --------
+enum { PH_FORWARD = 0, PH_DGRAD, PH_DX, PH_SCATTER, PH_WGRAD, PH_COUNT };
+static_assert(PH_COUNT == OBJNERF_TRAIN_PHASES, "phase list of objnerf_train_timing_read");
+static std::mutex g_pmu;
+static bool g_phase_timing = false;
+struct PhaseSpan { int phase; hipEvent_t e0, e1; };
+static std::vector<PhaseSpan> g_spans;
+// brackets consecutive phases of a call on its stream: begin(p) closes the phase before it; every span owns its two events
+struct PhaseClock {
+  hipStream_t s;
+  bool on;
+  int cur = -1;
+  hipEvent_t start = nullptr;
+  explicit PhaseClock(hipStream_t st) : s(st) { std::lock_guard<std::mutex> lk(g_pmu); on = g_phase_timing; }
+  void begin(int phase) {
+    if (!on) return;
+    if (cur >= 0) {
+      hipEvent_t e = nullptr;
+      hipEventCreate(&e);
+      hipEventRecord(e, s);
+      std::lock_guard<std::mutex> lk(g_pmu);
+      g_spans.push_back({cur, start, e});
+    }
+    cur = phase;
+    if (phase >= 0) { hipEventCreate(&start); hipEventRecord(start, s); }
+  }
+  void end() { begin(-1); }
+};
 
 template <bool TAIL>
 static void gemm_launch_part(const GemmArgs& g, hipStream_t s) {
@@ -138,8 +169,37 @@ int objnerf_gemm(const float* A, int64_t lda, int a_k_contig, const float* B, in
   return gemm_launch(g, (hipStream_t)stream);
 }
 
+int objnerf_train_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_pmu);
+  g_phase_timing = on != 0;
+  for (auto& sp : g_spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
+  g_spans.clear();
+  return 0;
+}
+int objnerf_train_timing_read(double* ms_by_phase, int64_t* spans_by_phase) {
+  std::lock_guard<std::mutex> lk(g_pmu);
+  double ms[PH_COUNT] = {0};
+  int64_t cnt[PH_COUNT] = {0};
+  for (auto& sp : g_spans) {
+    hipEventSynchronize(sp.e1);
+    float t = 0;
+    hipEventElapsedTime(&t, sp.e0, sp.e1);
+    if (sp.phase >= 0 && sp.phase < PH_COUNT) { ms[sp.phase] += t; ++cnt[sp.phase]; }
+    hipEventDestroy(sp.e0); hipEventDestroy(sp.e1);
+  }
+  g_spans.clear();
+  for (int i = 0; i < PH_COUNT; ++i) {
+    if (ms_by_phase) ms_by_phase[i] = ms[i];
+    if (spans_by_phase) spans_by_phase[i] = cnt[i];
+  }
+  return 0;
+}
+
+// saved activations, then (round 5) the LeakyReLU sign masks the fused forward packs for the fused dgrad chain (mlp_kernel.h:
+// 448 B per point, written only by a forward that runs with objnerf_train_args.blob)
+static long ws_act_floats(bool do_object, long n_points) { return (kWsScene + (do_object ? kWsObj : 0)) * n_points; }
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points) {
-  return (kWsScene + (do_object ? kWsObj : 0)) * n_points;
+  return ws_act_floats(do_object != 0, n_points) + train_mask_floats_host(n_points);
 }
 // gradients w.r.t. every layer's pre-activation output (the activation workspace's layout), then the partial tiles of
 // the grouped weight-gradient pass (wgrad.h)
@@ -158,6 +218,9 @@ int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
   auto Wt = [&](int id) { return p[2 * id]; };
   auto Bi = [&](int id) { return p[2 * id + 1]; };
   if (a->blob && !a->aux) return set_error(-1, "mlp_train_forward: blob needs aux");
+  PhaseClock clk((hipStream_t)stream);
+  clk.begin(PH_FORWARD);
+  struct EndClock { PhaseClock& c; ~EndClock() { c.end(); } } end_clock{clk};
   if (a->blob) {
     // persistent MFMA kernel (mlp_kernel.h, memory form) that also writes the activation matrices: one launch per
     // branch; same workspace layout (struct Ws here = struct SaveWs there)
@@ -170,6 +233,11 @@ int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
     m.sigma = a->sigma; m.rgb = a->rgb; m.inst_sigma = a->inst_sigma; m.inst_rgb = a->inst_rgb;
     const long ntiles = (P + 127) / 128;
     const unsigned grid = mlp_grid(ntiles);
+#ifdef OBJ_NO_MASKS          // A/B build switch: round 4's form (no masks written, the chain re-reads the activations)
+    unsigned* mask_ws = nullptr;
+#else
+    unsigned* mask_ws = (unsigned*)(a->workspace + ws_act_floats(a->do_object != 0, P));
+#endif
     if (a->rays) {
       // embeddings computed in registers from (rays, z, grid, codes): both branches in one launch
       if (!a->z_vals || a->S < 1 || a->n_rays * (int64_t)a->S != P || (a->do_object && !a->codes))
@@ -180,13 +248,13 @@ int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
       m.codes = a->codes; m.code_stride = a->code_stride; m.grid = a->grid;
       m.emb_xyz = nullptr; m.emb_dir = nullptr; m.obj_voxel = nullptr; m.obj_code = nullptr;
       m.do_scene = 1; m.do_object = a->do_object ? 1 : 0;
-      return launch_mlp_fused(m, ntiles, grid, (hipStream_t)stream, a->workspace);
+      return launch_mlp_fused(m, ntiles, grid, (hipStream_t)stream, a->workspace, mask_ws);
     }
     m.do_scene = 1; m.do_object = 0;
-    int rc = launch_mlp_memory(m, ntiles, grid, (hipStream_t)stream, a->workspace);
+    int rc = launch_mlp_memory(m, ntiles, grid, (hipStream_t)stream, a->workspace, mask_ws);
     if (rc == 0 && a->do_object) {
       m.do_scene = 0; m.do_object = 1;
-      rc = launch_mlp_memory(m, ntiles, grid, (hipStream_t)stream, a->workspace);
+      rc = launch_mlp_memory(m, ntiles, grid, (hipStream_t)stream, a->workspace, mask_ws);
     }
     return rc;
   }
@@ -255,13 +323,25 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   float* t2 = d.rgb();                    // (P,3) gradient w.r.t. the rgb heads' pre-sigmoid outputs
   float* t2i = d.irgb();
 
+  PhaseClock clk(c.s);
+  struct EndClock { PhaseClock& c; ~EndClock() { c.end(); } } end_clock{clk};
   // ---- phase A: the dgrad chain through the hidden layers -> d.* ----
+  clk.begin(PH_DGRAD);
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_rgb, a->rgb, 3 * P);
   if (obj) hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2i, d_inst_rgb, a->inst_rgb, 3 * P);
   c.rc = check_launch("sigmoid_bwd");
   if (a->blob_bwd) {
-    // one persistent MFMA kernel, gradient tiles stay in registers from layer to layer (mlp_bwd.hip)
-    if (!c.rc) c.rc = launch_mlp_bwd(a->blob_bwd, a->aux, P, a->workspace, scratch, d_sigma, t2, d_inst_sigma, t2i, obj, c.s);
+    // one persistent MFMA kernel, gradient tiles stay in registers from layer to layer (mlp_bwd.hip).  `blob` in THIS call says
+    // that the forward of this workspace ran with blob too, i.e. on the fused kernel, which left the LeakyReLU sign masks behind
+    // the activation matrices; after a layer-by-layer forward (no blob) the chain derives them from the activations instead
+    // (OBJNERF_BWD_MASKS=0: that form also after a fused forward -- A/B switch, identical gradients)
+#ifdef OBJ_NO_MASKS
+    const bool use_masks = false;
+#else
+    const bool use_masks = a->blob != nullptr && [] { const char* e = getenv("OBJNERF_BWD_MASKS"); return !e || atoi(e) != 0; }();
+#endif
+    const unsigned* masks = use_masks ? (const unsigned*)(a->workspace + ws_act_floats(obj, P)) : nullptr;
+    if (!c.rc) c.rc = launch_mlp_bwd(a->blob_bwd, a->aux, P, a->workspace, scratch, d_sigma, t2, d_inst_sigma, t2i, obj, masks, c.s);
   } else {
     // layer by layer: dX = dY W as a GEMM with the LeakyReLU backward in its epilogue
     lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, d.dirh(), 128, 0, w.dirh());
@@ -286,6 +366,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
 
   // ---- phase B0 (before the weight gradients: the dgrad results are consumed while they are cache-hot): gradients w.r.t.
   // the embeddings: every consumer layer's dY W block in one segmented product per input ----
+  clk.begin(PH_DX);
   {
     const int ov = vox ? kObjVoxPE : 0;
     const DgradSeg emb[4] = {{d.A(5), 256, Wt(P_S5), cx + 256, 256}, {d.A(1), 256, Wt(P_S1), cx, 256},
@@ -301,6 +382,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   // ---- the voxel-table scatter of those gradients (objnerf_train_args.scatter_*).  On a SIDE stream beside the weight-gradient
   // kernels it was measured slower (20.30 vs 20.05 ms per step, profiles/r04_train_ab.txt: its workgroups take compute units from
   // MFMA-bound kernels that already run at the part's power limit), so it is simply enqueued here ----
+  clk.begin(PH_SCATTER);
   if (vox && a->scatter_xyz && a->scatter_table_grad && !c.rc)
     c.rc = objnerf_voxel_embed_backward(&a->grid, a->scatter_xyz, P, d_emb_xyz, obj ? d_obj_voxel : nullptr,
                                         a->scatter_table_grad, c.s);
@@ -310,6 +392,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   // accumulation per product (developer A/B switch) ----
   // (read on every call, not cached: tests/test_gpu_train.py switches it inside one process to cross-check the two paths)
   const bool atomic_wgrad = [] { const char* e = getenv("OBJNERF_WGRAD"); return e && !strcmp(e, "atomic"); }();
+  clk.begin(PH_WGRAD);
   WgradBatch batch;
   auto wgrad = [&](const float* dY, long lddy, const float* Xo, long ldx, long /*P*/, int out, int in, float* dW, long ldw, float* db = nullptr) {
     if (atomic_wgrad) { lin_wgrad(c, dY, lddy, Xo, ldx, P, out, in, dW, ldw, db); return; }

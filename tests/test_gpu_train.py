@@ -319,14 +319,16 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
                 blk_a, blk_b = o["ws"][off * P:(off + w) * P], o_l["ws"][off * P:(off + w) * P]
                 assert H.normwise(blk_a, blk_b) < 2e-5, (mode, "activation matrix %d" % i)
             off += w
-        assert off * P == ws_floats
+        # behind the activation matrices: the LeakyReLU sign masks the fused forward leaves for the fused dgrad chain
+        # (csrc/mlp_kernel.h: 14 groups x 64 lanes x 16 bytes per 32 points, whole 128-point tiles)
+        assert off * P + ((P + 127) // 128) * 4 * 14 * 256 == ws_floats
 
     # backward on the layer-wise forward's activations: GEMM chain vs fused chain
     g = torch.Generator(device=DEV).manual_seed(9)
     d_sigma, d_rgb = torch.randn(P, device=DEV, generator=g), torch.randn(P, 3, device=DEV, generator=g)
     d_isig, d_irgb = (torch.randn(P, device=DEV, generator=g), torch.randn(P, 3, device=DEV, generator=g)) if fi else (None, None)
 
-    def backward(fused):
+    def backward(fused, a_l=a_l):
         a_l.aux = aux.data_ptr()
         a_l.blob_bwd = blob_bwd.data_ptr() if fused else None
         grads = [torch.zeros_like(p) for p in params]
@@ -349,6 +351,22 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
         worst = max(worst, rel_l2(u, v))
     assert worst < 1e-5, worst
     print(sname, fi, "fused dgrad chain vs GEMM chain: worst rel L2 %.2e" % worst)
+
+    # round 5: after a FUSED forward (blob given) the chain takes leaky' from the sign masks that forward packed, instead of
+    # re-reading the activations (what it did above, behind the layer-wise forward): the same bits, so the same gradients bit
+    # for bit as with the masks switched off (OBJNERF_BWD_MASKS=0), and the GEMM chain on that workspace agrees as before
+    a_f, o_f = forward("fused")          # (o_f keeps the workspace alive)
+    g_masks = backward(True, a_f)
+    os.environ["OBJNERF_BWD_MASKS"] = "0"
+    try:
+        g_acts = backward(True, a_f)
+    finally:
+        del os.environ["OBJNERF_BWD_MASKS"]
+    for i, (u, v) in enumerate(zip(g_masks, g_acts)):
+        assert torch.equal(u, v), "gradient %d differs between the mask-fed and the activation-fed dgrad chain" % i
+    g_gemm_f = backward(False, a_f)
+    worst = max(rel_l2(u, v) for u, v in zip(g_masks, g_gemm_f) if v.abs().max().item() > 0)
+    assert worst < 1e-5, worst
 
 
 @pytest.mark.parametrize("S", [128, 192])
