@@ -629,6 +629,8 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
         target = torch.rand(n_rays, 3, device=dev, generator=g)
         ids = synth.per_ray_ids(n_rays).to(dev)
         ptm = (ids == 1).view(-1, 1)
+        zeros = torch.zeros(n_rays, device=dev)
+        mse = torch.nn.functional.mse_loss
 
         def step():
             idx = torch.randint(0, rays_all.shape[0], (n_rays,), device=dev, generator=g)
@@ -637,8 +639,10 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
             codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
             r = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
                               embedding_instance=codes, frustum_bound_th=0.025, pass_through_mask=ptm)
-            loss = sum(((r["rgb_%s" % t] - target) ** 2).mean() + ((r["rgb_instance_%s" % t] - target) ** 2).mean()
-                       + 0.1 * (r["depth_%s" % t] ** 2).mean() + (r["opacity_instance_%s" % t] ** 2).mean() for t in ("coarse", "fine"))
+            # the reference's loss terms are nn.MSELoss against per-ray targets (models/losses.py: ColorLoss, DepthLoss, OpacityLoss):
+            # colour of both branches, depth (weight 0.1) and instance opacity, coarse + fine
+            loss = sum(mse(r["rgb_%s" % t], target) + mse(r["rgb_instance_%s" % t], target)
+                       + 0.1 * mse(r["depth_%s" % t], zeros) + mse(r["opacity_instance_%s" % t], zeros) for t in ("coarse", "fine"))
             loss.backward()
             sync.sync()
             opt.step()

@@ -516,6 +516,11 @@ int objnerf_voxel_embed_backward(const objnerf_voxel_grid* grid, const float* xy
 
 /* out[r, c] += sum_{s < S} x[r*S + s, c]   (gradient of the `repeat` of per-ray codes, rendering.py:94) */
 int objnerf_sum_over_samples(const float* x, int64_t n_rays, int S, int C, float* out, void* stream);
+/* Backward of the row gather CodeLibrary.forward does (models/code_library.py:20-28: nn.Embedding on `instance_ids`):
+ * table_grad (n_table_rows, C) += the rows d_rows (n, C) that picked each table row, added in ascending order of i
+ * (bit-reproducible, no atomics).  ids: int64 (n), values outside [0, n_table_rows) are ignored.  C <= 1024. */
+int objnerf_rows_gather_backward(const float* d_rows, const int64_t* ids, int64_t n, int C, int64_t n_table_rows, float* table_grad,
+                                 void* stream);
 
 /* xyz[n, s, :] = rays_o + rays_d * z_vals[n, s]  (rendering.py:279), materialised for the training path */
 int objnerf_sample_points(const float* rays, const float* z_vals, int64_t n_rays, int S, float* xyz, void* stream);

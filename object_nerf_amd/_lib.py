@@ -226,6 +226,7 @@ SIGNATURES = {
     "objnerf_composite_backward": (C.c_int, [C.POINTER(CompositeArgs), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "objnerf_voxel_embed_backward": (C.c_int, [C.POINTER(VoxelGrid), _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "objnerf_sum_over_samples": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_int, _VP, _VP]),
+    "objnerf_rows_gather_backward": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.c_int64, _VP, _VP]),
     "objnerf_sample_points": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, _VP, _VP]),
     "objnerf_arch_num_param_ptrs": (C.c_int, [C.POINTER(Arch)]),
     "objnerf_mlp_generic_workspace_floats": (C.c_int64, [C.POINTER(Arch), C.c_int64]),

@@ -5,10 +5,35 @@ an `nn.Embedding` registered as `embedding_instance` (state_dict key `embedding_
 by render_tools/multi_rendering.py:46 and tools/extract_mesh.py:99), and calling the module with a batch dict
 returns `{"embedding_instance": rows}` when the batch carries `instance_ids`, `{}` otherwise.
 
-A 64 x 64 table lookup is index plumbing, not arithmetic: it stays a torch gather on the device (which also gives
-the code table its gradient through ordinary autograd on the training path).
+A 64 x 64 table lookup is index plumbing, not arithmetic: the forward stays a torch gather on the device.  Its gradient on
+the training path (2048 rows scattered back into a 64-row table every step) goes through objnerf_rows_gather_backward: one
+workgroup per table row, fixed summation order (torch's embedding backward runs one 64-thread workgroup: 0.115 ms of a 19 ms
+training step, profiles/r05_train_kernel_stats.md).
 """
+import torch
 from torch import nn
+
+from . import _lib
+
+
+class _GatherRows(torch.autograd.Function):
+    """out = table[ids] with the HIP scatter as its backward (fp32 table on the GPU, 1-D int64 ids)"""
+
+    @staticmethod
+    def forward(ctx, table, ids):
+        ctx.save_for_backward(ids)
+        ctx.shape = table.shape
+        return table.detach()[ids]
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        (ids,) = ctx.saved_tensors
+        d = _lib.as_f32(d_rows)
+        g = torch.zeros(ctx.shape, dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            _lib.check(_lib.lib().objnerf_rows_gather_backward(_lib.ptr(d), _lib.ptr(ids), ids.numel(), ctx.shape[1], ctx.shape[0],
+                                                               _lib.ptr(g), _lib.stream_ptr()), "rows_gather_backward")
+        return g, None
 
 
 class CodeLibrary(nn.Module):
@@ -22,4 +47,10 @@ class CodeLibrary(nn.Module):
     def forward(self, inputs):
         if "instance_ids" not in inputs:
             return {}
-        return {"embedding_instance": self.embedding_instance(inputs["instance_ids"].squeeze())}
+        ids = inputs["instance_ids"].squeeze()
+        w = self.embedding_instance.weight
+        if (w.is_cuda and w.dtype == torch.float32 and w.requires_grad and torch.is_grad_enabled() and ids.dim() == 1
+                and ids.dtype == torch.int64 and ids.is_cuda and w.shape[1] <= 1024 and self.embedding_instance.padding_idx is None
+                and self.embedding_instance.max_norm is None):
+            return {"embedding_instance": _GatherRows.apply(w, ids.contiguous())}
+        return {"embedding_instance": self.embedding_instance(ids)}

@@ -164,6 +164,9 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
 #ifndef OBJ_VB_SLOT_BITS
 #define OBJ_VB_SLOT_BITS 8         // 256 slots: 26 KB of LDS, six workgroups per CU (512: three) -- step -0.15 ms, profiles/r04_train_ab.txt
 #endif
+#ifndef OBJ_VB_PROBE_LANES
+#define OBJ_VB_PROBE_LANES 1        // 1: one probing lane per corner (round 5); 0: every channel lane probes (A/B build switch)
+#endif
 constexpr int kVbSlots = 1 << OBJ_VB_SLOT_BITS;               // power of two
 constexpr int kVbStride = kVoxC + 1;        // odd stride: spreads the rows over the LDS banks
 constexpr int kVbPoints = 128;              // points per workgroup (the aggregation window)
@@ -222,9 +225,33 @@ __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxe
       dF += fr * (d[C * (1 + 2 * k) + cc] * sc.c - d[C * (2 + 2 * k) + cc] * sc.s);
       fr *= 2.f;
     }
+#if OBJ_VB_PROBE_LANES
+    // slot of each corner's row: lane k of the point's 32 probes for corner k and the point's lanes read the result (round 5;
+    // until then all 24 channel lanes ran the same compare-and-swap on the same key word: 24 serialised LDS atomics per probe --
+    // the kernel's 0.33 bank conflicts per LDS cycle, profiles/r04_train_pmc.md)
+    int my_row = -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) my_row = sub == k ? row[k] : my_row;
+    int my_slot = -1;
+    if (sub < 8 && my_row >= 0) {
+      unsigned h = ((unsigned)my_row * 2654435761u) >> (32 - OBJ_VB_SLOT_BITS);
+      for (int probe = 0; probe < 8; ++probe) {
+        const int prev = atomicCAS(&keys[h], -1, my_row);
+        if (prev == -1 || prev == my_row) { my_slot = (int)h; break; }
+        h = (h + 1) & (kVbSlots - 1);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+      const int slot = __shfl(my_slot, k, 32);
       if (row[k] < 0) continue;                       // invalid corners were zeroed in the forward pass
+      float* t = slot >= 0 ? vals + slot * kVbStride : table_grad + (size_t)row[k] * kVoxC;   // no free slot: to memory
+      atomicAdd(t + sub, dF * wt[k]);
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (row[k] < 0) continue;
       unsigned h = ((unsigned)row[k] * 2654435761u) >> (32 - OBJ_VB_SLOT_BITS);
       int slot = -1;
       for (int probe = 0; probe < 8; ++probe) {
@@ -232,9 +259,10 @@ __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxe
         if (prev == -1 || prev == row[k]) { slot = (int)h; break; }
         h = (h + 1) & (kVbSlots - 1);
       }
-      float* t = slot >= 0 ? vals + slot * kVbStride : table_grad + (size_t)row[k] * kVoxC;   // no free slot: to memory
+      float* t = slot >= 0 ? vals + slot * kVbStride : table_grad + (size_t)row[k] * kVoxC;
       atomicAdd(t + sub, dF * wt[k]);
     }
+#endif
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kVbSlots * kVoxC; i += 256) {
@@ -254,6 +282,36 @@ __global__ void sum_over_samples_kernel(const float* __restrict__ x, long n_rays
   float s = 0.f;
   for (int i = 0; i < S; ++i) s += x[(r * S + i) * C + c];
   out[idx] = out[idx] + s;      // accumulates: the coarse and the fine pass add into one (N, C) gradient
+}
+
+// gradient of a row gather out[i] = table[ids[i]] (nn.Embedding, models/code_library.py:20-28): one workgroup per TABLE row walks
+// the ids in ascending order and adds the rows that picked it -- a fixed summation order (bit-reproducible), no atomics; the
+// tables are small (N_max_objs = 64 rows), the batch a few thousand rays
+__global__ void __launch_bounds__(256) rows_gather_bwd_kernel(const float* __restrict__ d_rows, const long* __restrict__ ids, long n,
+                                                               int C, float* __restrict__ table_grad) {
+  __shared__ long ids_s[256];
+  const long r = blockIdx.x;
+  const int tid = threadIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};            // columns tid, tid + 256, ... (C <= 1024)
+  for (long base = 0; base < n; base += 256) {
+    const int m = (int)(n - base < 256 ? n - base : 256);
+    __syncthreads();
+    if (tid < m) ids_s[tid] = ids[base + tid];
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+      if (ids_s[j] != r) continue;               // uniform
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = tid + 256 * q;
+        if (c < C) acc[q] += d_rows[(base + j) * C + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = tid + 256 * q;
+    if (c < C) table_grad[r * C + c] += acc[q];
+  }
 }
 
 __global__ void sample_points_kernel(const float* __restrict__ rays, const float* __restrict__ z, long n_rays, int S,
@@ -314,6 +372,17 @@ int objnerf_sum_over_samples(const float* x, int64_t n_rays, int S, int C, float
   hipLaunchKernelGGL(sum_over_samples_kernel, dim3(blk(n_rays * C, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      (long)n_rays, S, C, out);
   return check_launch("sum_over_samples");
+}
+
+int objnerf_rows_gather_backward(const float* d_rows, const int64_t* ids, int64_t n, int C, int64_t n_table_rows, float* table_grad,
+                                 void* stream) {
+  if (!d_rows || !ids || !table_grad || C < 1 || C > 1024 || n < 0 || n_table_rows < 0)
+    return set_error(-1, "rows_gather_backward: bad arguments (1 <= C <= 1024)");
+  if (n == 0 || n_table_rows == 0) return 0;
+  static_assert(sizeof(long) == sizeof(int64_t), "ids are int64");
+  hipLaunchKernelGGL(rows_gather_bwd_kernel, dim3((unsigned)n_table_rows), dim3(256), 0, (hipStream_t)stream, d_rows,
+                     (const long*)ids, (long)n, C, table_grad);
+  return check_launch("rows_gather_backward");
 }
 
 int objnerf_sample_points(const float* rays, const float* z_vals, int64_t n_rays, int S, float* xyz, void* stream) {

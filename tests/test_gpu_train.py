@@ -660,3 +660,36 @@ def test_adam_step_on_the_layerwise_path_matches_oracle_autograd(monkeypatch):
         assert r <= max(1e-4, 3.0 * max(floor_rel[:i + 1])), (i, r)
     for k in drift:
         assert drift[k] <= 3.0 * floor[k] + 1e-3, (k, drift[k], floor[k])
+
+
+def test_code_table_gradient_matches_nn_embedding():
+    """CodeLibrary's row gather has the HIP scatter objnerf_rows_gather_backward as its backward on the training path (one
+    workgroup per table row, ascending order): against torch's own nn.Embedding backward on 2,048 rows with repeated, missing
+    and boundary ids, bit-reproducible run to run; CPU tables and no-grad calls keep the plain nn.Embedding path."""
+    from object_nerf_amd.code_library import CodeLibrary
+    lib_ = CodeLibrary(A.default_model_config()).to(DEV)
+    n = 2048
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 64, (n,), generator=g)
+    ids[:7] = torch.tensor([0, 63, 63, 5, 5, 5, 0])
+    ids = ids[(ids != 17) & (ids != 40)][:2000]                 # two rows never picked
+    ids_d = ids.to(DEV)
+    wgt = torch.randn(ids.numel(), 64, generator=g).to(DEV)
+    grads = []
+    for _ in range(2):
+        lib_.zero_grad()
+        out = lib_({"instance_ids": ids_d.view(-1, 1)})["embedding_instance"]
+        assert out.grad_fn is not None and "GatherRows" in type(out.grad_fn).__name__
+        (out * wgt).sum().backward()
+        grads.append(lib_.embedding_instance.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    ref = torch.nn.Embedding(64, 64).to(DEV)
+    with torch.no_grad():
+        ref.weight.copy_(lib_.embedding_instance.weight)
+    (ref(ids_d) * wgt).sum().backward()
+    assert torch.equal(out.detach(), ref(ids_d).detach())
+    assert rel_l2(grads[0], ref.weight.grad) < 1e-6
+    assert grads[0][17].abs().max().item() == 0 and grads[0][40].abs().max().item() == 0
+    with torch.no_grad():
+        o2 = lib_({"instance_ids": ids_d})["embedding_instance"]
+    assert o2.grad_fn is None and torch.equal(o2, out.detach())

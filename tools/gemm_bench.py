@@ -25,7 +25,13 @@ def main(tags):
     shapes += [("fwd  in=95 -> 256", 1, 1, P, 256, 95, 1), ("wgrad 256 x 95", 0, 0, 256, 95, P, 512),
                # the embedding-gradient product of the first scene layer (dX = dY W, 271 input columns: 3 column tiles
                # that all stream the same P x 256 panel of dY) and its weight gradient, at the fine pass's point count
-               ("dgrad dX=dY W 256->271", 1, 0, 2048 * 128, 271, 256, 1), ("wgrad 256 x 271", 0, 0, 256, 271, 2048 * 128, 256)]
+               ("dgrad dX=dY W 256->271", 1, 0, 2048 * 128, 271, 256, 1), ("wgrad 256 x 271", 0, 0, 256, 271, 2048 * 128, 256),
+               # round 5: the embedding-gradient products of the training step (N = 208 / 104 / 64 output columns) and the
+               # layer-wise path's first layers (K = 271 / 439 input columns)
+               ("dgrad 256 -> 208", 1, 0, 2048 * 128, 208, 256, 1), ("dgrad 128 -> 104", 1, 0, 2048 * 128, 104, 128, 1),
+               ("dgrad 128 -> 64", 1, 0, 2048 * 128, 64, 128, 1),
+               ("fwd  in=271 -> 256", 1, 1, P, 256, 271, 1), ("fwd  in=439 -> 128", 1, 1, P, 128, 439, 1),
+               ("fwd  in=283 -> 128", 1, 1, P, 128, 283, 1)]
     libs = {t: load(t) for t in tags}
     for name, akc, bkc, M, N, K, split in shapes:
         a = torch.randn((M, K) if akc else (K, M), device=dev)

@@ -31,6 +31,7 @@ def main(n_rays=2048, steps=5):
     sync = GradientSync(params)
     g = torch.Generator(device=dev).manual_seed(rank)
     target = torch.rand(n_rays, 3, device=dev, generator=g)
+    zeros = torch.zeros(n_rays, device=dev)
 
     def step(timed=True):
         idx = torch.randint(0, rays_all.shape[0], (n_rays,), device=dev, generator=g)
@@ -40,8 +41,9 @@ def main(n_rays=2048, steps=5):
         codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
         r = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
                           embedding_instance=codes, frustum_bound_th=0.025, pass_through_mask=(ids == 1).view(-1, 1))
-        loss = sum(((r["rgb_%s" % t] - target) ** 2).mean() + ((r["rgb_instance_%s" % t] - target) ** 2).mean()
-                   + 0.1 * (r["depth_%s" % t] ** 2).mean() + (r["opacity_instance_%s" % t] ** 2).mean() for t in ("coarse", "fine"))
+        mse = torch.nn.functional.mse_loss      # the reference's loss terms are nn.MSELoss (models/losses.py)
+        loss = sum(mse(r["rgb_%s" % t], target) + mse(r["rgb_instance_%s" % t], target)
+                   + 0.1 * mse(r["depth_%s" % t], zeros) + mse(r["opacity_instance_%s" % t], zeros) for t in ("coarse", "fine"))
         if not timed:                       # a training loop as it runs: nothing waits for the device inside a step
             loss.backward()
             sync.sync()
