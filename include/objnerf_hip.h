@@ -478,6 +478,14 @@ typedef struct {
    * after the embedding-gradient products (one call less per pass; on a side stream beside the weight-gradient kernels it
    * measured slower, CHANGELOG.md). */
   const float* scatter_xyz; float* scatter_table_grad;
+  /* optional (ABI 9), read by objnerf_mlp_train_backward only: the direction embedding per RAY (n_rays, 27).  Together with
+   * n_rays / S (S % 16 == 0, n_rays * S == n_points) and -- when do_object -- codes / code_stride (= 64) it selects the per-ray
+   * form of the terms that are constant along a ray (the reference repeats rays_d and the code over the samples,
+   * models/rendering.py:89-94): the gradients of the weight columns that meet the direction embedding / the object code, and the
+   * gradient w.r.t. the code, are contracted over n_points / 16 segment sums instead of n_points points.  emb_dir / obj_code
+   * (per point) may then be NULL, and d_obj_code receives (n_points / 16, 64): one row per 16 consecutive points, to be summed
+   * over a ray's S / 16 segments by the caller (objnerf_sum_over_samples with S / 16). */
+  const float* emb_dir_ray;
 } objnerf_train_args;
 int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points);
 /* scratch of objnerf_mlp_train_backward: the gradients w.r.t. every layer's pre-activation output (12.9 KB per point) + the
@@ -490,7 +498,7 @@ int objnerf_mlp_train_forward(const objnerf_train_args* args, void* stream);
  * pointers, one per parameter tensor, ACCUMULATED into (+=).  d_emb_xyz (P,in_xyz; only the 208 voxel-feature columns
  * are written -- the xyz positional-encoding columns have no consumer, depths are detached -- and nothing in plain-PE
  * mode), d_obj_voxel (P,104),
- * d_obj_code (P,64) are overwritten.  scratch: objnerf_train_scratch_floats() floats (holds the gradient w.r.t. every
+ * d_obj_code (P,64; (P/16,64) in the per-ray form, see emb_dir_ray) are overwritten.  scratch: objnerf_train_scratch_floats() floats (holds the gradient w.r.t. every
  * layer's pre-activation output, in the layout of the activation workspace). */
 int objnerf_mlp_train_backward(const objnerf_train_args* args, const float* d_sigma, const float* d_rgb,
                                const float* d_inst_sigma, const float* d_inst_rgb, float* const* h_param_grads,

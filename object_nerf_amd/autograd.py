@@ -31,7 +31,7 @@ def _empty(*shape, dev):
 class _Pass:
     """saved state of one (coarse / fine) pass"""
     __slots__ = ("z", "xyz", "emb_xyz", "obj_voxel", "emb_dir", "code_pts", "sigma", "rgb", "isig", "irgb", "ws",
-                 "noise", "noise_i", "S")
+                 "noise", "noise_i", "S", "per_ray")
 
 
 def _ptr_table(tensors):
@@ -85,9 +85,12 @@ def _train_args(meta, ps, params, packed=None, rays=None, codes=None):
     a.n_points = ps.emb_xyz.shape[0]
     table = _ptr_table(params)
     a.h_params = table
-    a.emb_xyz, a.emb_dir = ps.emb_xyz.data_ptr(), ps.emb_dir.data_ptr()
+    a.emb_xyz = ps.emb_xyz.data_ptr()
+    if ps.emb_dir is not None:
+        a.emb_dir = ps.emb_dir.data_ptr()
     if meta["forward_instance"]:
-        a.obj_code = ps.code_pts.data_ptr()
+        if ps.code_pts is not None:
+            a.obj_code = ps.code_pts.data_ptr()
         if meta["use_voxel"]:
             a.obj_voxel = ps.obj_voxel.data_ptr()
         a.inst_sigma, a.inst_rgb = ps.isig.data_ptr(), ps.irgb.data_ptr()
@@ -131,8 +134,14 @@ class RenderRaysFn(torch.autograd.Function):
             else:
                 ps.emb_xyz, ps.obj_voxel = _empty(P, 63, dev=dev), None
                 _lib.check(l.objnerf_pos_encode(_lib.ptr(ps.xyz), P, 3, 10, _lib.ptr(ps.emb_xyz), st), "pos_encode")
-            ps.emb_dir = emb_dir_ray.repeat_interleave(Sx, 0)
-            ps.code_pts = codes_c.repeat_interleave(Sx, 0) if fi else None
+            # per-ray form of the terms that are constant along a ray (include/objnerf_hip.h, objnerf_train_args.emb_dir_ray): the
+            # fused kernels embed directions / read codes per ray in the forward, and the backward contracts the weight columns
+            # they meet over 16-point segment sums -- the per-point copies are then never read
+            ps.per_ray = (packed is not None and packed[0] is not None and packed[2] is not None and Sx % 16 == 0
+                          and os.environ.get("OBJNERF_TRAIN_LAYERWISE") != "mem" and os.environ.get("OBJNERF_TRAIN_PER_RAY", "1") != "0"
+                          and os.environ.get("OBJNERF_WGRAD") != "atomic")
+            ps.emb_dir = None if ps.per_ray else emb_dir_ray.repeat_interleave(Sx, 0)
+            ps.code_pts = (None if ps.per_ray else codes_c.repeat_interleave(Sx, 0)) if fi else None
             ps.sigma, ps.rgb = _empty(P, dev=dev), _empty(P, 3, dev=dev)
             ps.isig, ps.irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
             ps.ws = _empty(l.objnerf_train_workspace_floats(int(fi), P), dev=dev)
@@ -175,6 +184,7 @@ class RenderRaysFn(torch.autograd.Function):
         ctx.meta, ctx.passes, ctx.keys = meta, passes, keys
         ctx.p_coarse, ctx.p_fine = p_coarse, p_fine
         ctx.rays_c = rays_c
+        ctx.emb_dir_ray, ctx.codes_c = emb_dir_ray, codes_c
         ctx.table_shape = table.shape if table is not None else None
         ctx.n_params = len(params)
         out = tuple(results[k] for k in keys)
@@ -227,7 +237,12 @@ class RenderRaysFn(torch.autograd.Function):
             gtable = _ptr_table(gp)
             d_emb = _empty(P, ps.emb_xyz.shape[1], dev=dev)
             d_ov = _empty(P, 104, dev=dev) if (fi and vox) else None
-            d_code = _empty(P, 64, dev=dev) if fi else None
+            seg = 16 if ps.per_ray else 1                       # per-ray form: one code-gradient row per 16 points
+            d_code = _empty(P // seg, 64, dev=dev) if fi else None
+            if ps.per_ray:
+                a.emb_dir_ray, a.n_rays, a.S = ctx.emb_dir_ray.data_ptr(), n, Sx
+                if fi:
+                    a.codes, a.code_stride = ctx.codes_c.data_ptr(), ctx.codes_c.stride(0)
             scratch = _empty(l.objnerf_train_scratch_floats(P), dev=dev)
             if vox:      # the table scatter rides inside the call (objnerf_train_args.scatter_*)
                 assert ps.xyz.is_contiguous() and d_table.is_contiguous()
@@ -237,7 +252,7 @@ class RenderRaysFn(torch.autograd.Function):
                                                     _lib.ptr(d_irgb), gtable, _lib.ptr(d_emb), _lib.ptr(d_ov), _lib.ptr(d_code),
                                                     _lib.ptr(scratch), st), "mlp_train_backward")
             if fi:
-                _lib.check(l.objnerf_sum_over_samples(_lib.ptr(d_code), n, Sx, 64, _lib.ptr(d_codes), st), "sum_over_samples")
+                _lib.check(l.objnerf_sum_over_samples(_lib.ptr(d_code), n, Sx // seg, 64, _lib.ptr(d_codes), st), "sum_over_samples")
         flat = list(param_grads[0]) + (list(param_grads[1]) if len(param_grads) > 1 else [])
         flat += [None] * (ctx.n_params - len(flat))
         return (None, None, d_codes, d_table, *flat)

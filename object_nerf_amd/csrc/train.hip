@@ -203,13 +203,28 @@ int64_t objnerf_train_workspace_floats(int do_object, int64_t n_points) {
 }
 // gradients w.r.t. every layer's pre-activation output (the activation workspace's layout), then the partial tiles of
 // the grouped weight-gradient pass (wgrad.h)
-int64_t objnerf_train_scratch_floats(int64_t n_points) { return (kWsScene + kWsObj) * n_points + wgrad_scratch_floats(n_points); }
+// ... then (round 5) the per-ray terms' area: column sums of four layers' gradients per 16 points, the per-segment input rows
+// they are contracted with, and the partial tiles of that second, small weight-gradient pass
+constexpr long kSegCols = 128 + 128 + 128 + 64;                 // O1 | O3 | scene direction layer | object direction layer
+constexpr long kSegXLd = 92;                                    // code (64) | direction embedding (27) | pad
+static long seg_count(long n_points) { return (n_points + 15) / 16; }
+static long seg_area_floats(long n_points) {
+  const long ns = seg_count(n_points);
+  return ns * (kSegCols + kSegXLd) + wgrad_scratch_floats(ns);
+}
+int64_t objnerf_train_scratch_floats(int64_t n_points) {
+  return (kWsScene + kWsObj) * n_points + wgrad_scratch_floats(n_points) + seg_area_floats(n_points);
+}
 
 int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
-  if (!a || !a->h_params || !a->emb_xyz || !a->emb_dir || !a->workspace || !a->sigma || !a->rgb)
+  if (!a || !a->h_params || !a->emb_xyz || !a->workspace || !a->sigma || !a->rgb)
     return set_error(-1, "mlp_train_forward: bad arguments");
-  if (a->do_object && (!a->obj_code || (a->use_voxel && !a->obj_voxel) || !a->inst_sigma || !a->inst_rgb))
+  if (a->do_object && ((a->use_voxel && !a->obj_voxel) || !a->inst_sigma || !a->inst_rgb))
     return set_error(-1, "mlp_train_forward: object branch inputs/outputs missing");
+  // the per-point direction embeddings / object codes are read only by a forward that does not embed in registers
+  const bool fused_inputs = a->blob && a->rays;
+  if (!fused_inputs && (!a->emb_dir || (a->do_object && !a->obj_code)))
+    return set_error(-1, "mlp_train_forward: emb_dir / obj_code are required unless the forward embeds in registers (blob + rays)");
   const long P = a->n_points;
   if (P == 0) return 0;
   const bool vox = a->use_voxel != 0;
@@ -304,6 +319,19 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     return set_error(-1, "mlp_train_backward: bad arguments");
   if (a->do_object && (!d_inst_sigma || !d_inst_rgb || !d_obj_code || (a->use_voxel && !d_obj_voxel)))
     return set_error(-1, "mlp_train_backward: object branch gradients missing");
+  // Per-ray terms (round 5).  The direction embedding and the object code are constant along a ray, so the gradients of the
+  // weight columns they meet (dir_encoding / inst_dir_encoding: 27 columns, instance_encoding_1 / _3: 64 columns) and the
+  // gradient w.r.t. the code are functions of the layer gradients SUMMED over the ray's samples: sum_p dY_p x_ray(p) =
+  // sum_ray (sum_s dY) x_ray.  The grouped weight-gradient pass leaves those sums per 16 points beside its bias sums
+  // (wgrad.h segsum), and a second, small pass contracts them over P / 16 segments instead of P points: four ragged tiles of
+  // the main pass, the (P x 64) code-gradient product and the per-point copies of codes / direction embeddings disappear.
+  // Needs whole 16-point segments inside a ray (S % 16 == 0) and the per-ray inputs; otherwise the per-point form below.
+  const bool per_ray = a->emb_dir_ray != nullptr && a->S >= 16 && a->S % 16 == 0 && a->n_rays * (int64_t)a->S == a->n_points &&
+                       (!a->do_object || (a->codes != nullptr && a->code_stride == kCodeC)) &&
+                       [] { const char* e = getenv("OBJNERF_TRAIN_PER_RAY"); return !e || atoi(e) != 0; }() &&
+                       [] { const char* e = getenv("OBJNERF_WGRAD"); return !(e && !strcmp(e, "atomic")); }();
+  if (!per_ray && (!a->emb_dir || (a->do_object && !a->obj_code)))
+    return set_error(-1, "mlp_train_backward: emb_dir / obj_code (per point) or emb_dir_ray / codes / S (per ray) are required");
   if (a->blob_bwd && !a->aux) return set_error(-1, "mlp_train_backward: blob_bwd needs aux");
   const long P = a->n_points;
   if (P == 0) return 0;
@@ -376,7 +404,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
       const DgradSeg ovs[2] = {{d.B(3), 128, Wt(P_O3) + cx, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx, co, 128}};
       if (vox) lin_dgrad_multi(c, ovs, 2, P, kObjVoxPE, d_obj_voxel, kObjVoxPE);
       const DgradSeg cds[2] = {{d.B(3), 128, Wt(P_O3) + cx + ov, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx + ov, co, 128}};
-      lin_dgrad_multi(c, cds, 2, P, kCodeC, d_obj_code, kCodeC);
+      if (!per_ray) lin_dgrad_multi(c, cds, 2, P, kCodeC, d_obj_code, kCodeC);
     }
   }
   // ---- the voxel-table scatter of those gradients (objnerf_train_args.scatter_*).  On a SIDE stream beside the weight-gradient
@@ -394,15 +422,18 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   const bool atomic_wgrad = [] { const char* e = getenv("OBJNERF_WGRAD"); return e && !strcmp(e, "atomic"); }();
   clk.begin(PH_WGRAD);
   WgradBatch batch;
-  auto wgrad = [&](const float* dY, long lddy, const float* Xo, long ldx, long /*P*/, int out, int in, float* dW, long ldw, float* db = nullptr) {
+  // seg (per_ray only): where this layer's 16-point column sums go (column offset inside the segment-sum rows)
+  float* const segsum = scratch + (kWsScene + kWsObj) * P + wgrad_scratch_floats(P);       // (P / 16) x kSegCols
+  auto wgrad = [&](const float* dY, long lddy, const float* Xo, long ldx, long /*P*/, int out, int in, float* dW, long ldw, float* db = nullptr,
+                   int seg = -1) {
     if (atomic_wgrad) { lin_wgrad(c, dY, lddy, Xo, ldx, P, out, in, dW, ldw, db); return; }
     if (out <= 3) batch.add_head(dY, out, Xo, ldx, in, dW, ldw, db);
-    else batch.add(dY, lddy, Xo, ldx, out, in, dW, ldw, db);
+    else batch.add(dY, lddy, Xo, ldx, out, in, dW, ldw, db, (per_ray && seg >= 0) ? segsum + seg : nullptr, kSegCols);
   };
   // scene heads and the direction layer (cat([final, emb_dir]) as column blocks)
   wgrad(t2, 3, w.dirh(), 128, P, 3, 128, gW(P_SRGB), 128, gB(P_SRGB));
-  wgrad(d.dirh(), 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC, gB(P_SD));
-  wgrad(d.dirh(), 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
+  wgrad(d.dirh(), 128, w.final_(), 256, P, 128, 256, gW(P_SD), 256 + kDirC, gB(P_SD), 256);
+  if (!per_ray) wgrad(d.dirh(), 128, a->emb_dir, kDirC, P, 128, kDirC, gW(P_SD) + 256, 256 + kDirC);
   wgrad(d.final_(), 256, w.A(8), 256, P, 256, 256, gW(P_SF), 256, gB(P_SF));
   wgrad(d_sigma, 1, w.A(8), 256, P, 1, 256, gW(P_SSIG), 256, gB(P_SSIG));
   for (int l = 8; l >= 1; --l) {
@@ -419,29 +450,57 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   if (obj) {
     const int ov = vox ? kObjVoxPE : 0;
     wgrad(t2i, 3, w.odirh(), 64, P, 3, 64, gW(P_ORGB), 64, gB(P_ORGB));
-    wgrad(d.odirh(), 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC, gB(P_OD));
-    wgrad(d.odirh(), 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
+    wgrad(d.odirh(), 64, w.ofinal(), 128, P, 64, 128, gW(P_OD), 128 + kDirC, gB(P_OD), 384);
+    if (!per_ray) wgrad(d.odirh(), 64, a->emb_dir, kDirC, P, 64, kDirC, gW(P_OD) + 128, 128 + kDirC);
     wgrad(d.ofinal(), 128, w.B(4), 128, P, 128, 128, gW(P_OF), 128, gB(P_OF));
     wgrad(d_inst_sigma, 1, w.B(4), 128, P, 1, 128, gW(P_OSIG), 128, gB(P_OSIG));
     // one layer fed by cat([emb_xyz, obj_voxel, obj_code]): three column blocks of its weight
-    auto obj_in_bwd = [&](const float* dY, int wid, int ldw, float* db) {
-      wgrad(dY, 128, X, cx, P, 128, cx, gW(wid), ldw, db);
+    auto obj_in_bwd = [&](const float* dY, int wid, int ldw, float* db, int seg) {
+      wgrad(dY, 128, X, cx, P, 128, cx, gW(wid), ldw, db, seg);
       if (vox) wgrad(dY, 128, a->obj_voxel, kObjVoxPE, P, 128, kObjVoxPE, gW(wid) + cx, ldw);
-      wgrad(dY, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
+      if (!per_ray) wgrad(dY, 128, a->obj_code, kCodeC, P, 128, kCodeC, gW(wid) + cx + ov, ldw);
     };
     for (int l = 4; l >= 1; --l) {
       float* db = gB(P_O1 + l - 1);
       if (l == 3) {        // cat([input_x, x_])
         wgrad(d.B(3), 128, w.B(2), 128, P, 128, 128, gW(P_O3) + co, co + 128);
-        obj_in_bwd(d.B(3), P_O3, co + 128, db);
+        obj_in_bwd(d.B(3), P_O3, co + 128, db, 128);
       } else if (l == 1) {
-        obj_in_bwd(d.B(1), P_O1, co, db);
+        obj_in_bwd(d.B(1), P_O1, co, db, 0);
       } else {
         wgrad(d.B(l), 128, w.B(l - 1), 128, P, 128, 128, gW(P_O1 + l - 1), 128, db);
       }
     }
   }
   if (!atomic_wgrad && !c.rc) c.rc = batch.launch(P, scratch + (kWsScene + kWsObj) * P, c.s);
+  if (per_ray && !c.rc) {
+    // ---- the per-ray terms from the segment sums the pass above left: K = P / 16 segments ----
+    const long ns = seg_count(P);
+    const int rep = a->S / 16;                                    // segments per ray
+    float* xseg = segsum + ns * kSegCols;                         // ns x kSegXLd: [code | direction embedding] of the segment's ray
+    float* scratch2 = xseg + ns * kSegXLd;
+    c.rc = objnerf_repeat_rows(a->emb_dir_ray, kDirC, ns, kDirC, rep, xseg + kCodeC, kSegXLd, c.s);       // (ns OUTPUT rows)
+    if (!c.rc && obj) c.rc = objnerf_repeat_rows(a->codes, a->code_stride, ns, kCodeC, rep, xseg, kSegXLd, c.s);
+    WgradBatch b2;
+    b2.add(segsum + 256, kSegCols, xseg + kCodeC, kSegXLd, 128, kDirC, gW(P_SD) + 256, 256 + kDirC, nullptr);
+    if (obj) {
+      const int ov = vox ? kObjVoxPE : 0;
+      b2.add(segsum + 384, kSegCols, xseg + kCodeC, kSegXLd, 64, kDirC, gW(P_OD) + 128, 128 + kDirC, nullptr);
+      b2.add(segsum + 0, kSegCols, xseg, kSegXLd, 128, kCodeC, gW(P_O1) + cx + ov, co, nullptr);
+      b2.add(segsum + 128, kSegCols, xseg, kSegXLd, 128, kCodeC, gW(P_O3) + cx + ov, co + 128, nullptr);
+      // gradient w.r.t. the code, per segment (the caller sums a ray's S / 16 segments): d_obj_code is (P / 16, 64) here
+      const DgradSeg cds[2] = {{segsum + 128, kSegCols, Wt(P_O3) + cx + ov, co + 128, 128}, {segsum + 0, kSegCols, Wt(P_O1) + cx + ov, co, 128}};
+      lin_dgrad_multi(c, cds, 2, ns, kCodeC, d_obj_code, kCodeC);
+    }
+    // four ragged tiles contracting over P / 16 rows: slices of 8 k tiles (256 segments) give the device ~100 workgroups instead
+    // of ~16; the slot area (sized for 64 tiles x the default slice count of ns rows) holds 4 tiles x 16 times as many slices
+    const long kt2 = (ns + GBK - 1) / GBK;
+    long sl2 = (kt2 + 7) / 8;
+    const long cap2 = 16L * wgrad_slices(ns);
+    if (sl2 > cap2) sl2 = cap2;
+    if (sl2 > kWgradMaxSlices) sl2 = kWgradMaxSlices;
+    if (!c.rc) c.rc = b2.launch(ns, scratch2, c.s, (int)(sl2 < 1 ? 1 : sl2));
+  }
   return c.rc;
 }
 

@@ -24,6 +24,10 @@ struct WgProduct {             // dW (M x N, leading dimension ldc) += dY^T X
   float* C; long ldc;
   float* rowsum;               // bias gradient db[m] += sum_k dY[k][m] (taken by the tiles of the first tile column) or null
   int M, N;
+  // optional, with rowsum, products without 256 x 256 tiles (round 5; full or ragged first column tile): the same column sums kept PER 16 POINTS,
+  // segsum[(k / 16) * seg_ld + m] = sum of dY[k .. k + 15][m] -- the gradient w.r.t. anything that is constant along a ray
+  // (the object code, the direction embedding: train.hip "per-ray terms") is a function of these sums, not of the points
+  float* segsum; long seg_ld;
 };
 struct WgTile {                // one output tile: rows [128 by, +128), columns [128 bx, +128) of product `prod`
   unsigned char prod, by, bx;
@@ -82,9 +86,10 @@ struct WgradBatch {
   HeadArgs h;
   bool overflow = false;
   WgradBatch() { a.nprod = a.ntile = a.nfull = a.nbig = 0; h.nheads = 0; }
-  void add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db);
+  void add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db,
+           float* segsum = nullptr, long seg_ld = 0);
   void add_head(const float* dY, int no, const float* X, long ldx, int ni, float* dW, long ldw, float* db);
-  int launch(long P, float* scratch, hipStream_t s);
+  int launch(long P, float* scratch, hipStream_t s, int slices = 0);
 };
 
 }  // namespace objnerf

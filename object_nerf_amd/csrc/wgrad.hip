@@ -10,7 +10,8 @@ namespace objnerf {
 
 // ---- ragged tiles (1..3 live 32-column sub-tiles): 4 x 1 waves, gemm.h's operand staging, single LDS buffer ----------------
 __device__ __forceinline__ void wgrad_tail_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend,
-                                                 float* slot, float* lds, int tid) {
+                                                 float* slot, float* lds, int tid, long P) {
+  const long nseg16 = (P + 15) >> 4;
   const int lane = tid & 63, wave = tid >> 6;
   const long m0 = (long)tl.by * GBM, n0 = (long)tl.bx * GBN;
   const int ncol = tl.ncol;
@@ -40,8 +41,13 @@ __device__ __forceinline__ void wgrad_tail_piece(const WgProduct& pr, const WgTi
       opb.fetch(k0 + GBK, kend, tid);
     }
     if (want_rowsum) {                   // A' tile is [k][row]: thread -> row tid % 128, 16 of the 32 k
+      float s16 = 0.f;                   // (the 16-point column sums of WgProduct::segsum; rsum keeps its own chain of additions)
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) rsum += As[((tid >> 7) * 16 + kk) * GLDR + (tid & 127)];
+      for (int kk = 0; kk < 16; ++kk) { const float x = As[((tid >> 7) * 16 + kk) * GLDR + (tid & 127)]; rsum += x; s16 += x; }
+      if (pr.segsum) {
+        const long seg = (k0 >> 4) + (tid >> 7);
+        if (seg < nseg16 && m0 + (tid & 127) < pr.M) gstore(pr.segsum + seg * pr.seg_ld + m0 + (tid & 127), s16);
+      }
     }
     if (m0 + wave * 32 < pr.M) {         // wave-uniform: this wave's row sub-tile exists
 #pragma unroll
@@ -161,9 +167,11 @@ struct WgOperand {             // one operand of a full tile: 128 columns ("rows
 #define OBJ_WG_SYNC() do { if (!(OBJ_ABL & 4)) __syncthreads(); } while (0)
 
 __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgTile& tl, long kbeg, long kend,
-                                                 float* slot, float* lds, int tid) {
+                                                 float* slot, float* lds, int tid, long P) {
   // the lists are read with vector loads (the compiler cannot know they are constant): say that they are uniform
-  const WgProduct pr{uni(prv.A), uni(prv.lda), uni(prv.B), uni(prv.ldb), prv.C, prv.ldc, uni(prv.rowsum), uni(prv.M), uni(prv.N)};
+  const WgProduct pr{uni(prv.A), uni(prv.lda), uni(prv.B), uni(prv.ldb), prv.C, prv.ldc, uni(prv.rowsum), uni(prv.M), uni(prv.N),
+                     uni(prv.segsum), uni(prv.seg_ld)};
+  const long nseg16 = (uni(P) + 15) >> 4;
   kbeg = uni(kbeg); kend = uni(kend); slot = uni(slot);
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const long m0 = (long)uni((int)tl.by) * GBM, n0 = (long)uni((int)tl.bx) * GBN;
@@ -200,8 +208,13 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
     float* An = lds + (buf ^ 1) * 2 * WTILE;
     float* Bn = An + WTILE;
     if (want_rowsum && !(OBJ_ABL & 8)) { // thread -> row tid % 128, 16 of the 32 k
+      float s16 = 0.f;                   // (rsum keeps its own chain of additions: the bias gradients stay bit-equal)
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) rsum += As[roff + kk * GLDR];
+      for (int kk = 0; kk < 16; ++kk) { const float x = As[roff + kk * GLDR]; rsum += x; s16 += x; }
+      if (pr.segsum) {                   // uniform
+        const long seg = ((kbeg + (klen - krem)) >> 4) + (tid >> 7);
+        if (seg < nseg16 && m0 + (tid & 127) < pr.M) gstore(pr.segsum + seg * pr.seg_ld + m0 + (tid & 127), s16);
+      }
     }
     // MFMA step (s4, s) of lane half h contracts k = 16 h + 4 s4 + s; the fragments of group s4 + 1 are read before the 16
     // MFMAs of group s4 issue
@@ -510,8 +523,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
   long kend = kbeg + L * GBK;
   if (kend > P) kend = P;
   float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
-  if constexpr (TAIL) wgrad_tail_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);      // an empty slice writes zeros
-  else wgrad_full_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid);
+  if constexpr (TAIL) wgrad_tail_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid, P);      // an empty slice writes zeros
+  else wgrad_full_piece(a.prod[tl.prod], tl, kbeg, kend, slot, lds, tid, P);
 }
 
 // Adds a tile's slices to dW in ascending slice order (= ascending points): every bit of the result is reproducible.
@@ -652,14 +665,16 @@ static int wgrad_pick_slices(long P, int nbig, int nfull) {
   return (int)best;
 }
 
-void WgradBatch::add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db) {
+void WgradBatch::add(const float* dY, long lddy, const float* X, long ldx, int out, int in, float* dW, long ldw, float* db,
+                     float* segsum, long seg_ld) {
   if (a.nprod >= kWgradMaxProducts) { overflow = true; return; }
   // 256 x 256 tiles (wgrad_big_kernel) for the products with exactly two row tiles and at least two full column tiles:
   // OBJNERF_WGRAD_BIG=0 keeps every full tile in the 128 x 128 kernel (developer A/B switch)
   static const bool big_on = [] { const char* e = getenv("OBJNERF_WGRAD_BIG"); return !e || atoi(e) != 0; }();
   const bool big = big_on && out == 2 * GBM && in >= 2 * GBN;
+  if (segsum && (big || !db)) { overflow = true; return; }     // segment sums ride on the rowsum tile of the 128 x 128 kernels
   const int pi = a.nprod++;
-  a.prod[pi] = WgProduct{dY, lddy, X, ldx, dW, ldw, db, out, in};
+  a.prod[pi] = WgProduct{dY, lddy, X, ldx, dW, ldw, db, out, in, segsum, seg_ld};
   const int ny = (out + GBM - 1) / GBM, nx = (in + GBN - 1) / GBN;
   for (int by = 0; by < ny; ++by)
     for (int bx = 0; bx < nx; ++bx) {
@@ -681,7 +696,9 @@ void WgradBatch::add_head(const float* dY, int no, const float* X, long ldx, int
   if (h.nheads >= kMaxHeads || no > 3 || ni > 256) { overflow = true; return; }
   h.h[h.nheads++] = HeadItem{dY, X, dW, db, ldx, ldw, no, ni};
 }
-int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
+// slices: 0 = the pass's own choice (wgrad_pick_slices); > 0: that many k slices per tile (the caller has sized the slot area for
+// ntile * slices slots) -- the small per-ray pass of train.hip, whose few tiles need many short slices to fill the device
+int WgradBatch::launch(long P, float* scratch, hipStream_t s, int slices) {
   if (overflow) return set_error(-3, "wgrad: work list overflow");
   if (a.ntile > kWgradSlotTiles) return set_error(-3, "wgrad: more output tiles than the scratch is sized for (kWgradSlotTiles)");
   if (P <= 0) return 0;
@@ -690,7 +707,8 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s) {
   if (a.ntile > 0) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
-    const int nz = a.nz = wgrad_pick_slices(P, a.nbig / 4, a.nfull - a.nbig);
+    const long KTl = (P + GBK - 1) / GBK;
+    const int nz = a.nz = slices > 0 ? (int)(slices < KTl ? slices : KTl) : wgrad_pick_slices(P, a.nbig / 4, a.nfull - a.nbig);
     static const int xcd = [] { const char* e = getenv("OBJNERF_WGRAD_XCD"); return e ? atoi(e) : 0; }();
     static const int prio = [] { const char* e = getenv("OBJNERF_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
     a.xcd = (xcd & 1) | ((prio & 3) << 1);

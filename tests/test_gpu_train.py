@@ -693,3 +693,52 @@ def test_code_table_gradient_matches_nn_embedding():
     with torch.no_grad():
         o2 = lib_({"instance_ids": ids_d})["embedding_instance"]
     assert o2.grad_fn is None and torch.equal(o2, out.detach())
+
+
+def test_per_ray_terms_match_the_per_point_contraction(monkeypatch):
+    """The weight columns that meet the direction embedding (dir_encoding / inst_dir_encoding: 27 columns) or the object code
+    (instance_encoding_1 / _3: 64 columns), and the gradient w.r.t. the code, contracted over 16-point segment sums (round 5:
+    objnerf_train_args.emb_dir_ray, csrc/wgrad.h segsum) against the same products over every sample point
+    (OBJNERF_TRAIN_PER_RAY=0): the same sums in another association -- every parameter gradient of both models, the code table's
+    and the voxel table's within 2e-5 relative L2; all OTHER weight columns and the biases bit-equal (their kernels do not change)."""
+    sc = cases.scene_for(A, "voxel", device=DEV)
+    n = 512
+    rays = H.test_rays(n, w=256, h=192, stride=23).to(DEV)
+    ids = synth.per_ray_ids(n, seed=5).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    rd = dict(perturb_rand=torch.rand(n, 64, generator=g).to(DEV), u_rand=torch.rand(n, 64, generator=g).to(DEV),
+              noise=[torch.randn(n, s, generator=g).to(DEV) for s in (64, 64, 128, 128)])
+    mods = (sc.models["coarse"], sc.models["fine"])
+
+    def grads():
+        for m in mods + (sc.code_library, sc.embeddings["xyz"]):
+            m.zero_grad()
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        res = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                            embedding_instance=codes, frustum_bound_th=0.025, _randoms=rd)
+        _loss(res).backward()
+        torch.cuda.synchronize()
+        out = {"%d.%s" % (i, k): p.grad.clone() for i, m in enumerate(mods) for k, p in m.named_parameters()}
+        out["codes"] = sc.code_library.embedding_instance.weight.grad.clone()
+        out["table"] = sc.embeddings["xyz"].embedding_space_ftr.weight.grad.clone()
+        return out
+    monkeypatch.delenv("OBJNERF_TRAIN_PER_RAY", raising=False)
+    a = grads()
+    monkeypatch.setenv("OBJNERF_TRAIN_PER_RAY", "0")
+    b = grads()
+    monkeypatch.delenv("OBJNERF_TRAIN_PER_RAY", raising=False)
+    cols = {"dir_encoding.0.weight": slice(256, 283), "inst_dir_encoding.0.weight": slice(128, 155),
+            "instance_encoding_1.0.weight": slice(375, 439), "instance_encoding_3.0.weight": slice(375, 439)}
+    changed = 0
+    for k in a:
+        assert rel_l2(a[k], b[k]) < 2e-5, (k, rel_l2(a[k], b[k]))
+        name = k.split(".", 1)[1] if k[0].isdigit() else k
+        if name in cols:
+            keep = torch.ones(a[k].shape[1], dtype=torch.bool)
+            keep[cols[name]] = False
+            assert torch.equal(a[k][:, keep], b[k][:, keep]), k
+            assert rel_l2(a[k][:, cols[name]], b[k][:, cols[name]]) < 2e-5, k
+            changed += int(not torch.equal(a[k][:, cols[name]], b[k][:, cols[name]]))
+        elif k not in ("codes", "table"):
+            assert torch.equal(a[k], b[k]), k
+    assert changed > 0, "the per-ray form was not selected"
