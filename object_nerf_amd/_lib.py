@@ -99,7 +99,7 @@ class TrainArgs(C.Structure):
         ("codes", C.c_void_p), ("code_stride", C.c_int64),
         ("grid", VoxelGrid),
         ("scatter_xyz", C.c_void_p), ("scatter_table_grad", C.c_void_p),
-        ("emb_dir_ray", C.c_void_p),
+        ("emb_dir_ray", C.c_void_p), ("ray_bias_ws", C.c_void_p),
     ]
 
 

@@ -65,7 +65,7 @@ def _composite_args(meta, ps, outs=None):
     return a
 
 
-def _train_args(meta, ps, params, packed=None, rays=None, codes=None):
+def _train_args(meta, ps, params, packed=None, rays=None, codes=None, ray_bias_ws=None):
     a = _lib.TrainArgs()
     if packed is not None:
         blob, aux, blob_bwd = packed
@@ -81,6 +81,8 @@ def _train_args(meta, ps, params, packed=None, rays=None, codes=None):
                 a.codes, a.code_stride = codes.data_ptr(), codes.stride(0)
             if meta["use_voxel"]:
                 a.grid = meta["grid"]
+            if ray_bias_ws is not None:
+                a.ray_bias_ws = ray_bias_ws.data_ptr()
     a.use_voxel, a.do_object = int(meta["use_voxel"]), int(meta["forward_instance"])
     a.n_points = ps.emb_xyz.shape[0]
     table = _ptr_table(params)
@@ -146,7 +148,9 @@ class RenderRaysFn(torch.autograd.Function):
             ps.isig, ps.irgb = (_empty(P, dev=dev), _empty(P, 3, dev=dev)) if fi else (None, None)
             ps.ws = _empty(l.objnerf_train_workspace_floats(int(fi), P), dev=dev)
             ps.noise, ps.noise_i = noise, noise_i
-            a, keep = _train_args(meta, ps, pp, packed, rays_c, codes_c if fi else None)
+            # scratch of the hoisted per-ray terms (objnerf_train_args.ray_bias_ws): only the fused forward uses it
+            rb = _empty(n, _lib.RAY_BIAS_FLOATS, dev=dev) if (packed is not None and packed[0] is not None) else None
+            a, keep = _train_args(meta, ps, pp, packed, rays_c, codes_c if fi else None, rb)
             _lib.check(l.objnerf_mlp_train_forward(C.byref(a), st), "mlp_train_forward")
             outs = {"weights": _empty(n, Sx, dev=dev), "opacity": _empty(n, dev=dev), "rgb": _empty(n, 3, dev=dev),
                     "depth": _empty(n, dev=dev)}

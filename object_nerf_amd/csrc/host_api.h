@@ -15,6 +15,7 @@ int check_launch(const char* what);
 int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr,
                      unsigned* mask_ws = nullptr);
 int launch_mlp_fused_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s);                // ray_bias
+int launch_mlp_fused_save_hoist(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws, unsigned* mask_ws);   // ray_bias, training
 int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws = nullptr,
                       unsigned* mask_ws = nullptr);
 // training: fused dgrad chain through the hidden layers (mlp_bwd.hip); act / dz in the workspace layout of train.hip

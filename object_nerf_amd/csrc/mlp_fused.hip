@@ -24,6 +24,7 @@ static void launch_save(const objnerf_mlp_args& a, long ntiles, unsigned grid, h
 
 int launch_mlp_fused(const objnerf_mlp_args& a, long ntiles, unsigned grid, hipStream_t s, float* save_ws, unsigned* mask_ws) {
   if (a.ray_bias && !save_ws) return launch_mlp_fused_hoist(a, ntiles, grid, s);      // (incl. the hoisted object density query)
+  if (a.ray_bias && save_ws) return launch_mlp_fused_save_hoist(a, ntiles, grid, s, save_ws, mask_ws);
   const bool sc = a.do_scene != 0, ob = a.do_object != 0;
 #ifdef OBJ_TUNE_ONLY_MAIN
   if (save_ws) return set_error(-9, "tuning build: training kernels are not compiled");

@@ -1007,7 +1007,8 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
                                                      unsigned* const mask_ws = nullptr) {
   // (with SIGMA_ONLY: the object-branch density query, whose ONE code is constant over all points -- its share of
   // instance_encoding_1 / _3 arrives as a single vector at ray_bias, every point reads "ray" 0)
-  static_assert(!HOIST || (FUSED && !SAVE && (!SIGMA_ONLY || (DO_OBJ && !DO_SCENE))), "hoisting: inference form of the fused kernel");
+  // (SAVE + HOIST, round 5: the training forward hoists as well -- the saved activations and masks are those of the same layers)
+  static_assert(!HOIST || (FUSED && (!SIGMA_ONLY || (DO_OBJ && !DO_SCENE))), "hoisting: the fused kernel");
   constexpr int kCB = kChunkBytes;       // bytes per weight chunk
   static_assert(!SIGMA_ONLY || (DO_SCENE != DO_OBJ), "sigma-only: one branch per launch (contiguous stream window)");
   static_assert(!SAVE || !SIGMA_ONLY, "the training forward needs every layer");

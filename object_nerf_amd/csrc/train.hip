@@ -263,6 +263,14 @@ int objnerf_mlp_train_forward(const objnerf_train_args* a, void* stream) {
       m.codes = a->codes; m.code_stride = a->code_stride; m.grid = a->grid;
       m.emb_xyz = nullptr; m.emb_dir = nullptr; m.obj_voxel = nullptr; m.obj_code = nullptr;
       m.do_scene = 1; m.do_object = a->do_object ? 1 : 0;
+      // ray_bias_ws: the terms that are constant along a ray arrive per ray (objnerf_ray_bias; the compact weight columns it
+      // reads sit behind the aux block: objnerf_pack_weights of the SAME parameter values) and their k-steps are skipped,
+      // exactly as in the inference passes (objnerf_mlp_args.ray_bias)
+      if (a->ray_bias_ws && [] { const char* e = getenv("OBJNERF_HOIST"); return !e || atoi(e) != 0; }()) {
+        const int rc = objnerf_ray_bias(&m, a->ray_bias_ws, stream);
+        if (rc) return rc;
+        m.ray_bias = a->ray_bias_ws;
+      }
       return launch_mlp_fused(m, ntiles, grid, (hipStream_t)stream, a->workspace, mask_ws);
     }
     m.do_scene = 1; m.do_object = 0;
