@@ -14,7 +14,7 @@ region.  `--config` selects the BASELINE.json configuration (index into its `con
                                                                            all-gathered -- the N = 1, 2, 4, 8 lines are
                                                                            one workload
   2  ScanNet-0113-multi frame, 5 object codes (per ray), 64 + 128, frustum bound 0.025, rays_in_bbox
-  3  configs[2]'s frame cut into contiguous ray bands over the N ranks + ONE RCCL all-gather of the rendered pixels
+  3  configs[2]'s frame cut into contiguous ray bands over the N ranks + ONE all-gather (RCCL) of the rendered pixels
      (rgb, depth, opacity packed in one message): strong scaling.  Every default N > 1 line also carries this frame as
      `strong_scaling` -- its time on the N ranks next to the time rank 0 needs for the SAME frame alone in the same run
   4  the editing demo (duplicating + moving): ray sets [background, object 4, object 4'] generated on the device,
@@ -195,8 +195,8 @@ CONFIG_TEXT = {
     1: "BASELINE configs[1]: ToyDesk-2 %dx%d frame, scene+object branches, %d coarse + %d fine, voxel embedding, eval mode",
     2: "BASELINE configs[2]: ScanNet-0113-multi %dx%d frame, 5 object codes (per ray), %d coarse + %d fine, frustum bound "
        "0.025, rays_in_bbox, voxel embedding, eval mode",
-    3: "BASELINE configs[3]: configs[2]'s %dx%d frame (5 codes, %d + %d), ray bands sharded over the ranks + one RCCL "
-       "all-gather of rgb/depth/opacity",
+    3: "BASELINE configs[3]: configs[2]'s %dx%d frame (5 codes, %d + %d), ray bands sharded over the ranks + one "
+       "all-gather of rgb/depth/opacity (backend: see `collective`)",
     4: "BASELINE configs[4]: demo_editable_render duplicating+moving, %dx%d, ray sets [background, object 4, object 4'] "
        "generated on the device, render_rays_multi %d + %d, removed-object box, pixel bands sharded over the ranks",
 }
@@ -456,7 +456,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
     # ---- the reference's training step on the differentiable HIP path (row f1), reported beside the headline ----
     train = None
     if on_gpu and args.train_steps > 0 and args.as_rank is None:
-        train = train_step_leg(args, dev, rank, world, dist, fence, allreduce)
+        train = train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend)
 
     res = None
     if rank == 0:
@@ -603,7 +603,7 @@ def strong_scaling_leg(args, R, rank, world, dist, fence, allreduce, allgather_l
             "frame_bit_equal_to_anchor": bits_n == bits_1, "collective": backend_name(backend)}
 
 
-def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
+def train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend="nccl", n_rays=2048):
     """The reference's training step (train.py:147-180, config/default_conf.yml: 2048 rays per batch, 64 coarse + 64 fine,
     perturb = 1, noise_std = 1, scene + object branches, occlusion mask, voxel embedding) through the differentiable HIP
     render_rays: forward, backward, gradient exchange (N > 1: broadcast_parameters once, GradientSync per step), Adam.
@@ -632,7 +632,9 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
         zeros = torch.zeros(n_rays, device=dev)
         mse = torch.nn.functional.mse_loss
 
-        def step():
+        sync_marks = []                             # (before, after) events around the gradient exchange, when asked for
+
+        def step(mark_sync=False):
             idx = torch.randint(0, rays_all.shape[0], (n_rays,), device=dev, generator=g)
             rays = rays_all[idx].contiguous()
             opt.zero_grad(set_to_none=True)
@@ -644,7 +646,14 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
             loss = sum(mse(r["rgb_%s" % t], target) + mse(r["rgb_instance_%s" % t], target)
                        + 0.1 * mse(r["depth_%s" % t], zeros) + mse(r["opacity_instance_%s" % t], zeros) for t in ("coarse", "fine"))
             loss.backward()
-            sync.sync()
+            if mark_sync:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sync.sync()
+                e1.record()
+                sync_marks.append((e0, e1))
+            else:
+                sync.sync()
             opt.step()
             return loss
         l0 = step().item()
@@ -676,9 +685,10 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
             lib.objnerf_train_timing_enable(1)
             tp = time.perf_counter()
             for _ in range(n_ph):
-                step()
+                step(mark_sync=True)
             torch.cuda.synchronize()
             wall = (time.perf_counter() - tp) / n_ph * 1e3
+            exchange_ms = sum(a.elapsed_time(b) for a, b in sync_marks) / max(1, len(sync_marks))
             ms = (C.c_double * 5)()
             cnt = (C.c_int64 * 5)()
             lib.objnerf_train_timing_read(ms, cnt)
@@ -686,7 +696,7 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
             names = ("forward", "dgrad", "dx", "scatter", "wgrad")
             phases = {k: ms[i] / n_ph for i, k in enumerate(names)}
             phases["other"] = wall - sum(phases.values())
-            phases = {"ms": phases, "steps": n_ph, "step_ms_with_marks": wall,
+            phases = {"ms": phases, "steps": n_ph, "step_ms_with_marks": wall, "gradient_exchange_ms": exchange_ms,
                       "spans_per_step": {k: cnt[i] / n_ph for i, k in enumerate(names)},
                       "note": "HIP events on the launch stream at the phase boundaries inside objnerf_mlp_train_forward / _backward, "
                               "both passes (coarse + fine) of a step summed; other = step - sum"}
@@ -704,7 +714,11 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, n_rays=2048):
                              "frac": tflops / (PEAK_FP32_MFMA_TFLOPS * world),
                              "flop_convention": "3 x forward GEMM FLOP (forward + dgrad + wgrad) per evaluated sample point, whole "
                                                 "step incl. sampling, compositing, gradient exchange and Adam"},
-                "gradient_exchange": ("GradientSync: %d flat all-reduce(s) of %s bytes" % (len(sync.buckets), sync.message_bytes()))
+                "gradient_exchange": ("GradientSync: %d flat all-reduce(s) of %s bytes over %s, %.3f ms per step on the compute stream "
+                                      "(events around sync(): packing, the all-reduces, un-packing; inside the step, not overlapped -- the "
+                                      "differentiable render_rays is one autograd node, its gradients appear together)"
+                                      % (len(sync.buckets), sync.message_bytes(), backend_name(backend),
+                                         (phases or {}).get("gradient_exchange_ms", float("nan"))))
                                      if (dist is not None and world > 1) else "none (1 rank)",
                 "optimizer": "torch.optim.Adam(lr=1e-3, %s)" % ("fused=True" if fused else "foreach"),
                 "loss_first": l0, "loss_last": l1}

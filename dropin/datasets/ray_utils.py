@@ -41,19 +41,27 @@ class HostDirections(torch.Tensor):
     def wrap(t, H, W, focal):
         d = torch.Tensor._make_subclass(HostDirections, t)
         d._hwf = (int(H), int(W), float(focal))
+        d._version_at_wrap = t._version          # an in-place edit of the host grid afterwards must travel with it (real copy)
         return d
+
+    def _pristine(self):
+        return self._version == getattr(self, "_version_at_wrap", -1)
 
     def _device_grid(self, device):
         H, W, focal = self._hwf
         return _hip.get_ray_directions(H, W, focal, device=device)
 
     def cuda(self, device=None, non_blocking=False, **kw):
+        if kw or not self._pristine():           # memory_format etc., or an edited grid: torch's own copy
+            return torch.Tensor.cuda(self.as_subclass(torch.Tensor), device, non_blocking, **kw)
         return self._device_grid("cuda" if device is None else (torch.device("cuda", device) if isinstance(device, int) else device))
 
     def to(self, *args, **kwargs):
         dev = kwargs.get("device", args[0] if args and isinstance(args[0], (str, torch.device, int)) else None)
         dtype = kwargs.get("dtype", next((a for a in args if isinstance(a, torch.dtype)), None))
-        if dev is not None and torch.device(dev).type == "cuda" and dtype in (None, torch.float32):
+        plain = not (set(kwargs) - {"device", "dtype", "non_blocking"}) and not any(isinstance(a, (bool, torch.memory_format)) for a in args)
+        if (dev is not None and torch.device(dev).type == "cuda" and dtype in (None, torch.float32) and plain and self._pristine()
+                and not kwargs.get("copy", False)):
             return self._device_grid(torch.device(dev))
         return torch.Tensor.to(self.as_subclass(torch.Tensor), *args, **kwargs)
 

@@ -49,10 +49,12 @@ class Embedding(nn.Module):
         xf = _lib.as_f32(x).reshape(-1, c)
         out = torch.empty(xf.shape[0], c * (2 * self.N_freqs + 1), dtype=torch.float32, device=x.device)
         bands = None
-        if not self.logscale:        # the bands travel as a device table; 2^k bands are generated in the kernel
-            if self._bands_dev is None or self._bands_dev.device != x.device:
-                self._bands_dev = self.freq_bands.to(torch.float32).to(x.device).contiguous()
-            bands = self._bands_dev
+        # (modules pickled whole before `logscale` / `_bands_dev` existed have neither attribute: they are 2^k modules)
+        if not getattr(self, "logscale", True):        # the bands travel as a device table; 2^k bands are generated in the kernel
+            cached = getattr(self, "_bands_dev", None)
+            if cached is None or cached.device != x.device:
+                cached = self._bands_dev = self.freq_bands.to(torch.float32).to(x.device).contiguous()
+            bands = cached
         _lib.check(_lib.lib().objnerf_pos_encode_freqs(_lib.ptr(xf), xf.shape[0], c, self.N_freqs, _lib.ptr(bands), _lib.ptr(out),
                                                        _lib.stream_ptr()), "pos_encode")
         return out.reshape(*shp[:-1], out.shape[-1])

@@ -130,6 +130,27 @@ def eval_points(model, embeddings, rays, z, codes, scene, obj):
     return v(sg), v(c, 3), v(isg), v(ic, 3)
 
 
+def eval_points_slabbed(model, embeddings, rays, z, codes, scene, obj):
+    """eval_points over ray slabs of RAY_CHUNK_POINTS sample points: the transient embeddings, repeated direction / code rows and
+    the MLP workspace (~3.5 W + in_xyz + in_obj floats per point) are bounded by the slab, not by the batch -- the editor's
+    32k-ray chunks x (64 + 64) samples would otherwise hold ~23 GB per ray set at W = 256, more for wider models."""
+    n, S = z.shape
+    step = max(1, RAY_CHUNK_POINTS // max(S, 1))
+    if n <= step:
+        return eval_points(model, embeddings, rays, z, codes, scene, obj)
+    dev = z.device
+    new = lambda *sh: torch.empty(n, S, *sh, dtype=torch.float32, device=dev)      # noqa: E731
+    sg, c = (new(), new(3)) if scene else (None, None)
+    isg, ic = (new(), new(3)) if obj else (None, None)
+    for lo in range(0, n, step):
+        hi = min(lo + step, n)
+        parts = eval_points(model, embeddings, rays[lo:hi], z[lo:hi], codes[lo:hi].contiguous() if codes is not None else None, scene, obj)
+        for dst, src in zip((sg, c, isg, ic), parts):
+            if dst is not None:
+                dst[lo:hi].copy_(src)
+    return sg, c, isg, ic
+
+
 def _composite(z, sg, c, isg, ic, flags, noise, noise_inst, ptm, out):
     n, S = z.shape
     ca = _lib.CompositeArgs()
@@ -215,7 +236,7 @@ def render_rays_multi(models, embeddings, table, rays_c, clips, ids, S, I, use_d
         sgs, cs = [], []
         for k in range(K):
             code = table[ids[k]].reshape(1, -1).expand(n, -1).contiguous() if ids[k] > 0 else None
-            sg, c, isg, ic = eval_points(model, embeddings, rays_c[k], zs[k], code, ids[k] == 0, ids[k] > 0)
+            sg, c, isg, ic = eval_points_slabbed(model, embeddings, rays_c[k], zs[k], code, ids[k] == 0, ids[k] > 0)
             sg, c = (sg, c) if ids[k] == 0 else (isg, ic)
             sg, c = sg.contiguous(), c.contiguous()
             use_boxes = ids[k] == 0 and boxes is not None and boxes.shape[0] > 0

@@ -61,6 +61,17 @@ if os.path.isdir(ref):
     try:
         assert d.to('cuda:0') == 'device grid' and d.to(device='cuda') == 'device grid'
         assert seen == [(6, 8, 7.0, 'cuda:0'), (6, 8, 7.0, 'cuda')]
+        # an in-place edit of the host grid, or copy / memory_format arguments, must take torch's real copy (round 5, ADVICE r4):
+        # the regenerated grid would silently drop the edit (no GPU here: the real copy raises, the regenerating path would not)
+        d2 = RU.get_ray_directions(6, 8, 7.0)
+        d2.mul_(2.0)
+        for call in (lambda: d2.to('cuda:0'), lambda: d2.cuda(), lambda: d.to('cuda', copy=True)):
+            try:
+                r = call()
+            except (RuntimeError, AssertionError):
+                r = None                 # torch tried to copy to a GPU this box does not have
+            assert not isinstance(r, str)
+        assert seen == [(6, 8, 7.0, 'cuda:0'), (6, 8, 7.0, 'cuda')]
     finally:
         HIPRU.get_ray_directions = real
     from object_nerf_amd import synth

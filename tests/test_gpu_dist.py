@@ -131,6 +131,32 @@ def test_default_two_rank_line_on_one_gpu():
     assert ts["n_gpus"] == 2 and "all-reduce" in ts["gradient_exchange"] and ts["loss_last"] < ts["loss_first"]
 
 
+def test_default_eight_rank_line_on_one_gpu():
+    """the exact command of the driver's 8-GPU run -- `bench.py --gpus 8` (self-launched ranks, configs[1] weak scaling, the
+    configs[3] frame with its same-run anchor, the data-parallel training step with broadcast_parameters + GradientSync) -- with
+    all eight ranks on this box's one GPU: no rank runs out of memory, the JSON object is the LAST line on stdout (rendezvous
+    banners come before it), the sharded frame is bit-equal to its anchor, the exchange is timed"""
+    small = [a for a in SMALL]
+    small[small.index("--train-steps") + 1] = "8"
+    small[small.index("--steps") + 1] = "2"
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small + ["--gpus", "8", "--one-gpu"], env=e,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    r = json.loads(lines[-1])                               # the LAST non-empty stdout line parses
+    assert sum(ln.startswith("{") for ln in lines) == 1
+    assert r["n_gpus"] == 8 and r["config"]["baseline_config_index"] == 1 and r["scaling"] == "weak"
+    assert r["config"]["frames_per_step"] == 8 and len(r["multi_gpu"]["per_rank_render_ms"]) == 8
+    ss = r["strong_scaling"]
+    assert ss["n_gpus"] == 8 and ss["frame_bit_equal_to_anchor"] is True and ss["collective"] == "gloo"
+    assert "RCCL" not in ss["workload"]
+    ts = r["train_step"]
+    assert "error" not in ts, ts
+    assert ts["n_gpus"] == 8 and ts["loss_last"] < ts["loss_first"]
+    assert ts["phases_ms"]["gradient_exchange_ms"] > 0 and "all-reduce" in ts["gradient_exchange"]
+
+
 def test_gradient_sync_over_rccl_world1():
     """the collective path of data-parallel training on the GPU: flat buckets, asynchronous all-reduces over RCCL, the voxel
     table exchanged as its active-row prefix; with one rank the mean over ranks is the identity"""
