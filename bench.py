@@ -852,9 +852,11 @@ def cpu_baseline(wl, n_sample):
     ref = o_cpu[key]
     g_cpu = g_cpu[:m]
     psnr = psnr_of(g_cpu, ref)
-    # "PSNR within 0.1 dB of the reference" (BASELINE north_star; utils/metrics.py:5-15): there are no ground-truth
-    # images here, so both renders are scored against one synthetic target T = reference render + N(0, 0.05) noise
-    tgt = (ref + 0.05 * torch.randn(ref.shape, generator=torch.Generator().manual_seed(7))).clamp(0, 1)
+    # "PSNR within 0.1 dB of the reference" (BASELINE north_star; utils/metrics.py:5-15): there are no ground-truth images
+    # here, so both renders are scored against one synthetic target that is INDEPENDENT of either (uniform random pixels, as
+    # tests/helpers.py::frame_report; until round 4 the target was the reference render + noise, against which the difference is
+    # insensitive by construction)
+    tgt = torch.rand(ref.shape, generator=torch.Generator().manual_seed(3))
     delta = abs(psnr_of(g_cpu, tgt) - psnr_of(ref, tgt))
     base = {"value": evals_of(m) / med, "unit": "ray-samples/s", "cores": ncpu, "cores_available": avail, "kind": "port",
             "sample": "%d-ray slab (BASELINE.md §3 asks for 4096%s), rays evenly spread over the frame, same "

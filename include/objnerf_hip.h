@@ -145,7 +145,7 @@ typedef struct {
   float* comp_rec;
   float comp_last_delta;
   int32_t comp_inst_weights;
-  /* fused form, optional (either arithmetic mode): (n_rays, OBJNERF_RAY_BIAS_FLOATS) vectors written by objnerf_ray_bias for
+  /* fused form, optional: (n_rays, OBJNERF_RAY_BIAS_FLOATS) vectors written by objnerf_ray_bias for
    * the SAME blob / aux / rays / codes.  The parts of four layers' pre-activations that are constant along a ray -- the
    * object code's share of instance_encoding_1 / _3 and the direction embedding's share of dir_encoding /
    * inst_dir_encoding: the reference repeats both over the samples (rendering.py:89-94) -- are then taken from there

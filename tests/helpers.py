@@ -187,7 +187,7 @@ def frame_report(case, out, g):
                 dpsnr=abs(psnr(out["rgb_fine"], target) - psnr(g["rgb_fine"], target)))
 
 
-FLOOR_FACTOR = 3.0      # end-to-end fine-pass tolerance in units of the reference's own fp32-vs-fp64 distance: BOTH arithmetic modes
+FLOOR_FACTOR = 3.0      # end-to-end fine-pass tolerance in units of the reference's own fp32-vs-fp64 distance
 
 
 def oracle_multi_f64(sc, sets, obj_ids, boxes=None, randoms=None, arch=None, **kw):

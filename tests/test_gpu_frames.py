@@ -3,7 +3,7 @@ weights, camera, code assignment as bench.py) rendered through the drop-in API, 
 reference (tests/golden/frame_*.npz, oracle/make_golden.py::frames).  utils/metrics.py:5-15 defines PSNR as a mean over a
 frame, so this -- not the 48-ray cases of test_gpu_render.py -- is where the BASELINE's "PSNR within 0.1 dB" is graded.
 
-Per case, in BOTH arithmetic modes with the same numbers:
+Per case:
   * PSNR(ours, reference) of rgb_fine over the frame >= 60 dB;
   * |PSNR(ours, T) - PSNR(reference, T)| <= 0.1 dB against a fixed synthetic target T;
   * every pixel map (rgb / depth / opacity + the three instance maps, both passes): max-norm distance from the reference's
@@ -51,7 +51,7 @@ def test_full_size_frame_matches_the_reference_frame():
     """BASELINE configs[1] at its OWN size: the 640x480 ToyDesk-2 frame bench.py times (same scene, weights, camera, code)
     against the same 307,200 pixels rendered by the real reference (tests/golden/full_frame_toydesk2.npz: rgb_fine as
     uint16 / 65535 -- quantisation 107 dB --, depth_fine of every 16th pixel in fp32).  "PSNR within 0.1 dB of the
-    reference" (BASELINE north_star; utils/metrics.py:5-15), literally, at 640x480, in both arithmetic modes."""
+    reference" (BASELINE north_star; utils/metrics.py:5-15), literally, at 640x480."""
     g = cases.load_golden("full_frame_toydesk2")
     rays, ids, kw, sname = cases.full_frame_inputs()
     sc = scene(sname)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Parity table of the HIP path against the committed reference outputs (tests/golden/, produced by the real reference
-through oracle/make_golden.py): per render case x result key, in both arithmetic modes of the fused MLP kernel,
+through oracle/make_golden.py): per render case x result key,
 
     err        max-norm error vs the reference      max|a - b| / max|b|
     floor      the same distance between the reference's fp32 result and the oracle run in float64 on the same inputs
