@@ -529,8 +529,8 @@ int objnerf_voxel_embed_backward(const objnerf_voxel_grid* grid, const float* xy
 /* out[r, c] += sum_{s < S} x[r*S + s, c]   (gradient of the `repeat` of per-ray codes, rendering.py:94) */
 int objnerf_sum_over_samples(const float* x, int64_t n_rays, int S, int C, float* out, void* stream);
 /* Backward of the row gather CodeLibrary.forward does (models/code_library.py:20-28: nn.Embedding on `instance_ids`):
- * table_grad (n_table_rows, C) += the rows d_rows (n, C) that picked each table row, added in ascending order of i
- * (bit-reproducible, no atomics).  ids: int64 (n), values outside [0, n_table_rows) are ignored.  C <= 1024. */
+* table_grad (n_table_rows, C) += the rows d_rows (n, C) that picked each table row, added in a fixed order (blocks of 128 ids dealt
+ * to 16 waves, ascending inside a wave, the waves' sums in wave order: bit-reproducible, no atomics).  ids: int64 (n), values outside [0, n_table_rows) are ignored.  C <= 1024. */
 int objnerf_rows_gather_backward(const float* d_rows, const int64_t* ids, int64_t n, int C, int64_t n_table_rows, float* table_grad,
                                  void* stream);
 

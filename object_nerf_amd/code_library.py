@@ -8,7 +8,7 @@ returns `{"embedding_instance": rows}` when the batch carries `instance_ids`, `{
 A 64 x 64 table lookup is index plumbing, not arithmetic: the forward stays a torch gather on the device.  Its gradient on
 the training path (2048 rows scattered back into a 64-row table every step) goes through objnerf_rows_gather_backward: one
 workgroup per table row, fixed summation order (torch's embedding backward runs one 64-thread workgroup: 0.115 ms of a 19 ms
-training step, profiles/r05_train_kernel_stats.md).
+training step).
 """
 import torch
 from torch import nn
