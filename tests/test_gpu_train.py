@@ -60,7 +60,8 @@ def _loss(res, seed=0):
     return tot
 
 
-@pytest.mark.parametrize("case", ["voxel_train", "plain_train", "voxel_eval_flags", "voxel_random", "voxel_ragged", "voxel_reference_batch"])
+@pytest.mark.parametrize("case", ["voxel_train", "plain_train", "voxel_eval_flags", "voxel_random", "voxel_ragged", "voxel_scene_only",
+                                  "voxel_reference_batch"])
 def test_render_rays_gradients_match_oracle_autograd(case):
     cfgs = {
         # 24 x 13 = 312 and 24 x 19 = 456 sample points: neither a multiple of the 32-point k tile of the weight-gradient
@@ -72,6 +73,9 @@ def test_render_rays_gradients_match_oracle_autograd(case):
         "voxel_reference_batch": dict(scene="voxel", kw=dict(is_eval=False, frustum_bound_th=0.025, perturb=1.0, noise_std=1.0),
                                       rnd=True, ptm=True, sizes=(64, 64, 2048)),
         "voxel_train": dict(scene="voxel", kw=dict(is_eval=False, frustum_bound_th=0.025, rays_in_bbox=False), ptm=True),
+        # scene branch only (the per-ray pass then has the direction columns of dir_encoding alone; the object branch's parameters
+        # get exact zeros)
+        "voxel_scene_only": dict(scene="voxel", kw=dict(is_eval=False, forward_instance=False)),
         "plain_train": dict(scene="plain", kw=dict(is_eval=False, frustum_bound_th=-1.0, white_back=True)),
         "voxel_eval_flags": dict(scene="sparse", kw=dict(is_eval=True, use_zero_as_last_delta=True, use_disp=True, rays_in_bbox=True)),
         "voxel_random": dict(scene="voxel", kw=dict(is_eval=False, frustum_bound_th=0.025, perturb=1.0, noise_std=1.0), rnd=True),
@@ -145,7 +149,11 @@ def test_render_rays_gradients_match_oracle_autograd(case):
                 assert p.grad.abs().max().item() == 0, name
                 continue
             errs["%s.%s" % (typ, name)] = rel_l2(p.grad, ref[name].grad)
-    errs["codes"] = rel_l2(sc.code_library.embedding_instance.weight.grad, ctab.grad)
+    cg = sc.code_library.embedding_instance.weight.grad
+    if ctab.grad is None:                     # scene branch only: the codes are not on the path
+        assert cg is None or cg.abs().max().item() == 0
+    else:
+        errs["codes"] = rel_l2(cg, ctab.grad)
     if use_voxel:
         tg = sc.embeddings["xyz"].embedding_space_ftr.weight.grad
         assert tg is not None
