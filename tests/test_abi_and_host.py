@@ -316,3 +316,26 @@ def test_optimizer_steps_invalidate_only_the_models_they_own():
     kc0 = c._pack_key(pc)
     opt_a.step()
     assert c._pack_key(pc) != kc0 and b._pack_key(pb) == kb
+
+
+def test_training_workspace_sizes():
+    """size queries of the training calls (the library never allocates): the activation workspace = 12.6 KB of saved layer outputs
+    per point (2,436 floats scene + 708 object) + the LeakyReLU sign masks the fused forward packs (14 groups x 64 lanes x 16
+    bytes per 32 points, whole 128-point tiles); the backward's scratch = the gradient matrices in the same layout + the partial
+    tiles of the grouped weight-gradient pass + the per-ray terms' area -- monotone in the point count and 16-byte granular"""
+    l = _lib.lib()
+    for P in (1, 127, 128, 129, 4096, 131072, 262144):
+        masks = ((P + 127) // 128) * 4 * 14 * 256
+        assert l.objnerf_train_workspace_floats(1, P) == (2436 + 708) * P + masks
+        assert l.objnerf_train_workspace_floats(0, P) == 2436 * P + masks
+    prev = 0
+    for P in (16, 384, 768, 131072, 262144, 393216):
+        s = l.objnerf_train_scratch_floats(P)
+        assert s > (2436 + 708) * P + ((P + 15) // 16) * (448 + 92) and s % 4 == 0 and s > prev
+        prev = s
+    assert l.objnerf_train_timing_enable(0) == 0
+    ms, cnt = (C.c_double * 5)(), (C.c_int64 * 5)()
+    assert l.objnerf_train_timing_read(ms, cnt) == 0 and list(cnt) == [0] * 5 and list(ms) == [0.0] * 5
+    # the row-gather backward validates before it launches
+    assert l.objnerf_rows_gather_backward(None, None, 4, 64, 64, None, None) < 0 and b"rows_gather_backward" in l.objnerf_last_error()
+    assert l.objnerf_rows_gather_backward(64, 64, 4, 2048, 64, 64, None) < 0
