@@ -4,11 +4,15 @@
 gradient.  One `torch.autograd.Function` covers the whole call; both its forward and its backward are
 sequences of C-ABI kernel launches (include/objnerf_hip.h "training path"):
 
-  forward   coarse depths -> sample points -> voxel / positional embedding (materialised) -> layer-wise
-            MLP forward on the fp32 MFMA GEMM, activations kept -> compositing -> sample_pdf + merge
-            (no gradient, as in the reference: rendering.py:307 detaches) -> fine pass
-  backward  compositing backward -> MLP backward (dgrad / wgrad / bias grads) -> voxel-embedding backward
-            (atomics into the feature table) -> per-ray sum of the object-code gradients
+  forward   coarse depths -> sample points -> voxel / positional embedding (materialised: the weight-gradient products read it) ->
+            fused persistent MLP forward that embeds in registers, hoists the per-ray constant terms, and keeps every layer's
+            output and its LeakyReLU sign mask -> compositing -> sample_pdf + merge (no gradient, as in the reference:
+            rendering.py:307 detaches) -> fine pass
+  backward  compositing backward -> fused dgrad chain (fed by the masks) -> gradients w.r.t. the embeddings -> voxel-table scatter
+            (LDS hash + atomics into the feature table) -> one grouped deterministic weight-gradient pass, which also leaves
+            16-point column sums from which a small second pass forms the terms that are constant along a ray (direction / code
+            weight columns, the code gradient) -> per-ray sum of the code gradients
+  (OBJNERF_TRAIN_LAYERWISE=1: the same step layer by layer on the fp32 MFMA GEMM; non-default architectures: generic.py)
 
 Gradients are produced for every ObjectNeRF parameter (coarse and fine), the voxel feature table and
 `embedding_instance`; none for rays / depths (the reference has none either).  The Python here only
