@@ -167,6 +167,33 @@ static void lin(GCtx& c, const float* X, long ldx, const float* W, long ldw, lon
   GemmArgs g{X, ldx, 1, W, ldw, 1, Y, ldy, P, out, in, accumulate, epi, bias, 1, nullptr};
   c.rc = gemm_launch(g, c.s);
 }
+// y = act(cat(x_0 .. x_{n-1}) * W^T + b): the column blocks of a torch.cat input as ONE segmented contraction (gemm.h: up to four
+// segments, each with its own operand pointers) instead of one accumulating launch per block -- no read-modify-write passes over
+// y, and the 27- / 64- / 104-column blocks ride inside a kernel that is already running instead of costing a launch and two trips
+// of y through memory each (round 5: the layer-wise path was 28 launches per MLP call, 8 of them such accumulations).
+// OBJNERF_GENERIC_CAT=launches restores the per-block launches (developer A/B switch).
+struct CatBlk { const float* x; long ldx; int c; const float* W; };          // W: first weight column of the block (row stride ldw)
+static void lin_cat(GCtx& c, const CatBlk* blk, int nblk_, long ldw, long P, int out, float* Y, long ldy, int epi, const float* bias) {
+  if (c.rc || nblk_ <= 0) return;
+  static const bool per_block = [] { const char* e = getenv("OBJNERF_GENERIC_CAT"); return e && !strcmp(e, "launches"); }();
+  if (per_block || nblk_ > 4) {
+    for (int i = 0; i < nblk_; ++i) {
+      const bool last = i == nblk_ - 1;
+      lin(c, blk[i].x, blk[i].ldx, blk[i].W, ldw, P, out, blk[i].c, Y, ldy, i == 0 ? 0 : 1, last ? epi : EPI_NONE, last ? bias : nullptr);
+    }
+    return;
+  }
+  GemmArgs g{blk[0].x, blk[0].ldx, 1, blk[0].W, ldw, 1, Y, ldy, P, out, blk[0].c, 0, epi, bias, 1, nullptr};
+  if (nblk_ > 1) {
+    g.nseg = nblk_;
+    for (int i = 0; i < nblk_; ++i) {
+      g.segA[i] = blk[i].x; g.seglda[i] = blk[i].ldx;
+      g.segB[i] = blk[i].W; g.segldb[i] = ldw;
+      g.segK[i] = blk[i].c;
+    }
+  }
+  c.rc = gemm_launch(g, c.s);
+}
 static bool has(const int32_t* list, int n, int v) {
   for (int i = 0; i < n; ++i) if (list[i] == v) return true;
   return false;
@@ -253,37 +280,31 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
   auto branch = [&](const float* const* q, int D, int W, const int32_t* skips, int nsk, const Blk* in, int nin, float* sig, float* rgb) {
     int cin = 0;
     for (int i = 0; i < nin; ++i) cin += in[i].c;
-    // y (+)= cat(in) * W[:, col0 : col0 + cin]^T, epilogue on the last block unless more follows
-    auto input_blocks = [&](const float* Wm, long ldw, int col0, float* y, int acc_first, int epi_last, const float* bias) {
-      int col = col0;
-      for (int i = 0; i < nin; ++i) {
-        const bool last = i == nin - 1;
-        lin(c, in[i].x, in[i].c, Wm + col, ldw, P, W, in[i].c, y, W, (i == 0 ? acc_first : 1), last ? epi_last : EPI_NONE, last ? bias : nullptr);
-        col += in[i].c;
-      }
+    // y = act(cat([hidden,] in) * W^T + b) as one segmented product (lin_cat): the hidden block of a skip layer sits BEHIND the
+    // input blocks in the weight (columns cin .. cin + W, nerf_model.py:104-105) and is contracted first
+    auto cat_layer = [&](const float* Wm, long ldw, const float* hid, float* y, const float* bias) {
+      CatBlk blk[5];
+      int nb = 0, col = 0;
+      if (hid) blk[nb++] = CatBlk{hid, W, W, Wm + cin};
+      for (int i = 0; i < nin; ++i) { blk[nb++] = CatBlk{in[i].x, in[i].c, in[i].c, Wm + col}; col += in[i].c; }
+      lin_cat(c, blk, nb, ldw, P, W, y, W, EPI_BIAS_LEAKY, bias);
     };
     const float* h = nullptr;
     for (int l = 0; l < D; ++l) {
       float* y = buf[l & 1];
       const float* Wm = q[2 * l];
       const float* b = q[2 * l + 1];
-      if (l == 0) {
-        input_blocks(Wm, cin, 0, y, 0, EPI_BIAS_LEAKY, b);
-      } else if (has(skips, nsk, l)) {
-        // hidden block first (columns cin .. cin + W), then the input blocks with the epilogue on the last one
-        lin(c, h, W, Wm + cin, cin + W, P, W, W, y, W, 0, EPI_NONE, nullptr);
-        input_blocks(Wm, cin + W, 0, y, 1, EPI_BIAS_LEAKY, b);
-      } else {
-        lin(c, h, W, Wm, W, P, W, W, y, W, 0, EPI_BIAS_LEAKY, b);
-      }
+      if (l == 0) cat_layer(Wm, cin, nullptr, y, b);
+      else if (has(skips, nsk, l)) cat_layer(Wm, cin + W, h, y, b);
+      else lin(c, h, W, Wm, W, P, W, W, y, W, 0, EPI_BIAS_LEAKY, b);
       h = y;
     }
     const float* const* t = q + 2 * D;          // final, dir, sigma, rgb
     lin(c, h, W, t[4], W, P, 1, W, sig, 1, 0, EPI_BIAS, t[5]);
     if (g->sigma_only) return;
     lin(c, h, W, t[0], W, P, W, W, fin, W, 0, EPI_BIAS, t[1]);
-    lin(c, fin, W, t[2], W + a->in_dir, P, W / 2, W, dirh, W / 2, 0, EPI_NONE, nullptr);
-    lin(c, g->emb_dir, a->in_dir, t[2] + W, W + a->in_dir, P, W / 2, a->in_dir, dirh, W / 2, 1, EPI_BIAS_LEAKY, t[3]);
+    const CatBlk dblk[2] = {{fin, W, W, t[2]}, {g->emb_dir, a->in_dir, a->in_dir, t[2] + W}};       // cat([final, emb_dir])
+    lin_cat(c, dblk, 2, W + a->in_dir, P, W / 2, dirh, W / 2, EPI_BIAS_LEAKY, t[3]);
     lin(c, dirh, W / 2, t[6], W / 2, P, 3, W / 2, rgb, 3, 0, EPI_BIAS_SIGMOID, t[7]);
   };
   if (g->do_scene) {
@@ -349,28 +370,25 @@ int objnerf_mlp_generic_train_forward(const objnerf_mlp_generic_args* g, void* s
                     float* dirh, float* sig, float* rgb) {
     int cin = 0;
     for (int i = 0; i < nin; ++i) cin += in[i].c;
-    auto input_blocks = [&](const float* Wm, long ldw, float* y, int acc_first, const float* bias) {
-      int col = 0;
-      for (int i = 0; i < nin; ++i) {
-        const bool last = i == nin - 1;
-        lin(c, in[i].x, in[i].c, Wm + col, ldw, P, W, in[i].c, y, W, (i == 0 ? acc_first : 1), last ? EPI_BIAS_LEAKY : EPI_NONE, last ? bias : nullptr);
-        col += in[i].c;
-      }
+    auto cat_layer = [&](const float* Wm, long ldw, const float* hid, float* y, const float* bias) {      // as in objnerf_mlp_generic
+      CatBlk blk[5];
+      int nb = 0, col = 0;
+      if (hid) blk[nb++] = CatBlk{hid, W, W, Wm + cin};
+      for (int i = 0; i < nin; ++i) { blk[nb++] = CatBlk{in[i].x, in[i].c, in[i].c, Wm + col}; col += in[i].c; }
+      lin_cat(c, blk, nb, ldw, P, W, y, W, EPI_BIAS_LEAKY, bias);
     };
     for (int l = 0; l < D; ++l) {
       float* y = act_of(l);
-      if (l == 0) input_blocks(q[0], cin, y, 0, q[1]);
-      else if (has(skips, nsk, l)) {
-        lin(c, act_of(l - 1), W, q[2 * l] + cin, cin + W, P, W, W, y, W, 0, EPI_NONE, nullptr);
-        input_blocks(q[2 * l], cin + W, y, 1, q[2 * l + 1]);
-      } else lin(c, act_of(l - 1), W, q[2 * l], W, P, W, W, y, W, 0, EPI_BIAS_LEAKY, q[2 * l + 1]);
+      if (l == 0) cat_layer(q[0], cin, nullptr, y, q[1]);
+      else if (has(skips, nsk, l)) cat_layer(q[2 * l], cin + W, act_of(l - 1), y, q[2 * l + 1]);
+      else lin(c, act_of(l - 1), W, q[2 * l], W, P, W, W, y, W, 0, EPI_BIAS_LEAKY, q[2 * l + 1]);
     }
     const float* h = act_of(D - 1);
     const float* const* t = q + 2 * D;
     lin(c, h, W, t[4], W, P, 1, W, sig, 1, 0, EPI_BIAS, t[5]);
     lin(c, h, W, t[0], W, P, W, W, fin, W, 0, EPI_BIAS, t[1]);
-    lin(c, fin, W, t[2], W + a->in_dir, P, W / 2, W, dirh, W / 2, 0, EPI_NONE, nullptr);
-    lin(c, g->emb_dir, a->in_dir, t[2] + W, W + a->in_dir, P, W / 2, a->in_dir, dirh, W / 2, 1, EPI_BIAS_LEAKY, t[3]);
+    const CatBlk dblk[2] = {{fin, W, W, t[2]}, {g->emb_dir, a->in_dir, a->in_dir, t[2] + W}};
+    lin_cat(c, dblk, 2, W + a->in_dir, P, W / 2, dirh, W / 2, EPI_BIAS_LEAKY, t[3]);
     lin(c, dirh, W / 2, t[6], W / 2, P, 3, W / 2, rgb, 3, 0, EPI_BIAS_SIGMOID, t[7]);
   };
   {
