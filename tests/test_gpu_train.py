@@ -758,3 +758,51 @@ def test_per_ray_terms_match_the_per_point_contraction(monkeypatch):
         elif k not in ("codes", "table"):
             assert torch.equal(a[k], b[k]), k
     assert changed > 0, "the per-ray form was not selected"
+
+
+def test_hoisted_training_forward_matches_the_per_sample_contraction(monkeypatch):
+    """the training forward with the per-ray constant terms hoisted (objnerf_train_args.ray_bias_ws: objnerf_ray_bias + skipped
+    k-steps, as in the inference passes) against the same kernel contracting every term per sample point (OBJNERF_HOIST=0): the
+    same sums in another association -- results within 2e-6 (coarse keys; the fine keys ride on the sampler), every gradient within
+    5e-4 relative L2 (two forwards that differ by roundoff flip the LeakyReLU masks of the few units within roundoff of their kink:
+    measured ~1e-5..1e-4 at this size; a wrong hoist would be O(1))"""
+    sc = cases.scene_for(A, "voxel", device=DEV)
+    n = 256
+    rays = H.test_rays(n, w=256, h=192, stride=23).to(DEV)
+    ids = synth.per_ray_ids(n, seed=5).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    rd = dict(perturb_rand=torch.rand(n, 64, generator=g).to(DEV), u_rand=torch.rand(n, 64, generator=g).to(DEV),
+              noise=[torch.randn(n, s, generator=g).to(DEV) for s in (64, 64, 128, 128)])
+    mods = (sc.models["coarse"], sc.models["fine"])
+
+    def run():
+        for m in mods + (sc.code_library, sc.embeddings["xyz"]):
+            m.zero_grad()
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        res = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                            embedding_instance=codes, frustum_bound_th=0.025, _randoms=rd)
+        _loss(res).backward()
+        torch.cuda.synchronize()
+        gr = {"%d.%s" % (i, k): p.grad.clone() for i, m in enumerate(mods) for k, p in m.named_parameters()}
+        gr["codes"] = sc.code_library.embedding_instance.weight.grad.clone()
+        gr["table"] = sc.embeddings["xyz"].embedding_space_ftr.weight.grad.clone()
+        return {k: v.detach().clone() for k, v in res.items()}, gr
+    monkeypatch.delenv("OBJNERF_HOIST", raising=False)
+    ra, ga = run()
+    monkeypatch.setenv("OBJNERF_HOIST", "0")
+    rb, gb = run()
+    monkeypatch.delenv("OBJNERF_HOIST", raising=False)
+    assert any(not torch.equal(ra[k], rb[k]) for k in ra), "the switch did not select another path"
+    for k in ra:
+        if k.endswith("coarse"):
+            assert H.normwise(ra[k], rb[k]) < 2e-6, (k, H.normwise(ra[k], rb[k]))
+    moved = H.moved_rays(ra["z_vals_fine"], rb["z_vals_fine"], ra["z_vals_coarse"])
+    if int(moved.sum()) == 0:            # the same importance samples on every ray: gradients comparable end to end
+        for k in ga:
+            assert rel_l2(ga[k], gb[k]) < 5e-4, (k, rel_l2(ga[k], gb[k]))
+    else:
+        for k in ga:
+            if k.startswith("0."):       # the coarse model's gradients do not depend on the fine depths' placement
+                assert rel_l2(ga[k], gb[k]) < 5e-4, (k, rel_l2(ga[k], gb[k]))
+    print("hoisted vs per-sample training forward: worst gradient rel L2 %.2e, %d rays with moved importance samples"
+          % (max(rel_l2(ga[k], gb[k]) for k in ga if k.startswith("0.")), int(moved.sum())))
