@@ -169,7 +169,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
 #endif
 constexpr int kVbSlots = 1 << OBJ_VB_SLOT_BITS;               // power of two
 constexpr int kVbStride = kVoxC + 1;        // odd stride: spreads the rows over the LDS banks
-constexpr int kVbPoints = 128;              // points per workgroup (the aggregation window)
+#ifndef OBJ_VB_POINTS
+#define OBJ_VB_POINTS 128
+#endif
+constexpr int kVbPoints = OBJ_VB_POINTS;    // points per workgroup (the aggregation window)
 // 32 lanes per point, lane = voxel channel (0..15 scene, 16..23 object; 24..31 idle), 8 points per pass of a
 // 256-thread workgroup: a corner's features and every (frequency, sin|cos) block of the incoming gradient row are
 // contiguous across the lanes, and the 24 lanes of a point add to 24 different LDS words of its row's slot.
