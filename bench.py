@@ -544,6 +544,16 @@ def run(args, renderer=None, backend="nccl", argv=None):
             gc.collect()
             torch.cuda.empty_cache()
         res["roofline"].update(pmc_traffic(args, cfg_id, live=live))
+    # RCCL prints its version banner through C stdio at communicator creation; into a pipe or a file that buffer is only
+    # written at process exit, i.e. AFTER the line below.  Every rank flushes it, then a barrier, then rank 0 prints: the JSON
+    # object is the last stdout line of the job.
+    try:
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist is not None:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
