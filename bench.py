@@ -761,7 +761,12 @@ def pmc_traffic(args, cfg_id, live):
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(base, ctr)
                 cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child
-                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                # the child is a plain one-process run: a launcher's rendezvous variables must not reach it (it would join the
+                # parent's store as a second "rank 0")
+                env = {k: v for k, v in os.environ.items()
+                       if not k.startswith(("TORCHELASTIC_", "MASTER_", "GROUP_", "ROLE_", "TORCH_NCCL_"))
+                       and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+                p = subprocess.run(cmd, cwd="/tmp", env=dict(env, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                    stderr=subprocess.DEVNULL, timeout=240)
                 if p.returncode != 0:
                     raise RuntimeError("rocprofv3 --pmc %s exited %d" % (ctr, p.returncode))
