@@ -48,10 +48,13 @@ import ctypes as C
 import json
 import math
 import os
+import datetime
 import socket
 import subprocess
 import sys
+import threading
 import time
+import traceback
 
 # the host driver supports dmabuf IPC only: RCCL needs this BEFORE the HIP runtime comes up (i.e. before `import torch`
 # touches the device), not just before init_process_group
@@ -71,6 +74,64 @@ PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# failing loudly (round 6): the first real N > 1 run must not hang or die silently
+# ---------------------------------------------------------------------------------------------------------------------
+def flush_stdio():
+    """RCCL / gloo banners sit in the C stdio buffer of a piped process until exit: push them out BEFORE a JSON line"""
+    try:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def die_with_error_line(msg, code=1, phase=None):
+    """One JSON object as this process's LAST stdout line, then an immediate exit without interpreter / process-group teardown
+    (a wedged communicator must not hold the exit): a launcher (torchrun, self_launch) sees the non-zero code within seconds and
+    stops the other ranks."""
+    rec = {"error": str(msg)[-1500:], "rank": int(os.environ.get("RANK", "0")), "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+           "phase": phase or Heartbeat.phase, "metric": None, "value": None}
+    flush_stdio()
+    try:
+        sys.stdout.write(json.dumps(rec) + "\n")
+        sys.stdout.flush()
+    finally:
+        os._exit(code)
+
+
+class Heartbeat:
+    """Stall detector of a multi-rank run: the main thread names the phase it enters (`Heartbeat.beat`); if no phase is entered
+    for `limit` seconds -- a rank wedged inside a collective, a peer that never arrived -- the watcher prints the error line and
+    exits the process (code 3) instead of sitting out the driver's lease.  RCCL's own collective timeout is set at
+    init_process_group (180 s) and aborts the process through torch's watchdog without a parseable line; this limit is longer
+    than any phase of a healthy run and shorter than the lease."""
+    phase = "start"
+    _last = time.monotonic()
+    _thread = None
+
+    @classmethod
+    def beat(cls, phase):
+        cls.phase, cls._last = phase, time.monotonic()
+
+    @classmethod
+    def start(cls, limit):
+        if cls._thread is not None or limit <= 0:
+            return
+        cls.beat(cls.phase)
+
+        def watch():
+            while True:
+                time.sleep(1.0)
+                idle = time.monotonic() - cls._last
+                if idle > limit:
+                    die_with_error_line("no progress for %.0f s in phase '%s' (stall limit %d s: a rank wedged in a collective, or a "
+                                        "peer that never arrived)" % (idle, cls.phase, limit), code=3)
+        cls._thread = threading.Thread(target=watch, name="bench-heartbeat", daemon=True)
+        cls._thread.start()
 
 
 def parse(argv=None):
@@ -105,6 +166,10 @@ def parse(argv=None):
                          "`strong_scaling` together with rank 0 rendering the same frame alone (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=24,
                     help="extra, separately reported free-running training steps of the reference batch (`train_step`; 0 = skip)")
+    ap.add_argument("--stall-limit", type=int, default=300,
+                    help="multi-rank runs: seconds without entering a new phase before the process prints an error line and exits "
+                         "(0 = off)")
+    ap.add_argument("--pg-timeout", type=int, default=180, help="process-group (RCCL / gloo) collective timeout in seconds")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -157,6 +222,16 @@ def self_launch(args, argv, cmd=None):
             if p.poll() is None:
                 p.kill()
     return rc
+
+
+def self_launch_or_die(args, argv, cmd=None):
+    """self_launch, and on failure one JSON error object as the job's last stdout line + the failing rank's exit code.  The
+    failing rank printed its own error line when it could; a rank killed by a signal (RCCL's watchdog aborts the process) could
+    not: either way the last line says what happened."""
+    rc = self_launch(args, argv, cmd=cmd)
+    if rc != 0:
+        die_with_error_line("a rank exited with code %d (its own error line, if it could print one, is above)" % rc,
+                            code=rc if 0 < rc < 256 else 1, phase="self_launch")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -353,6 +428,9 @@ def run(args, renderer=None, backend="nccl", argv=None):
     if renderer is None:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d wants cuda:%d but only %d GPU(s) are visible (--gpus %d; --one-gpu puts every rank on "
+                             "cuda:0)" % (rank, local_rank, torch.cuda.device_count(), args.gpus))
         torch.cuda.set_device(local_rank)
         renderer = HipRenderer(torch.device("cuda", local_rank))
     R = renderer
@@ -364,9 +442,22 @@ def run(args, renderer=None, backend="nccl", argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if on_gpu:
+            Heartbeat.start(args.stall_limit)
+        Heartbeat.beat("init_process_group(%s, world %d)" % (backend, world))
         if not dist_mod.is_initialized():
-            dist_mod.init_process_group(backend, rank=rank, world_size=world)
+            kw = dict(timeout=datetime.timedelta(seconds=args.pg_timeout))
+            if backend == "nccl":
+                # device_id: the communicator is created HERE (eagerly, on this rank's GPU) -- a bad topology / IPC setting fails
+                # at init with RCCL's message instead of inside the first timed collective
+                kw["device_id"] = torch.device("cuda", local_rank)
+            dist_mod.init_process_group(backend, rank=rank, world_size=world, **kw)
         dist = dist_mod
+        Heartbeat.beat("first barrier")
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
 
     # ONE default workload at every N (configs[1], the configuration the metric is quoted on; one frame per rank per step),
     # so that the driver's N = 1, 2, 4, 8 series is same-workload and its N = 1 point is the BENCH line
@@ -393,15 +484,20 @@ def run(args, renderer=None, backend="nccl", argv=None):
 
     log("config %d (scaling: %s), %d pixels/frame, %d rays on rank %d (%s), world %d" % (
         cfg_id, scaling_label, wl.n_pixels, wl.n_local, wl.rank, wl.shard_mode, wl.world))
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        Heartbeat.beat("warm-up step %d" % i)
         wl.step()
+    Heartbeat.beat("fence after warm-up")
     fence()
+    Heartbeat.beat("timed region")
     wl.marks.clear()
     if lib is not None:
         lib.objnerf_timing_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        Heartbeat.beat("timed step %d" % i)           # two attribute writes: not a device or host cost worth a line
         out = wl.step()
+    Heartbeat.beat("fence after the timed region")
     fence()
     t1 = time.perf_counter()
     launches, kms = C.c_int64(0), C.c_double(0.0)
@@ -410,6 +506,7 @@ def run(args, renderer=None, backend="nccl", argv=None):
         lib.objnerf_timing_enable(0)
     render_ms, gather_ms = wl.phase_ms()
     log("timed region done: %.3f s for %d steps" % (t1 - t0, args.steps))
+    Heartbeat.beat("per-rank statistics")
     if args.pmc_child:            # a rocprofv3 --pmc pass of this workload: the counters are all that is wanted
         if dist is not None:
             dist.destroy_process_group()
@@ -452,11 +549,14 @@ def run(args, renderer=None, backend="nccl", argv=None):
     # ---- BASELINE configs[3] beside a default N > 1 line: one frame over the N ranks + its same-run N = 1 anchor ----
     strong = None
     if dist is not None and world > 1 and cfg_id in (0, 1, 2) and args.strong_steps > 0 and args.as_rank is None:
+        Heartbeat.beat("strong-scaling leg (configs[3])")
         strong = strong_scaling_leg(args, R, rank, world, dist, fence, allreduce, allgather_list, backend)
     # ---- the reference's training step on the differentiable HIP path (row f1), reported beside the headline ----
     train = None
     if on_gpu and args.train_steps > 0 and args.as_rank is None:
+        Heartbeat.beat("training-step leg")
         train = train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend)
+    Heartbeat.beat("assembling the line")
 
     res = None
     if rank == 0:
@@ -547,15 +647,13 @@ def run(args, renderer=None, backend="nccl", argv=None):
     # RCCL prints its version banner through C stdio at communicator creation; into a pipe or a file that buffer is only
     # written at process exit, i.e. AFTER the line below.  Every rank flushes it, then a barrier, then rank 0 prints: the JSON
     # object is the last stdout line of the job.
-    try:
-        sys.stdout.flush()
-        C.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    flush_stdio()
+    Heartbeat.beat("barrier before the line")
     if dist is not None:
         dist.barrier()
     if rank == 0:
         print(json.dumps(res), flush=True)
+    Heartbeat.beat("barrier after the line")
     if dist is not None:
         dist.barrier()
         if backend == "nccl" or not os.environ.get("OBJNERF_BENCH_KEEP_PG"):
@@ -673,6 +771,7 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend="nccl
         t0 = time.perf_counter()
         host = 0.0                                   # host time spent ENQUEUEING (waits at the synchronisations excluded)
         for i in range(args.train_steps):
+            Heartbeat.beat("training step %d" % i)
             th = time.perf_counter()
             loss = step()
             host += time.perf_counter() - th
@@ -692,17 +791,20 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend="nccl
             lib = _lib.lib()
             n_ph = 8
             fence()
-            lib.objnerf_train_timing_enable(1)
-            tp = time.perf_counter()
-            for _ in range(n_ph):
-                step(mark_sync=True)
-            torch.cuda.synchronize()
-            wall = (time.perf_counter() - tp) / n_ph * 1e3
-            exchange_ms = sum(a.elapsed_time(b) for a, b in sync_marks) / max(1, len(sync_marks))
+            Heartbeat.beat("training steps with phase marks")
             ms = (C.c_double * 5)()
             cnt = (C.c_int64 * 5)()
-            lib.objnerf_train_timing_read(ms, cnt)
-            lib.objnerf_train_timing_enable(0)
+            lib.objnerf_train_timing_enable(1)
+            try:
+                tp = time.perf_counter()
+                for _ in range(n_ph):
+                    step(mark_sync=True)
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - tp) / n_ph * 1e3
+                exchange_ms = sum(a.elapsed_time(b) for a, b in sync_marks) / max(1, len(sync_marks))
+                lib.objnerf_train_timing_read(ms, cnt)
+            finally:        # a failure in the marked loop must not leave every later training call creating events nobody reads
+                lib.objnerf_train_timing_enable(0)
             names = ("forward", "dgrad", "dx", "scatter", "wgrad")
             phases = {k: ms[i] / n_ph for i, k in enumerate(names)}
             phases["other"] = wall - sum(phases.values())
@@ -885,11 +987,19 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
-        rc = self_launch(args, argv)
-        if rc != 0:
-            raise SystemExit(rc)
+        self_launch_or_die(args, argv)
         return None
-    return run(args, argv=argv)
+    try:
+        return run(args, argv=argv)
+    except KeyboardInterrupt:
+        raise
+    except SystemExit as e:
+        if e.code in (0, None):
+            raise
+        die_with_error_line(e.code if isinstance(e.code, str) else "exit code %r" % (e.code,), code=e.code if isinstance(e.code, int) else 2)
+    except BaseException as e:      # noqa: B036 -- every failure of every rank ends in ONE parseable line and a fast non-zero exit
+        traceback.print_exc()
+        die_with_error_line("%s: %s" % (type(e).__name__, e), code=1)
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define OBJNERF_ABI_VERSION 9
+#define OBJNERF_ABI_VERSION 10
 
 int objnerf_abi_version(void);
 const char* objnerf_last_error(void);
@@ -57,6 +57,14 @@ int objnerf_pack_index(int use_voxel, uint32_t* h_blob_idx, uint32_t* h_aux_idx)
  * h_param_ptrs: HOST array of objnerf_num_param_ptrs() DEVICE pointers. */
 int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx,
                          const float* const* h_param_ptrs, float* blob, float* aux, void* stream);
+/* ABI 10: the same for n_models (1 or 2) modules of one mode in ONE launch -- the coarse and fine model of a render_rays call
+ * (train.py:45-51 builds both from one config).  h_param_ptrs: HOST array of n_models * objnerf_num_param_ptrs() DEVICE
+ * pointers (model-major); h_blobs / h_auxs: HOST arrays of n_models DEVICE output pointers.  The product gathers on EVERY
+ * call (SURVEY 8b "repack when params change": a cache keyed on host-visible parameter versions cannot see fused optimizers,
+ * `.data` writes or graph-replayed steps; the launch costs ~8 us and is captured with the call in a graph).
+ * objnerf_pack_weights is this with n_models = 1. */
+int objnerf_pack_models(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx, int n_models,
+                        const float* const* h_param_ptrs, float* const* h_blobs, float* const* h_auxs, void* stream);
 
 /* Training only: the transposed weight stream of the hidden-to-hidden blocks, consumed by the fused backward of the
  * hidden chain (objnerf_train_args.blob_bwd).  Same tile/chunk format as the forward stream with rows = input

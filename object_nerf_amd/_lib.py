@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OBJNERF_LIB: developer hook for A/B-timing build variants (tools/); the product library is the in-tree one
 LIB_PATH = os.environ.get("OBJNERF_LIB") or os.path.join(_HERE, "libobjnerf_hip.so")
-ABI_VERSION = 9     # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
+ABI_VERSION = 10    # OBJNERF_ABI_VERSION of include/objnerf_hip.h these struct mirrors were written against
 
 c_float_p = C.POINTER(C.c_float)
 c_u8_p = C.POINTER(C.c_uint8)
@@ -185,6 +185,7 @@ SIGNATURES = {
     "objnerf_param_numel": (C.c_int64, [C.c_int, C.c_int]),
     "objnerf_pack_index": (C.c_int, [C.c_int, _VP, _VP]),
     "objnerf_pack_weights": (C.c_int, [C.c_int, _VP, _VP, C.POINTER(_VP), _VP, _VP, _VP]),
+    "objnerf_pack_models": (C.c_int, [C.c_int, _VP, _VP, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), _VP]),
     "objnerf_bwd_blob_floats": (C.c_int64, []),
     "objnerf_pack_index_bwd": (C.c_int, [C.c_int, _VP]),
     "objnerf_pack_weights_bwd": (C.c_int, [_VP, C.POINTER(_VP), _VP, _VP]),

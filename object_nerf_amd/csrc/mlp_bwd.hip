@@ -49,15 +49,11 @@ __device__ __forceinline__ void fetch_tiles(RawTiles& raw, const float* mat, lon
   for (int t = 0; t < N; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#ifdef OBJ_ABL_BWD_NOLOAD     // timing ablation only
-      raw.v[t][i] = f32x4{1.f, 1.f, 1.f, 1.f};
-#else
       const long row = sg.p0 + 8 * i + q;
 #if OBJ_NT_ACT
       raw.v[t][i] = __builtin_nontemporal_load((const f32x4*)(mat + (row < sg.P ? row : sg.P - 1) * ld + 32 * (t0 + t) + 4 * k));
 #else
       raw.v[t][i] = *(const f32x4*)(mat + (row < sg.P ? row : sg.P - 1) * ld + 32 * (t0 + t) + 4 * k);
-#endif
 #endif
     }
 }

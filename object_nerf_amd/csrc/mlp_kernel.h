@@ -34,31 +34,18 @@
 #include "../../include/objnerf_hip.h"
 
 // ---- tuning switches (defaults = the shipped configuration; tools/tune_mlp.py A/Bs them) ----
-#ifndef OBJ_HOIST_LDS
-#define OBJ_HOIST_LDS 0      // issue the next group's ds_read_b128 before this group's MFMAs
-#endif
 #ifndef OBJ_AUX_LDS
 #define OBJ_AUX_LDS 1        // biases / head weights staged once per workgroup in LDS
 #endif
-#ifndef OBJ_EMB_PIPE
-#define OBJ_EMB_PIPE 0       // compute the B operand of k-step s+1 under the MFMAs of k-step s
-#endif
-#ifndef OBJ_SPREAD_LDS
-#define OBJ_SPREAD_LDS 0     // N > 0: schedule one ds_read_b128 of the next group after every N-th MFMA
-#endif
 #ifndef OBJ_OCTAVE_DOUBLING
-#define OBJ_OCTAVE_DOUBLING 1   // sin/cos of 2a from (sin a, cos a) for 2 of every 3 octaves of one argument
+#define OBJ_OCTAVE_DOUBLING 3   // P > 1: of every P octaves of one argument the first is evaluated in full, the P - 1 after it come
+                                // from the double-angle identities; 0 or 1: every octave in full
 #endif
 #ifndef OBJ_PREFETCH_TILE
 #define OBJ_PREFETCH_TILE 1  // gather prologue of the NEXT tile staged between the object-branch layers
 #endif
 #ifndef OBJ_PREFETCH_SCENE
 #define OBJ_PREFETCH_SCENE 1 // density query, scene branch: gather prologue of the NEXT tile staged on the chunk barriers of xyz_encoding_1
-#endif
-#ifndef OBJ_XCD_TILES
-#define OBJ_XCD_TILES 1      // each XCD works on one contiguous eighth of the tiles (L2 locality of the voxel gathers); 1: its
-                             // workgroups walk it side by side (shipped), 2: each workgroup walks its own contiguous run of it
-                             // (round 4, measured: the counter's fetch per launch 4.8 -> 9.2 GB, time equal -- rejected)
 #endif
 #ifndef OBJ_SPREAD_DMA
 #define OBJ_SPREAD_DMA 1     // weight DMA pieces issued between the MFMA groups instead of as a burst
@@ -71,9 +58,6 @@
 #endif
 #ifndef OBJ_CODE_REGS
 #define OBJ_CODE_REGS 1      // object code (32 floats per lane half) loaded once per pass into VGPRs
-#endif
-#ifndef OBJ_EMB_V
-#define OBJ_EMB_V 5          // VALU instructions scheduled into each MFMA issue gap
 #endif
 
 namespace objnerf {
@@ -92,14 +76,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---------------------------------------------------------------------------------------------
 // weight stream: 2-slot LDS ring, one chunk (32 KiB) prefetched ahead, one barrier per chunk
 // ---------------------------------------------------------------------------------------------
-#ifndef OBJ_DMA_BUFFER
-#define OBJ_DMA_BUFFER 1     // weight DMA as buffer_load_dwordx4 ... lds (SGPR descriptor + soffset + imm offset)
-#endif
-
-#ifndef OBJ_RING_SLOTS
-#define OBJ_RING_SLOTS 2     // 2: DMA one chunk ahead, vmcnt(0) at the chunk barrier; 3: two chunks ahead, counted vmcnt
-#endif
-constexpr int kRingSlots = OBJ_RING_SLOTS;
+constexpr int kRingSlots = 2;   // the DMA runs one chunk ahead; vmcnt(0) is part of the chunk barrier
 
 template <int CB>
 struct WeightStreamT {
@@ -111,46 +88,29 @@ struct WeightStreamT {
   lds_char* ring;      // 2 * CB
   lds_char* rd;        // per-lane read base of the current slot (ring + cur*chunk + lane*16)
   int tid;
-#if OBJ_DMA_BUFFER
   __amdgpu_buffer_rsrc_t rsrc;
   int wave;            // wave-uniform (readfirstlane)
-#endif
 
-  // One chunk = CB, copied linearly global -> LDS by the 4 waves.
-  // OBJ_DMA_BUFFER: wave w owns the contiguous quarter [w*Q, (w+1)*Q) and moves it as Q/1024
-  // buffer_load_dwordx4...lds: descriptor and chunk offset live in SGPRs, the piece offset in the
+  // One chunk = CB, copied linearly global -> LDS by the 4 waves: wave w owns the contiguous quarter [w*Q, (w+1)*Q) and
+  // moves it as Q/1024 buffer_load_dwordx4...lds: descriptor and chunk offset live in SGPRs, the piece offset in the
   // 12-bit immediate (applied to the global AND the LDS address), M0 (LDS base) changes once per
-  // 4 KiB.  A flat global_load_lds needs a 64-bit VALU address add + M0 write + hazard nop per
-  // piece and measured ~49 cycles of lost MFMA issue per piece (4 % of the kernel).
+  // 4 KiB.  (A flat global_load_lds needs a 64-bit VALU address add + M0 write + hazard nop per
+  // piece and measured ~49 cycles of lost MFMA issue per piece, 4 % of the kernel: docs/HISTORY_r1_r3.md.)
   template <int I>
   __device__ __forceinline__ void piece(lds_char* dst, int voff, int soff) {
-#if OBJ_DMA_BUFFER
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (I >> 2) * 4096), 16,
                                              voff, soff + (I >> 2) * 4096, (I & 3) * 1024, 0);
-#endif
   }
   __device__ __forceinline__ void issue(int slot) {
     // `next` is statically predictable inside one pass; hide it from the optimiser or LICM hoists
     // one 64-bit source address per (chunk, piece) out of the tile loop (hundreds of VGPRs, spills)
     int n = next;
     asm volatile("" : "+s"(n));
-#if OBJ_DMA_BUFFER
     constexpr int Q = CB / 4;
     lds_char* dst = ring + slot * CB + wave * Q;
     const int soff = n * CB + wave * Q;
     const int voff = (tid & 63) * 16;
     static_for<Q / 1024>([&](auto I) __attribute__((always_inline)) { piece<decltype(I)::value>(dst, voff, soff); });
-#else
-    const char* src = win + (size_t)n * CB + tid * 16;
-    // wave-uniform LDS base; the DMA adds lane*16 itself
-    lds_char* dst = ring + slot * CB + (tid >> 6) * 1024;
-#pragma unroll
-    for (int i = 0; i < CB / 4096; ++i) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + i * 4096),
-          (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-    }
-#endif
     next = (next + 1 == nchunks) ? 0 : next + 1;
   }
   // Spread mode: next_chunk() only selects the chunk; its kPieces DMA instructions are then issued one at a time
@@ -172,40 +132,17 @@ struct WeightStreamT {
   }
   __device__ __forceinline__ void init(const char* w, int n, lds_char* r, int t) {
     win = w; nchunks = n; next = 0; ring = r; tid = t; cur = kRingSlots - 1;
-#if OBJ_DMA_BUFFER
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, n * CB, 0x00020000);
     wave = __builtin_amdgcn_readfirstlane(t >> 6);
-#endif
     issue(0);
-    if constexpr (kRingSlots == 3) issue(1);
   }
   // called right before the first A read of a chunk
   __device__ __forceinline__ void next_chunk() {
-    if constexpr (kRingSlots == 2) {
-#ifndef OBJ_ABL_BARRIER     // timing ablation only: racy without the barrier
-      __syncthreads();   // all DMA of the chunk landed (vmcnt(0) is part of the barrier) and every
-                         // wave is done reading the slot we are about to overwrite
-#endif
-      cur ^= 1;
-#ifndef OBJ_ABL_DMA         // timing ablation only: weights never refreshed
-      if constexpr (OBJ_SPREAD_DMA) select(cur ^ 1);
-      else issue(cur ^ 1);
-#endif
-    } else {
-      // 3 slots: the chunk consumed next was DMA'd two chunk-times ago; only the pieces of the
-      // chunk after it (the newest CB/4096 VMEM ops of this wave) may still be in flight.
-      // __syncthreads() would drain vmcnt(0) (LDS-DMA counts as a pending LDS write), so: counted
-      // vmcnt + lgkmcnt(0) (this wave's reads of the slot being recycled) + raw s_barrier.
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(CB / 4096) : "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      cur = cur == 2 ? 0 : cur + 1;
-      // slot of the chunk consumed before the current one.  Spread mode: only selected here, its pieces are issued
-      // between this chunk's MFMA groups; at the NEXT barrier they are the newest CB/4096 VMEM operations of the wave
-      // (or older than later prologue loads), which is exactly what the counted vmcnt above leaves in flight
-      if constexpr (OBJ_SPREAD_DMA) select(cur == 0 ? 2 : cur - 1);
-      else issue(cur == 0 ? 2 : cur - 1);
-    }
+    __syncthreads();   // all DMA of the chunk landed (vmcnt(0) is part of the barrier) and every
+                       // wave is done reading the slot we are about to overwrite
+    cur ^= 1;
+    if constexpr (OBJ_SPREAD_DMA) select(cur ^ 1);
+    else issue(cur ^ 1);
     rd = ring + cur * CB + (tid & 63) * 16;
   }
 };
@@ -268,9 +205,6 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
   ATiles<NT> abuf[2];
   load_group<NT, 0>(abuf[0], st);
   after_barrier(std::integral_constant<int, 0>{});
-#if OBJ_EMB_PIPE
-  float b_next = src.template get<0>();
-#endif
   static_for<NG4>([&](auto G) __attribute__((always_inline)) {
     constexpr int g = decltype(G)::value;
     constexpr int ks0 = g * 4;
@@ -289,19 +223,11 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
         if constexpr (decltype(I)::value >= (g % GPC + 1) * PPG) st.template piece_now<decltype(I)::value>();
       });
     }
-#if OBJ_HOIST_LDS
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     static_for<4>([&](auto J) __attribute__((always_inline)) {
       constexpr int j = decltype(J)::value;
       constexpr int ks = ks0 + j;
       if constexpr (ks < KS && !skipped) {
-#if OBJ_EMB_PIPE
-        const float b = b_next;
-        if constexpr (ks + 1 < KS) b_next = src.template get<ks + 1>();
-#else
         const float b = src.template get<ks>();
-#endif
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
           if constexpr (ZERO && ks == 0) {
@@ -311,25 +237,8 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[m][j], b, acc[m], 0, 0, 0);
           }
         }
-#if OBJ_EMB_PIPE
-        // 1 MFMA, then up to OBJ_EMB_V VALU ops of the next operand's arithmetic, per out tile
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, OBJ_EMB_V, 0);
-        }
-#endif
       }
     });
-#if OBJ_SPREAD_LDS
-    // 4 waves issue the same 8 KiB of LDS reads in lockstep: spread them under the MFMAs instead of
-    // one burst in front of the group's last MFMA
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, OBJ_SPREAD_LDS, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#endif
     __builtin_amdgcn_sched_barrier(0);
   });
 }
@@ -350,9 +259,6 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT])
 #pragma unroll
   for (int m = 0; m < NT; ++m)
 #pragma unroll
-#ifdef OBJ_ABL_FINISH      // timing ablation only: no LeakyReLU arithmetic
-    for (int r = 0; r < 16; ++r) h[m][r] = acc[m][r];
-#else
     for (int r = 0; r < 16; r += 2) {
       if constexpr (ACT && OBJ_PK_LEAKY) {
         // 0.01 v for two values in one v_pk_mul_f32 (gfx950 has packed fp32 mul / fma, no packed max): the same two IEEE
@@ -366,7 +272,6 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[NT], f32x16 (&h)[NT])
         h[m][r + 1] = ACT ? leaky(acc[m][r + 1]) : acc[m][r + 1];
       }
     }
-#endif
 }
 
 // HOIST: per-ray vectors (objnerf_mlp_args.ray_bias, aux-bias layout [m][half][16]) and the epilogue that adds them
@@ -504,12 +409,8 @@ struct FusedSrc {
   // positional-encoding pair slots: even local index = sin, odd = cos of the same argument;
   // slots are consumed in increasing order, so the cos rides along from the sin slot
   __device__ __forceinline__ float pe_pair(float arg, int fn) {
-#ifdef OBJ_ABL_SINCOS      // timing ablation only (tools/tune_mlp.py): no sin/cos arithmetic
-    return arg;
-#else
     if (fn == 0) { const SinCos sc = psincos(arg); saved_cos = sc.c; saved_sin = sc.s; return sc.s; }
     return saved_cos;
-#endif
   }
   // Octave k of the SAME base argument, consumed in increasing k (k = 0 restarts).  Every third octave
   // is evaluated in full; the two after it come from the double-angle identities
@@ -519,8 +420,8 @@ struct FusedSrc {
   // kernel before this change).
   template <int K>
   __device__ __forceinline__ float pe_octave(float base, int fn) {
-#if OBJ_OCTAVE_DOUBLING && !defined(OBJ_ABL_SINCOS)
-    if constexpr (K % 3 != 0) {
+#if OBJ_OCTAVE_DOUBLING > 1
+    if constexpr (K % OBJ_OCTAVE_DOUBLING != 0) {
       if (fn == 0) {
         const float s = saved_sin, c = saved_cos;
         saved_sin = (2.f * s) * c;
@@ -917,9 +818,6 @@ struct Stage {
 };
 template <int NT>
 __device__ __forceinline__ void save_tile(const f32x16 (&h)[NT], int t, float* mat, long ld, const Stage& sg) {
-#ifdef OBJ_ABL_NOSAVE         // timing ablation only
-  return;
-#endif
   const int pt = sg.lane & 31, half = sg.lane >> 5, q = sg.lane >> 3, k = sg.lane & 7;
   {
 #pragma unroll
@@ -1040,30 +938,12 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   // its own 4 MB L2.  Every XCD gets ONE contiguous eighth of the tiles and its 32 workgroups walk it side by side, so
   // the voxel-table rows shared by neighbouring depths / neighbouring pixels are fetched into one L2 instead of eight
   // (with the plain "tile = b + k * grid" map consecutive tiles land on 8 different XCDs).
-#if OBJ_XCD_TILES
   const bool by_xcd = (gridDim.x & 7) == 0;
-#else
-  const bool by_xcd = false;
-#endif
   const long tiles_per_xcd = (ntiles + 7) / 8;
-#if OBJ_XCD_TILES == 2
-  // Tuning variant (round 4, NOT shipped): inside its eighth every workgroup walks its OWN contiguous run, so that the XCD's 32
-  // workgroups hold pixels of ~32 different image rows at about the same column (a strip compact in both image directions)
-  // instead of 32-64 horizontally neighbouring pixels of one row.  Measured on the headline frame (tools/xcd_ab.sh,
-  // profiles/r04_xcd_ab.txt): time equal, memory-side fetch per launch 4.8 -> 9.2 GB -- 32 workgroups each streaming their own
-  // table rows turn the 0.4 MB of L2 the weight stream leaves free over faster than 64 neighbouring rays that share most rows.
-  const long wgs_per_xcd = gridDim.x >> 3;
-  const long run = by_xcd ? (tiles_per_xcd + wgs_per_xcd - 1) / wgs_per_xcd : 0;
-  const long xcd_end = by_xcd ? (((blockIdx.x & 7) + 1) * tiles_per_xcd < ntiles ? ((blockIdx.x & 7) + 1) * tiles_per_xcd : ntiles) : ntiles;
-  const long tile_first = by_xcd ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) * run : blockIdx.x;
-  const long tile_step = by_xcd ? 1 : gridDim.x;
-  const long tile_end = by_xcd ? (tile_first + run < xcd_end ? tile_first + run : xcd_end) : ntiles;
-#else
   const long tile_first = by_xcd ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   const long tile_step = by_xcd ? (gridDim.x >> 3) : gridDim.x;
   const long tile_end = by_xcd ? (((blockIdx.x & 7) + 1) * tiles_per_xcd < ntiles ? ((blockIdx.x & 7) + 1) * tiles_per_xcd : ntiles)
                                : ntiles;
-#endif
   // a workgroup without a tile (the grid is sized for all n_rays, a culled ray subset may need far fewer): leave before
   // the weight DMA, the aux staging and the first gather prologue are issued -- uniform per workgroup
   if (tile_first >= tile_end) return;
@@ -1097,14 +977,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
   constexpr bool PREFETCH_S = OBJ_PREFETCH_TILE && OBJ_PREFETCH_SCENE && POINTS && DO_SCENE && !DO_OBJ;
   TilePrologue<VOXEL, POINTS> pre;
   if constexpr (FUSED) {
-#ifdef OBJ_ABL_PROLOGUE     // timing ablation only: no voxel gather
-    pre.stage_a(a, tile_first, P, wave, lane);
-    pre.stage_b(a.grid);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) pre.vf[i] = pre.pos[i % 3];
-#else
     pre.run_all(a, tile_first, P, wave, lane, half);
-#endif
   }
   // compositing in the epilogue (objnerf_mlp_args.comp_w, composite_seg.h): inference form of the fused kernel only
   constexpr bool COMP = FUSED && !SAVE && !SIGMA_ONLY && DO_SCENE;
@@ -1119,12 +992,7 @@ __global__ void __launch_bounds__(256, 1) mlp_kernel(const objnerf_mlp_args a, c
     if constexpr (FUSED) {
       if constexpr (!PREFETCH && !PREFETCH_S) {
         if (tile != tile_first) {
-#ifdef OBJ_ABL_PROLOGUE
-          pre.stage_a(a, tile, P, wave, lane);
-          pre.stage_b(a.grid);
-#else
           pre.run_all(a, tile, P, wave, lane, half);
-#endif
         }
       }
       p = pre.p;

@@ -901,37 +901,41 @@ struct RayBiasArgs {
   float* out;
   const int32_t* ray_index; const int32_t* n_active;      // optional ray subset (objnerf_mlp_args): only the listed rays are computed
 };
-__device__ __forceinline__ float blob_weight(const float* blob, bool vox, int l, int ks, int half, int row) {
+// position in the packed weight stream of W[row][column held by k-step `ks`, lane half `half`] of layer l (layout.h)
+__device__ __forceinline__ long blob_weight_index(bool vox, int l, int ks, int half, int row) {
   const int nt = layer_nt(l), kg = kChunkTiles / nt;
   const long base = (long)layer_chunk_start(vox, l) * kChunkFloats;
   const int chunk = ks / kg, kl = ks % kg, g4 = kl / 4, j = kl % 4, m = row >> 5, lane = (row & 31) + 32 * half;
-  return blob[base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j];
+  return base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j;
 }
-// Step 1 (one workgroup per input column): the hoisted weight columns as a compact matrix wm[group][c][16] + bias[group][16], group = 16
-// consecutive floats of the per-ray vector (one (layer, out tile, lane half) of the MLP kernel's D layout), c = input
-// column (64 code columns or 27 direction columns) -- read from the packed stream by the packer's own layout arithmetic.
-__global__ void __launch_bounds__(448) ray_bias_weights_kernel(const RayBiasArgs a, float* __restrict__ wm) {
-  const int o = threadIdx.x;                  // position in the per-ray vector
-  const int c = blockIdx.x;                   // input column (0..63 of the code, 0..26 of the direction embedding)
-  const bool vox = a.use_voxel != 0;
+// Step 1 (inside the packer, pack_all_kernel): the hoisted weight columns as a compact matrix wm[group][c][16] + bias[group][16],
+// group = 16 consecutive floats of the per-ray vector (one (layer, out tile, lane half) of the MLP kernel's D layout), c = input
+// column (64 code columns or 27 direction columns).  This returns WHERE element (o, c) sits in the packed stream (-1: zero) by the
+// packer's own layout arithmetic; the packer resolves it through the same gather map the stream itself is written through.
+__device__ __forceinline__ long rb_matrix_src(bool vox, int o, int c) {
   const int l = o < 128 ? L_O1 : (o < 256 ? L_O3 : (o < 384 ? L_SD : L_OD));
   const int off = o < 128 ? 0 : (o < 256 ? 128 : (o < 384 ? 256 : 384));
   const int q = o - off, m = q >> 5, half = (q >> 4) & 1, r = q & 15;
   const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;   // D layout
-  const int g = o >> 4, j = o & 15;
-  float w = 0.f;
   if (o < 256) {
     const int ks0 = ks_emb(vox) + (vox ? kKsObjVox : 0);        // first code k-step of the object input list (layout.h)
-    w = blob_weight(a.blob, vox, l, ks0 + (c & 31), c >> 5, row);
-  } else if (c < kDirC) {
+    return blob_weight_index(vox, l, ks0 + (c & 31), c >> 5, row);
+  }
+  long src = -1;
+  if (c < kDirC) {
     const int nh = l == L_SD ? 128 : 64;
     // slot (i, h) of the direction list that holds column c (layout.h::dir_slot_col)
     for (int i = 0; i < kKsDir; ++i)
       for (int h = 0; h < 2; ++h)
-        if (dir_slot_col(i, h) == c) w = blob_weight(a.blob, vox, l, nh + i, h, row);
+        if (dir_slot_col(i, h) == c) src = blob_weight_index(vox, l, nh + i, h, row);
   }
-  wm[((long)g * 64 + c) * 16 + j] = w;
-  if (c == 0) wm[kRbGroups * 64 * 16 + o] = a.aux[aux_bias_off(l) + q];
+  return src;
+}
+// aux position of the bias that starts position o of the per-ray vector
+__device__ __forceinline__ int rb_bias_src(int o) {
+  const int l = o < 128 ? L_O1 : (o < 256 ? L_O3 : (o < 384 ? L_SD : L_OD));
+  const int off = o < 128 ? 0 : (o < 256 ? 128 : (o < 384 ? 256 : 384));
+  return aux_bias_off(l) + (o - off);
 }
 // Step 2: lane = ray (its code and direction embedding in registers), the weights of 16 outputs at a time as wave-uniform
 // (scalar) operands; every lane stores the 16 outputs as one 64-byte piece of its ray's vector.  One wave per workgroup and
@@ -1086,11 +1090,49 @@ __global__ void __launch_bounds__(64) composite_multi_kernel(const MultiPtrs ptr
 // weight packer: gather through the index map
 // ------------------------------------------------------------------------------------------
 struct ParamPtrs { const float* p[kNumParamPtrs]; };
+__device__ __forceinline__ float pack_fetch(const ParamPtrs& pp, uint32_t e) {
+  return e == kPackZero ? 0.f : pp.p[e >> 24][e & 0xFFFFFFu];
+}
 __global__ void pack_kernel(const uint32_t* __restrict__ idx, long n, const ParamPtrs pp, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t e = idx[i];
-  out[i] = e == kPackZero ? 0.f : pp.p[e >> 24][e & 0xFFFFFFu];
+  out[i] = pack_fetch(pp, idx[i]);
+}
+// Everything the inference kernels read of up to kPackModels ObjectNeRF modules in ONE launch (round 6: the product re-gathers on
+// EVERY call instead of caching per parameter version -- a cache keyed on host-visible versions cannot see `.data` writes, fused
+// optimizers or graph-replayed steps; three launches per model were ~40 us per render_rays call, this is one of ~8 us).
+// blockIdx.y = model; blockIdx.x walks [weight stream | aux block | compact matrix of the hoisted columns + its biases]; the
+// compact matrix reads the PARAMETERS through the gather maps (not the freshly packed stream: no ordering inside one launch).
+constexpr int kPackModels = 2;
+struct PackJob { ParamPtrs pp; float* blob; float* aux; };
+struct PackJobs { PackJob j[kPackModels]; };
+__global__ void __launch_bounds__(256) pack_all_kernel(const uint32_t* __restrict__ blob_idx, long nb, const uint32_t* __restrict__ aux_idx,
+                                                       long na, int use_voxel, const PackJobs jobs) {
+  const PackJob& job = jobs.j[blockIdx.y];
+  const long nbB = (nb + 255) / 256, naB = (na + 255) / 256;
+  long b = blockIdx.x;
+  if (b < nbB) {
+    const long i = b * 256 + threadIdx.x;
+    if (i < nb) job.blob[i] = pack_fetch(job.pp, blob_idx[i]);
+    return;
+  }
+  b -= nbB;
+  if (b < naB) {
+    const long i = b * 256 + threadIdx.x;
+    if (i < na) job.aux[i] = pack_fetch(job.pp, aux_idx[i]);
+    return;
+  }
+  b -= naB;
+  const long t = b * 256 + threadIdx.x;
+  float* wm = job.aux + kAuxFloats;
+  if (t < 64L * kRayBiasFloats) {
+    const int c = (int)(t / kRayBiasFloats), o = (int)(t % kRayBiasFloats);
+    const long src = rb_matrix_src(use_voxel != 0, o, c);
+    wm[((long)(o >> 4) * 64 + c) * 16 + (o & 15)] = src < 0 ? 0.f : pack_fetch(job.pp, blob_idx[src]);
+  } else if (t < 65L * kRayBiasFloats) {
+    const int o = (int)(t - 64L * kRayBiasFloats);
+    wm[kRbGroups * 64 * 16 + o] = pack_fetch(job.pp, aux_idx[rb_bias_src(o)]);
+  }
 }
 
 }  // namespace objnerf
@@ -1390,22 +1432,34 @@ int objnerf_composite_multi(const objnerf_composite_multi_args* a, void* stream)
   return check_launch("composite_multi");
 }
 
+int objnerf_pack_models(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx, int n_models,
+                        const float* const* h_param_ptrs, float* const* h_blobs, float* const* h_auxs, void* stream) {
+  if (!blob_idx || !aux_idx || !h_param_ptrs || !h_blobs || !h_auxs) return set_error(-1, "pack_models: bad arguments");
+  if (n_models < 1 || n_models > kPackModels) return set_error(-1, "pack_models: 1 <= n_models <= 2");
+  PackJobs jobs;
+  for (int m = 0; m < n_models; ++m) {
+    for (int i = 0; i < kNumParamPtrs; ++i) {
+      if (!h_param_ptrs[m * kNumParamPtrs + i]) return set_error(-1, "pack_models: null parameter pointer");
+      jobs.j[m].pp.p[i] = h_param_ptrs[m * kNumParamPtrs + i];
+    }
+    if (!h_blobs[m] || !h_auxs[m]) return set_error(-1, "pack_models: null output");
+    jobs.j[m].blob = h_blobs[m];
+    jobs.j[m].aux = h_auxs[m];
+  }
+  for (int m = n_models; m < kPackModels; ++m) jobs.j[m] = jobs.j[0];
+  const long nb = objnerf_blob_floats(use_voxel), na = kAuxFloats;       // the tail of the aux block is the compact matrix
+  const unsigned blocks = blocks_for(nb, 256) + blocks_for(na, 256) + blocks_for(65L * kRayBiasFloats, 256);
+  hipLaunchKernelGGL(pack_all_kernel, dim3(blocks, (unsigned)n_models), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, aux_idx, na,
+                     use_voxel, jobs);
+  return check_launch("pack_models");
+}
+
 int objnerf_pack_weights(int use_voxel, const uint32_t* blob_idx, const uint32_t* aux_idx,
                          const float* const* h_param_ptrs, float* blob, float* aux, void* stream) {
-  if (!blob_idx || !aux_idx || !h_param_ptrs || !blob || !aux) return set_error(-1, "pack_weights: bad arguments");
-  ParamPtrs pp;
-  for (int i = 0; i < kNumParamPtrs; ++i) {
-    if (!h_param_ptrs[i]) return set_error(-1, "pack_weights: null parameter pointer");
-    pp.p[i] = h_param_ptrs[i];
-  }
-  const long nb = objnerf_blob_floats(use_voxel), na = objnerf_aux_floats();
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(nb, 256)), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, pp, blob);
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(na, 256)), dim3(256), 0, (hipStream_t)stream, aux_idx, na, pp, aux);
-  // behind the aux block: the hoisted weight columns as the compact matrix objnerf_ray_bias reads (once per parameter
-  // version instead of once per call)
-  RayBiasArgs a{blob, aux, nullptr, nullptr, 0, 0, use_voxel, 1, 1, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(ray_bias_weights_kernel, dim3(64), dim3(448), 0, (hipStream_t)stream, a, aux + kAuxFloats);
-  return check_launch("pack_weights");
+  if (!blob || !aux) return set_error(-1, "pack_weights: bad arguments");
+  float* blobs[1] = {blob};
+  float* auxs[1] = {aux};
+  return objnerf_pack_models(use_voxel, blob_idx, aux_idx, 1, h_param_ptrs, blobs, auxs, stream);
 }
 
 int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream) {

@@ -92,11 +92,6 @@ __device__ __forceinline__ void wgrad_tail_piece(const WgProduct& pr, const WgTi
 // tile keeps a wave's two 32-column sub-tiles 64 floats apart so that one ds_read2st64_b32 with immediate offsets fetches both
 // operands of a k step, and the tile is double-buffered: ONE barrier per k tile, the next tile's registers -> LDS copy and the
 // fetch after next issue at the head of the MFMA burst.  64 KB of LDS: two workgroups per CU.
-// Timing ablations (tools/, results are wrong when set): OBJ_ABL bits: 1 no global loads, 2 no registers -> LDS copy, 4 no
-// barrier, 8 no fragment reads, 16 no MFMAs, 32 every k tile re-reads the first one (operands from cache)
-#ifndef OBJ_ABL
-#define OBJ_ABL 0
-#endif
 // 16-byte load at (uniform base) + (per-lane 32-bit byte offset) inside the branch-free k loops.  The empty asm only keeps the
 // zero-extension of the offset from being hoisted out of the loop as a 64-bit register pair (the address would then need a
 // 64-bit VALU add per load); it emits no instruction and hides nothing from the wait-count pass.
@@ -136,7 +131,6 @@ struct WgOperand {             // one operand of a full tile: 128 columns ("rows
   // Piece i of the k tile that starts krem points before the end of the slice (32-bit counters: the SALU has no 64-bit ordered
   // compare).  The contraction range must be zero-filled in BOTH operands (0 x garbage could be NaN): a ragged last tile only.
   __device__ __forceinline__ void fetch_piece(int i, int krem, int tid) {
-    if (OBJ_ABL & 1) return;
     if (fast && krem >= GBK) {                 // uniform
       v[i] = aligned ? gload4((const float*)(base + off[i])) : gload4u((const float*)(base + off[i]));
     } else {
@@ -149,14 +143,13 @@ struct WgOperand {             // one operand of a full tile: 128 columns ("rows
       }
     }
   }
-  __device__ __forceinline__ void advance() { if (!(OBJ_ABL & 32)) base += step; }       // after the four pieces of a k tile
+  __device__ __forceinline__ void advance() { base += step; }       // after the four pieces of a k tile
   __device__ __forceinline__ void fetch(int krem, int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) fetch_piece(i, krem, tid);
     advance();
   }
   __device__ __forceinline__ void put_piece(int i, float* tile, int tid) const {
-    if (OBJ_ABL & 2) return;
     *(f32x4*)&tile[((tid >> 5) + 8 * i) * GLDR + wg_pos(4 * (tid & 31))] = v[i];
   }
   __device__ __forceinline__ void put(float* tile, int tid) const {
@@ -164,7 +157,7 @@ struct WgOperand {             // one operand of a full tile: 128 columns ("rows
     for (int i = 0; i < 4; ++i) put_piece(i, tile, tid);
   }
 };
-#define OBJ_WG_SYNC() do { if (!(OBJ_ABL & 4)) __syncthreads(); } while (0)
+#define OBJ_WG_SYNC() __syncthreads()
 
 __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgTile& tl, long kbeg, long kend,
                                                  float* slot, float* lds, int tid, long P) {
@@ -207,7 +200,7 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
     const float* Bs = As + WTILE;
     float* An = lds + (buf ^ 1) * 2 * WTILE;
     float* Bn = An + WTILE;
-    if (want_rowsum && !(OBJ_ABL & 8)) { // thread -> row tid % 128, 16 of the 32 k
+    if (want_rowsum) { // thread -> row tid % 128, 16 of the 32 k
       float s16 = 0.f;                   // (rsum keeps its own chain of additions: the bias gradients stay bit-equal)
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) { const float x = As[roff + kk * GLDR]; rsum += x; s16 += x; }
@@ -221,7 +214,6 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
     float fa[2][2][4], fb[2][2][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (OBJ_ABL & 8) { fa[0][0][s] = fa[0][1][s] = fb[0][0][s] = fb[0][1][s] = (float)(tid + s); continue; }
       fa[0][0][s] = As[aoff + s * GLDR]; fa[0][1][s] = As[aoff + s * GLDR + 64];
       fb[0][0][s] = Bs[boff + s * GLDR]; fb[0][1][s] = Bs[boff + s * GLDR + 64];
     }
@@ -239,10 +231,8 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
         // the scalar-base addressing form (global_load_dwordx4 v, v_off, s[base:base+1]): no per-load VALU address arithmetic.
         opa.put_piece(s4, An, tid);
         opb.put_piece(s4, Bn, tid);
-        if (!(OBJ_ABL & 1)) {
-          opa.v[s4] = steady_load(opa.base, opa.off[s4]);
-          opb.v[s4] = steady_load(opb.base, opb.off[s4]);
-        }
+        opa.v[s4] = steady_load(opa.base, opa.off[s4]);
+        opb.v[s4] = steady_load(opb.base, opb.off[s4]);
       } else if (krem > GBK) {           // uniform
         opa.put_piece(s4, An, tid);
         opb.put_piece(s4, Bn, tid);
@@ -251,7 +241,7 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
           opb.fetch_piece(s4, krem - 2 * GBK, tid);
         }
       }
-      if (s4 < 3 && !(OBJ_ABL & 8)) {
+      if (s4 < 3) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int kk = 4 * (s4 + 1) + s;
@@ -260,18 +250,13 @@ __device__ __forceinline__ void wgrad_full_piece(const WgProduct& prv, const WgT
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(OBJ_ABL & 16)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[(OBJ_ABL & 8) ? 0 : (s4 & 1)][i][s], fb[(OBJ_ABL & 8) ? 0 : (s4 & 1)][j][s], acc[2 * i + j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s][0] += fa[s4 & 1][0][s] + fa[s4 & 1][1][s] + fb[s4 & 1][0][s] + fb[s4 & 1][1][s];
-      }
+          for (int j = 0; j < 2; ++j)
+            acc[2 * i + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s4 & 1][i][s], fb[s4 & 1][j][s], acc[2 * i + j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (STEADY || krem > 2 * GBK) { opa.advance(); opb.advance(); }

@@ -17,6 +17,7 @@ import torch
 from . import _lib
 from .bbox import pack_boxes
 from .embedding_helper import EmbeddingVoxel
+from .nerf_model import pack_models
 from .rendering import _linspace, hoist_enabled
 
 __all__ = ["render_rays_multi"]
@@ -118,14 +119,12 @@ def render_rays_multi(
     rin.h_rays, rin.h_obj_ids = h_rays, h_ids
     if table is not None:
         rin.code_table = table.data_ptr()
-    bc, ac = coarse.packed()
-    rin.blob_coarse, rin.aux_coarse = bc.data_ptr(), ac.data_ptr()
-    keep = [rays_c, table, ws, bc, ac, boxes]
+    packs = pack_models([coarse] + ([models["fine"]] if I > 0 else []))        # one launch, nothing cached
+    rin.blob_coarse, rin.aux_coarse = packs[0][0].data_ptr(), packs[0][1].data_ptr()
+    keep = [rays_c, table, ws, packs, boxes]
     if I > 0:
-        bf, af = models["fine"].packed()
-        rin.blob_fine, rin.aux_fine = bf.data_ptr(), af.data_ptr()
+        rin.blob_fine, rin.aux_fine = packs[1][0].data_ptr(), packs[1][1].data_ptr()
         rin.u_det = _linspace(I, dev).data_ptr()
-        keep += [bf, af]
         if perturb != 0:                      # sample_pdf(det=False) draws torch.rand per set (rendering.py:40)
             if _randoms and "u_rand" in _randoms:
                 u = _randoms["u_rand"]

@@ -10,16 +10,14 @@ Kept from the reference so checkpoints and callers interoperate
     returning the same dict keys.
 
 Different by design: the module never multiplies anything in PyTorch.  Its parameters are
-gathered once per parameter version into the MFMA operand stream (`packed()`), and both forward
-methods enqueue the HIP kernel (csrc/mlp_kernel.h) on the current stream.  That persistent kernel is
+gathered into the MFMA operand stream at EVERY call (`packed()` / `pack_models()`: one ~8 us launch,
+no cache to go stale), and both forward methods enqueue the HIP kernel (csrc/mlp_kernel.h) on the current stream.  That persistent kernel is
 specialised for the architecture every shipped reference config uses (config/default_conf.yml:7-36);
 any other `config.model` shape (D, W, skips, inst_*, N_freq_*, voxel channels, code length) is built
 too and runs layer by layer on the fp32 MFMA GEMM (csrc/generic.hip, object_nerf_amd/generic.py):
 inference only, slower, still no PyTorch arithmetic.
 """
 import ctypes as C
-import os
-import weakref
 
 import torch
 from torch import nn
@@ -34,35 +32,11 @@ PARAM_LAYERS = _SCENE_LAYERS + _OBJ_LAYERS
 
 _index_cache = {}   # (use_voxel, device) -> (blob_idx, aux_idx) uint32 device tensors
 
-# Parameter updates that do not bump `Tensor._version`: torch's FUSED optimizers (`Adam(fused=True)` writes the parameters
-# inside one multi-tensor kernel; measured: `_version` stays put, torch 2.10) -- the cached weight streams would go stale
-# silently.  A step of a torch.optim.Optimizer therefore advances the epoch of every live ObjectNeRF THAT OPTIMIZER OWNS A
-# PARAMETER OF (the epoch is part of the module's cache key; a re-gather costs a few microseconds of device time).  Steps of
-# optimizers that hold none of a module's parameters leave its cache alone (round 4 bumped one process-wide counter).
-_live_models = weakref.WeakSet()
-_optimizer_param_ids = weakref.WeakKeyDictionary()      # optimizer -> (number of parameters, frozenset of their ids)
-
-
-def _on_optimizer_step(optimizer, *_args, **_kwargs):
-    try:
-        n = sum(len(g["params"]) for g in optimizer.param_groups)
-        cached = _optimizer_param_ids.get(optimizer)
-        if cached is None or cached[0] != n:
-            cached = (n, frozenset(id(p) for g in optimizer.param_groups for p in g["params"]))
-            _optimizer_param_ids[optimizer] = cached
-        ids = cached[1]
-    except Exception:                   # an optimizer we cannot introspect: be safe, invalidate every model
-        ids = None
-    for m in list(_live_models):
-        if ids is None or not ids.isdisjoint(m._param_ids()):
-            m._opt_epoch += 1
-
-
-try:
-    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
-    _register_step_hook(_on_optimizer_step)
-except ImportError:      # older torch: `_version` / invalidate_packed() are the only signals
-    pass
+# The weight streams are NOT cached (round 6).  Rounds 1-5 keyed a cache on (data_ptr, _version) of every parameter plus an
+# optimizer-step hook -- and each round found another writer the key could not see: torch's fused optimizers (no `_version`
+# bump), `.data` writes, optimizer steps replayed from a captured graph, deep-copied modules carrying the original's parameter
+# ids.  A stale stream renders a wrong image without an error; the gather it saved is one launch of ~8 us (both models of a
+# render_rays call together, objnerf_pack_models).  The gather is part of every call and is captured with it in a CUDA graph.
 
 
 def _pack_index(use_voxel, device):
@@ -89,6 +63,43 @@ def _pack_index_bwd(use_voxel, device):
 
 def _linear_act(i, o, act):
     return nn.Sequential(nn.Linear(i, o), act)
+
+
+def pack_models(models):
+    """[(blob, aux)] for a list of fused-architecture ObjectNeRF modules: the MFMA operand stream + aux block (biases, heads,
+    compact matrix of the hoisted columns) of each, gathered from the parameters AS THEY ARE NOW on the current stream.  Two
+    modules of one mode on one device (the coarse and fine model of a render_rays call) share ONE launch (objnerf_pack_models)."""
+    out = [None] * len(models)
+    groups = {}
+    for i, m in enumerate(models):
+        params = m._param_list()
+        _lib.require_cuda(params[0], "ObjectNeRF parameters")
+        groups.setdefault((int(m.use_voxel_embedding), params[0].device), []).append((i, params))
+    l = _lib.lib()
+    n = l.objnerf_num_param_ptrs()
+    for (uv, dev), items in groups.items():
+        bi, ai = _pack_index(uv, dev)
+        nb, na = l.objnerf_blob_floats(uv), l.objnerf_aux_floats()
+        for lo in range(0, len(items), 2):
+            part = items[lo:lo + 2]
+            srcs, outs = [], []
+            for _, params in part:
+                assert n == len(params)
+                for j, p in enumerate(params):
+                    if p.numel() != l.objnerf_param_numel(uv, j):
+                        raise RuntimeError("ObjectNeRF parameter %d has %d elements, kernel layout expects %d"
+                                           % (j, p.numel(), l.objnerf_param_numel(uv, j)))
+                    srcs.append(_lib.as_f32(p.detach()))
+                outs.append((torch.empty(nb, dtype=torch.float32, device=dev), torch.empty(na, dtype=torch.float32, device=dev)))
+            table = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+            blobs = (C.c_void_p * len(part))(*[o[0].data_ptr() for o in outs])
+            auxs = (C.c_void_p * len(part))(*[o[1].data_ptr() for o in outs])
+            with torch.cuda.device(dev):
+                _lib.check(l.objnerf_pack_models(uv, _lib.ptr(bi), _lib.ptr(ai), len(part), table, blobs, auxs, _lib.stream_ptr()),
+                           "pack_models")
+            for (i, _), o in zip(part, outs):
+                out[i] = o
+    return out
 
 
 class ObjectNeRF(nn.Module):
@@ -146,94 +157,30 @@ class ObjectNeRF(nn.Module):
         self.inst_dir_encoding = _linear_act(self.inst_W + self.in_channels_dir, self.inst_W // 2, self.activation)
         self.inst_rgb = nn.Sequential(nn.Linear(self.inst_W // 2, 3), nn.Sigmoid())
 
-        self._packed = None
-        self._packed_key = None
-        self._packed_bwd = None
-        self._packed_bwd_key = None
-        self._opt_epoch = 0                 # advanced by steps of optimizers that own one of this module's parameters
-        self._param_id_cache = None
-        _live_models.add(self)
 
     # ---- weight stream ---------------------------------------------------------------------
     def invalidate_packed(self):
-        """Drops the cached weight streams.  They are re-gathered automatically when a parameter's
-        (data_ptr, _version) changes -- optimizer steps, load_state_dict, .to() -- but in-place writes made through
-        `.data` (`p.data.copy_(w)`, EMA / weight-clipping code, some manual checkpoint loaders) do not bump
-        `_version`: call this after them.  (Steps of any torch.optim.Optimizer -- fused ones included, which do not bump
-        `_version` either -- are seen through a global step hook, and the differentiable render_rays re-gathers on every
-        call.)  OBJNERF_PACK_CHECK=1 adds a content checksum to the cache key (one small
-        reduction + host read per parameter set and call: a debugging aid, not for production)."""
-        self._packed = self._packed_key = None
-        self._packed_bwd = self._packed_bwd_key = None
-        self._param_id_cache = None
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self.invalidate_packed()
-        return super()._load_from_state_dict(*args, **kwargs)
-
-    def _apply(self, fn, *args, **kwargs):
-        self.invalidate_packed()
-        return super()._apply(fn, *args, **kwargs)
-
-    def _param_ids(self):
-        if self._param_id_cache is None:
-            self._param_id_cache = frozenset(id(p) for p in self.parameters())
-        return self._param_id_cache
-
-    def _pack_key(self, params):
-        _live_models.add(self)          # (also modules that were unpickled / deep-copied: __init__ did not run for them)
-        key = tuple((p.data_ptr(), p._version) for p in params) + (getattr(self, "_opt_epoch", 0),)
-        if os.environ.get("OBJNERF_PACK_CHECK") == "1":
-            with torch.no_grad():
-                key += (float(sum(p.detach().double().sum() for p in params)),)
-        return key
+        """No-op, kept for callers written against rounds 1-5 (which cached the weight streams per parameter version and
+        needed this after `.data` writes): the streams are re-gathered from the parameters at every call."""
 
     def _param_list(self):
         if not self.fused_architecture:
             raise RuntimeError("ObjectNeRF: the packed weight stream exists for the default architecture only (internal error: "
                                "a non-default shape must take the layer-wise path, object_nerf_amd/generic.py)")
-        mods = dict(self.named_modules())
         out = []
         for name in PARAM_LAYERS:
-            m = mods[name]
+            m = self.get_submodule(name)
             out += [m.weight, m.bias]
         return out
 
     def packed(self):
-        """(blob, aux) device tensors for the kernel; re-gathered when any parameter changed
-        (optimizer step, load_state_dict, .to()) -- keyed on (data_ptr, _version) + the module's optimizer-step epoch."""
-        params = self._param_list()
-        key = self._pack_key(params)
-        if self._packed is not None and key == self._packed_key:
-            return self._packed
-        dev = params[0].device
-        _lib.require_cuda(params[0], "ObjectNeRF parameters")
-        l = _lib.lib()
-        uv = int(self.use_voxel_embedding)
-        n = l.objnerf_num_param_ptrs()
-        assert n == len(params)
-        srcs = []
-        for i, p in enumerate(params):
-            if p.numel() != l.objnerf_param_numel(uv, i):
-                raise RuntimeError("ObjectNeRF parameter %d has %d elements, kernel layout expects %d"
-                                   % (i, p.numel(), l.objnerf_param_numel(uv, i)))
-            srcs.append(_lib.as_f32(p.detach()))
-        bi, ai = _pack_index(uv, dev)
-        blob = torch.empty(l.objnerf_blob_floats(uv), dtype=torch.float32, device=dev)
-        aux = torch.empty(l.objnerf_aux_floats(), dtype=torch.float32, device=dev)
-        table = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
-        _lib.check(l.objnerf_pack_weights(uv, _lib.ptr(bi), _lib.ptr(ai), table, _lib.ptr(blob), _lib.ptr(aux),
-                                          _lib.stream_ptr()), "pack_weights")
-        self._packed, self._packed_key = (blob, aux), key
-        return self._packed
+        """(blob, aux) device tensors for the kernels, gathered from the parameters as they are NOW (on the current stream)."""
+        return pack_models([self])[0]
 
     def packed_bwd(self):
         """Training only: device tensor with the transposed hidden-block weight stream of the fused backward
-        (objnerf_pack_weights_bwd), re-gathered like `packed()` when a parameter changed."""
+        (objnerf_pack_weights_bwd), gathered from the parameters as they are now."""
         params = self._param_list()
-        key = self._pack_key(params)
-        if self._packed_bwd is not None and key == self._packed_bwd_key:
-            return self._packed_bwd
         dev = params[0].device
         _lib.require_cuda(params[0], "ObjectNeRF parameters")
         l = _lib.lib()
@@ -242,7 +189,6 @@ class ObjectNeRF(nn.Module):
         blob = torch.empty(l.objnerf_bwd_blob_floats(), dtype=torch.float32, device=dev)
         table = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
         _lib.check(l.objnerf_pack_weights_bwd(_lib.ptr(idx), table, _lib.ptr(blob), _lib.stream_ptr()), "pack_weights_bwd")
-        self._packed_bwd, self._packed_bwd_key = blob, key
         return blob
 
     # ---- reference-compatible forward passes (pre-embedded inputs) -------------------------------

@@ -19,6 +19,7 @@ import torch
 
 from . import _lib
 from .embedding_helper import Embedding, EmbeddingVoxel
+from .nerf_model import pack_models
 
 __all__ = ["render_rays", "sample_pdf"]
 
@@ -121,15 +122,10 @@ def _train_packs(coarse, fine):
     if mode == "1":
         return None
 
-    # a training call never trusts the cache: whatever updated the parameters since the last call (a fused or third-party
-    # optimizer, `.data` writes) may not have bumped `_version`, and the weights change every step anyway
-    for m in {id(m): m for m in (coarse, fine) if m is not None}.values():
-        m.invalidate_packed()
-
     def one(m):
         if m is None:
             return None
-        blob, aux = m.packed()
+        blob, aux = m.packed()          # gathered from the parameters as they are now (nothing is cached)
         return (None if mode == "fwd" else blob, aux, None if mode == "bwd" else m.packed_bwd())
     return (one(coarse), one(fine))
 
@@ -281,11 +277,12 @@ def render_rays(
         ptm = pass_through_mask.reshape(n).to(torch.uint8).contiguous()
         rin.pass_through_mask = ptm.data_ptr()
         keep.append(ptm)
-    bc, ac = coarse.packed()
-    rin.blob_coarse, rin.aux_coarse = bc.data_ptr(), ac.data_ptr()
+    # both models' weight streams, gathered from the parameters as they are now, in one launch (nothing is cached)
+    packs = pack_models([coarse] + ([models["fine"]] if I > 0 else []))
+    keep.append(packs)
+    rin.blob_coarse, rin.aux_coarse = packs[0][0].data_ptr(), packs[0][1].data_ptr()
     if I > 0:
-        bf, af = models["fine"].packed()
-        rin.blob_fine, rin.aux_fine = bf.data_ptr(), af.data_ptr()
+        rin.blob_fine, rin.aux_fine = packs[1][0].data_ptr(), packs[1][1].data_ptr()
     if use_voxel:
         rin.grid = emb_xyz.grid_struct()
     rin.z_steps = _linspace(S, dev).data_ptr()

@@ -158,6 +158,38 @@ def full_frame(ref, scene):
     save("full_frame_toydesk2", out)
 
 
+def coarse_f64(ref, scene):
+    """Coarse-pass attribution vectors (round 6, tools/frame_parity.py --coarse): for the two single-ray-set 160x120 frames
+    the float64 oracle's coarse maps themselves (frame_*.npz holds the reference's maps and only the DISTANCE to float64),
+    and for the 640x480 configs[1] frame the coarse maps of every FULL_FRAME["sub"]-th pixel from the real reference (the
+    coarse pass does not depend on N_importance: rendered with N_importance=0) next to the float64 oracle's.  With both,
+    dist(ours, float64) can be set beside dist(reference, float64): which of the two fp32 computations is the noisier one."""
+    import helpers as H
+    from oracle import objnerf_oracle as O
+    out = {}
+    todo = [(c, cases.frame_inputs(c), None) for c in ("frame_toydesk2", "frame_scannet_multi")]
+    todo.append(("full_frame_toydesk2_sub", cases.full_frame_inputs(), cases.FULL_FRAME["sub"]))
+    for name, (rays, ids, kw, sname), sub in todo:
+        if sub:
+            rays, ids = rays[::sub].contiguous(), ids[::sub].contiguous()
+        sc = scene(sname)
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        kw = dict(kw, N_importance=0)
+        r = dict(ref.render_rays(sc.models, sc.embeddings, rays, embedding_instance=codes, chunk=32768, **kw))
+        f64 = _f64_oracle(O.render_rays, _dbl(H.state(sc.models["coarse"])), _dbl(H.state(sc.models["fine"])),
+                          _dbl(H.oracle_grid(sc.embeddings["xyz"])), rays.double(), embedding_instance=codes.double(), **kw)
+        for m in cases.FRAME_MAPS:
+            k = m + "_coarse"
+            out["%s__%s" % (name, k)] = r[k]
+            out["%s__%s_f64" % (name, k)] = f64[k]
+            print(name, k, "reference vs float64: max-norm %.2e, rel L2 %.2e" % (H.normwise(r[k], f64[k]), H.rel_l2(r[k], f64[k])))
+        if not sub:        # the coarse maps of a full render (frame_*.npz) are the maps of this coarse-only render
+            g = cases.load_golden(name)
+            for m in cases.FRAME_MAPS:
+                assert torch.equal(g[m + "_coarse"], r[m + "_coarse"]), (name, m)
+    save("coarse_f64", out)
+
+
 def multi_training_mode(ref, scene):
     """render_rays_multi in training mode (perturb != 0, noise_std != 0; multi_rendering.py:186-190, 126, 272-274) with the
     draws of cases.multi_randoms() injected in call order: randn_like (coarse compositing), rand x K (sample_pdf per set),
@@ -272,6 +304,10 @@ def main():
             multi_training_mode(ref, scene)
         other_architectures(ref, scene)
         return
+    if "--coarse-f64" in sys.argv:  # only the coarse-pass attribution vectors (a minute of CPU)
+        with torch.no_grad():
+            coarse_f64(ref, scene)
+        return
     if "--full-frame" in sys.argv:   # only the 640x480 frame (about five minutes of CPU)
         with torch.no_grad():
             full_frame(ref, scene)
@@ -280,6 +316,7 @@ def main():
     with torch.no_grad():
         frames(ref, scene)
         full_frame(ref, scene)
+        coarse_f64(ref, scene)
         sigma_grids(ref, scene)
         # ---- render_rays end to end ----
         for case, c in cases.RENDER_CASES.items():

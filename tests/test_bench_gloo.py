@@ -173,3 +173,41 @@ def test_self_launch_starts_every_rank_and_propagates_failures(tmp_path):
     if not torch.cuda.is_available():
         with pytest.raises(SystemExit, match="GPU"):
             bench.main(["--gpus", "2"])
+
+
+def test_a_failing_run_ends_in_one_json_error_line(tmp_path):
+    """round 6: whatever goes wrong on whatever rank, the process's LAST stdout line is one JSON object with
+    `error`, `rank`, `n_gpus` and the phase, and the exit is immediate and non-zero -- (a) an exception / SystemExit inside run(),
+    (b) a stalled phase (the heartbeat's limit), (c) a self-launched job whose rank fails."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", RANK="2", WORLD_SIZE="4", LOCAL_RANK="2")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "needs a GPU" in rec["error"] and rec["rank"] == 2 and rec["n_gpus"] == 4 and rec["value"] is None
+    # (b) the stall detector: a phase that never ends
+    stall = tmp_path / "stall.py"
+    stall.write_text("import sys, time\nsys.path.insert(0, %r)\nimport bench\nprint('banner', flush=True)\n"
+                     "bench.Heartbeat.beat('all_gather that never returns')\nbench.Heartbeat.start(2)\ntime.sleep(60)\n" % root)
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(stall)], env=dict(os.environ, RANK="5", WORLD_SIZE="8"), capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode == 3 and time.time() - t0 < 50
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "no progress" in rec["error"] and rec["phase"] == "all_gather that never returns" and rec["rank"] == 5 and rec["n_gpus"] == 8
+    # (c) self-launch: the failing rank's code comes back, with an error line as the launcher's last stdout line
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\nif os.environ['RANK'] == '1': os.kill(os.getpid(), 6)\ntime.sleep(30)\n")
+    launcher = tmp_path / "launch.py"
+    launcher.write_text(
+        "import sys\nsys.path.insert(0, %r)\nimport bench\n"
+        "bench.self_launch_or_die(bench.parse(['--gpus', '2', '--one-gpu']), [], cmd=[sys.executable, %r])\n" % (root, str(child)))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(launcher)], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and time.time() - t0 < 25
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "exited with code" in rec["error"] and rec["phase"] == "self_launch"

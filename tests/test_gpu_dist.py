@@ -160,6 +160,29 @@ def test_default_eight_rank_line_on_one_gpu():
     assert ts["phases_ms"]["gradient_exchange_ms"] > 0 and "all-reduce" in ts["gradient_exchange"]
 
 
+def test_ddp_wrapper_equals_gradient_sync():
+    """what the reference's trainer instantiates (train.py:261-262: Lightning `accelerator="ddp"` = torch's
+    DistributedDataParallel around the module that owns the models): two ranks on this box's one GPU over gloo, one training step
+    of the drop-in modules under DDP against the same step + GradientSync -- bit-equal averaged gradients for both MLPs and the
+    codes, the voxel table (atomic scatter) to 1e-5, a second DDP step after a fused Adam step (tests/ddp_one_gpu_worker.py)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_one_gpu_worker.py"), str(r), "2", str(port)], env=e,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d: %s" % (r, se[-3000:])
+    assert "ddp ok" in outs[0][0]
+
+
 def test_gradient_sync_over_rccl_world1():
     """the collective path of data-parallel training on the GPU: flat buckets, asynchronous all-reduces over RCCL, the voxel
     table exchanged as its active-row prefix; with one rank the mean over ranks is the identity"""

@@ -204,8 +204,8 @@ class _DataSGD:
 @pytest.mark.parametrize("kind", ["adam_foreach", "adam_fused", "data_writes"])
 def test_training_step_updates_weights_and_repacks(kind):
     """an optimizer step on the HIP gradients changes the render, through the automatic weight repack -- also when the
-    optimizer does not bump `Tensor._version` (torch's fused Adam: measured; `.data` writes): the training path re-gathers the
-    weight stream on every call, and inference after a torch optimizer's step sees it through the global step hook"""
+    optimizer does not bump `Tensor._version` (torch's fused Adam: measured; `.data` writes): every call -- training or
+    inference -- gathers the weight stream from the parameters as they are (round 6: no cache, no step hook, no invalidate_packed())"""
     sc = cases.scene_for(A, "plain", device=DEV)
     rays = H.test_rays(32).to(DEV)
     ids = synth.per_ray_ids(32).to(DEV)
@@ -227,9 +227,6 @@ def test_training_step_updates_weights_and_repacks(kind):
         return loss.item()
     losses = [step() for _ in range(8)]
     assert losses[-1] < losses[0]
-    if kind == "data_writes":      # the one case the INFERENCE cache cannot see by itself (documented): invalidate_packed()
-        for m in (sc.models["coarse"], sc.models["fine"]):
-            m.invalidate_packed()
     with torch.no_grad():      # inference path sees the updated parameters (re-packed weight stream)
         codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
         r_inf = A.render_rays(sc.models, sc.embeddings, rays, N_samples=16, N_importance=16, perturb=0, noise_std=0,
