@@ -592,10 +592,8 @@ def run(args, renderer=None, backend="nccl", argv=None):
                                "launches": int(launches.value), "avg_launch_ms": kms.value / max(1, launches.value),
                                "flop_per_eval": wl.flop_per_eval if wl.flop_per_eval else {"scene": FLOP_SCENE, "object": FLOP_OBJECT},
                                "flop_per_launch_avg": flop / max(1, launches.value), "mlp_time_frac_of_step": mlp_s / (t1 - t0),
-                               # what `traffic` is to be held against: z 4 + local weights 4 + segment records 2 + per-ray vectors 19 +
-                               # rays / codes 3 bytes per evaluated sample point
-                               "algorithmic_bytes_per_launch_avg": 32.0 * wl.evals_rank * args.steps / max(1, launches.value),
                                "measured_on": "rank 0"}
+            res["roofline"].update(algorithmic_bytes(wl, args.steps, max(1, launches.value)))
             from object_nerf_amd.rendering import composite_mode, hoist_enabled
             if hoist_enabled():
                 res["roofline"]["hoisting"] = (
@@ -644,6 +642,15 @@ def run(args, renderer=None, backend="nccl", argv=None):
             gc.collect()
             torch.cuda.empty_cache()
         res["roofline"].update(pmc_traffic(args, cfg_id, live=live))
+        rf = res["roofline"]
+        if rf.get("traffic"):
+            rf["traffic_over_survey_8d_bytes"] = rf["traffic"] / rf["algorithmic_bytes_per_launch_avg"]["survey_8d"]
+            rf["traffic_over_survey_plus_workspace_bytes"] = rf["traffic"] / rf["algorithmic_bytes_per_launch_avg"]["total"]
+            rf["traffic_rate_GBps"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+            rf["traffic_reading"] = ("%.1f x the bytes SURVEY 8d counts for this path, %.1f x those plus the per-ray workspace this design "
+                                     "added; %.1f GB/s against ~8,000: the kernel is MFMA-bound and this traffic bounds nothing"
+                                     % (rf["traffic_over_survey_8d_bytes"], rf["traffic_over_survey_plus_workspace_bytes"],
+                                        rf["traffic_rate_GBps"]))
     # RCCL prints its version banner through C stdio at communicator creation; into a pipe or a file that buffer is only
     # written at process exit, i.e. AFTER the line below.  Every rank flushes it, then a barrier, then rank 0 prints: the JSON
     # object is the last stdout line of the job.
@@ -659,6 +666,26 @@ def run(args, renderer=None, backend="nccl", argv=None):
         if backend == "nccl" or not os.environ.get("OBJNERF_BENCH_KEEP_PG"):
             dist.destroy_process_group()
     return res
+
+
+def algorithmic_bytes(wl, steps, launches):
+    """What `roofline.traffic` is to be held against, per launch of the MLP kernel, split honestly:
+      survey_8d        -- the bytes SURVEY.md 8d counts for this path once compositing is fused into the kernel: depths read (4 B) and
+                          local weights written (4 B) per evaluated sample point, the ray (32 B) and -- object branch -- its code
+                          (256 B) per ray and pass;
+      design_workspace -- bytes only THIS design moves: the per-ray hoist vectors (448 floats per ray and pass, written by
+                          objnerf_ray_bias and read once by the kernel) and the 64-byte segment record per 32 samples that carries
+                          the compositing state to composite_finish."""
+    from object_nerf_amd.rendering import composite_mode, hoist_enabled
+    evals = float(wl.evals_rank) * steps
+    per_ray = wl.S + (wl.S + wl.I if wl.I > 0 else 0)
+    ray_passes = evals / per_ray * (2 if wl.I > 0 else 1)
+    has_obj = wl.flop_per_eval != FLOP_SCENE if wl.flop_per_eval else True
+    survey = 8.0 * evals + ray_passes * (32.0 + (256.0 if has_obj else 0.0))
+    design = (2.0 * evals if composite_mode() == "fused" else 0.0) + (ray_passes * 448 * 4.0 if hoist_enabled() else 0.0)
+    return {"algorithmic_bytes_per_launch_avg": {"survey_8d": survey / launches, "design_workspace": design / launches,
+                                                 "total": (survey + design) / launches,
+                                                 "per_eval": {"survey_8d": survey / evals, "design_workspace": design / evals}}}
 
 
 def backend_name(backend):
@@ -732,7 +759,14 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend="nccl
         fused = torch.device(dev).type == "cuda" and os.environ.get("OBJNERF_BENCH_ADAM", "fused") == "fused"
         opt = torch.optim.Adam(params, lr=1e-3, fused=fused)
         table = sc.embeddings["xyz"].embedding_space_ftr.weight
-        sync = GradientSync(params, active_rows={table: sc.embeddings["xyz"].active_rows()})
+        # buckets in the order the gradients become final: fine model (its node's backward runs first), coarse model, then what both
+        # passes feed (codes, voxel table as its active-row prefix); attach(): a bucket's all-reduce starts from the gradient hooks
+        # as soon as it is complete -- the fine model's while the coarse node's backward runs (round 6, object_nerf_amd/autograd.py)
+        groups = [list(sc.models["fine"].parameters()), list(sc.models["coarse"].parameters()),
+                  list(sc.code_library.parameters()) + list(sc.embeddings["xyz"].parameters())]
+        sync = GradientSync(params, groups=groups, active_rows={table: sc.embeddings["xyz"].active_rows()})
+        if os.environ.get("OBJNERF_BENCH_SYNC_ATTACH", "1") == "1":
+            sync.attach()
         g = torch.Generator(device=dev).manual_seed(rank)
         target = torch.rand(n_rays, 3, device=dev, generator=g)
         ids = synth.per_ray_ids(n_rays).to(dev)
@@ -809,6 +843,7 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend="nccl
             phases = {k: ms[i] / n_ph for i, k in enumerate(names)}
             phases["other"] = wall - sum(phases.values())
             phases = {"ms": phases, "steps": n_ph, "step_ms_with_marks": wall, "gradient_exchange_ms": exchange_ms,
+                      "gradient_exchange_buckets_started_during_backward": sync.early_launches,
                       "spans_per_step": {k: cnt[i] / n_ph for i, k in enumerate(names)},
                       "note": "HIP events on the launch stream at the phase boundaries inside objnerf_mlp_train_forward / _backward, "
                               "both passes (coarse + fine) of a step summed; other = step - sum"}
@@ -826,10 +861,12 @@ def train_step_leg(args, dev, rank, world, dist, fence, allreduce, backend="nccl
                              "frac": tflops / (PEAK_FP32_MFMA_TFLOPS * world),
                              "flop_convention": "3 x forward GEMM FLOP (forward + dgrad + wgrad) per evaluated sample point, whole "
                                                 "step incl. sampling, compositing, gradient exchange and Adam"},
-                "gradient_exchange": ("GradientSync: %d flat all-reduce(s) of %s bytes over %s, %.3f ms per step on the compute stream "
-                                      "(events around sync(): packing, the all-reduces, un-packing; inside the step, not overlapped -- the "
-                                      "differentiable render_rays is one autograd node, its gradients appear together)"
-                                      % (len(sync.buckets), sync.message_bytes(), backend_name(backend),
+                "gradient_exchange": ("GradientSync: %d flat all-reduce(s) of %s bytes over %s [fine model | coarse model | codes + voxel "
+                                      "table's active rows]; %d of them started from the gradient hooks DURING the backward (the coarse and "
+                                      "the fine pass are two autograd nodes: the fine model's bucket travels while the coarse node's backward "
+                                      "runs); %.3f ms per step EXPOSED on the compute stream (events around sync(): whatever was not "
+                                      "started yet, the waits, averaging and un-packing)"
+                                      % (len(sync.buckets), sync.message_bytes(), backend_name(backend), sync.early_launches,
                                          (phases or {}).get("gradient_exchange_ms", float("nan"))))
                                      if (dist is not None and world > 1) else "none (1 rank)",
                 "optimizer": "torch.optim.Adam(lr=1e-3, %s)" % ("fused=True" if fused else "foreach"),

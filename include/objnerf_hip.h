@@ -468,7 +468,11 @@ typedef struct {
   /* optional (both or neither): the packed weight stream of the SAME parameter values (objnerf_pack_weights).  When
    * given, the forward runs on the persistent MFMA kernel of objnerf_mlp_eval (memory form), which additionally
    * writes every layer's activations -- one launch per branch instead of one GEMM per layer.  The backward is
-   * the same either way. */
+   * the same either way.
+   * CONTRACT with the backward: a forward that ran WITH blob also leaves the LeakyReLU sign masks behind the activation matrices
+   * of `workspace`, and a backward called with blob != NULL reads them there (its dgrad chain is fed by the masks).  Pass the
+   * SAME blob / no-blob choice to both calls of a pair: a backward given a blob after a layer-by-layer forward (blob == NULL)
+   * would read masks nobody wrote. */
   const float* blob; const float* aux;
   /* optional, read by objnerf_mlp_train_backward only (needs aux too): objnerf_pack_weights_bwd() of the same
    * parameter values.  When given, the dgrad chain through the hidden layers runs in one persistent MFMA kernel
@@ -492,7 +496,8 @@ typedef struct {
    * models/rendering.py:89-94): the gradients of the weight columns that meet the direction embedding / the object code, and the
    * gradient w.r.t. the code, are contracted over n_points / 16 segment sums instead of n_points points.  emb_dir / obj_code
    * (per point) may then be NULL, and d_obj_code receives (n_points / 16, 64): one row per 16 consecutive points, to be summed
-   * over a ray's S / 16 segments by the caller (objnerf_sum_over_samples with S / 16). */
+   * over a ray's S / 16 segments by the caller (objnerf_sum_over_samples with S / 16).  The CALLER selects the form by passing
+   * emb_dir_ray or NULL (round 6: the library no longer consults OBJNERF_TRAIN_PER_RAY / OBJNERF_WGRAD for it). */
   const float* emb_dir_ray;
   /* optional (ABI 9), forward only, with rays / blob / aux: n_rays * OBJNERF_RAY_BIAS_FLOATS floats of scratch.  When given, the
    * forward takes the per-ray constant terms from objnerf_ray_bias (written there by this call) and skips their k-steps, as

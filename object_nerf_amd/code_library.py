@@ -23,7 +23,8 @@ class _GatherRows(torch.autograd.Function):
     def forward(ctx, table, ids):
         ctx.save_for_backward(ids)
         ctx.shape = table.shape
-        return table.detach()[ids]
+        # nn.Embedding's own lookup: the same range checks (a negative or too large id raises, as in the reference)
+        return torch.nn.functional.embedding(ids, table.detach())
 
     @staticmethod
     def backward(ctx, d_rows):
@@ -51,6 +52,7 @@ class CodeLibrary(nn.Module):
         w = self.embedding_instance.weight
         if (w.is_cuda and w.dtype == torch.float32 and w.requires_grad and torch.is_grad_enabled() and ids.dim() == 1
                 and ids.dtype == torch.int64 and ids.is_cuda and w.shape[1] <= 1024 and self.embedding_instance.padding_idx is None
-                and self.embedding_instance.max_norm is None):
+                and self.embedding_instance.max_norm is None and not self.embedding_instance.sparse
+                and not self.embedding_instance.scale_grad_by_freq):
             return {"embedding_instance": _GatherRows.apply(w, ids.contiguous())}
         return {"embedding_instance": self.embedding_instance(ids)}

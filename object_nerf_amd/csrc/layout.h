@@ -218,11 +218,23 @@ constexpr uint32_t kPackZero = 0xFFFFFFFFu;   // index-map entry meaning "0.0f"
 // per-ray vectors of the hoisted terms (mlp_kernel HOIST, ray_bias_kernel): [O1 128 | O3 128 | SD 128 | OD 64] in the
 // aux-bias layout of each layer
 constexpr int kRayBiasFloats = 448;
-// the weight columns those vectors are made from, as a compact matrix wm[group][c][16] + bias[group][16] (group = 16
-// consecutive floats of the per-ray vector, c = input column: 64 code / 27 direction columns): gathered ONCE per parameter
-// version by objnerf_pack_weights and kept behind the aux block (objnerf_aux_floats() = kAuxFloats + kRbMatFloats)
-constexpr int kRbGroups = kRayBiasFloats / 16;                  // 28: O1 8 | O3 8 | SD 8 | OD 4
-constexpr int kRbMatFloats = kRbGroups * 64 * 16 + kRbGroups * 16;
+// the weight columns those vectors are made from, as the A-operand stream of ray_bias_kernel (round 6: the per-ray vectors are
+// a 448 x 91 product per ray -- 340 v_mfma_f32_32x32x2_f32 per 32 rays, exactly the MFMAs the hoisting takes out of the MLP
+// kernel -- formed on the matrix pipe instead of 29 k fp32 FMAs per ray on the VALU): 14 out tiles T of 32 rows
+//     T 0-3: instance_encoding_1 | 4-7: instance_encoding_3 (k = 64 code columns: 32 k-steps, column of (ks, h) = 32 h + ks)
+//     T 8-11: dir_encoding | 12-13: inst_dir_encoding      (k = 27 direction columns: 14 k-steps, column of (ks, h) = 14 h + ks)
+// each as [k-step group q of 4][lane][4 k-steps] floats (one ds_read_b128 feeds 4 MFMAs; lane = (row & 31) + 32 h), then the
+// 448 biases in the per-ray vector's own order.  Gathered by objnerf_pack_models, kept behind the aux block
+// (objnerf_aux_floats() = kAuxFloats + kRbMatFloats).
+constexpr int kRbGroups = kRayBiasFloats / 16;                  // 28 groups of 16 floats: O1 8 | O3 8 | SD 8 | OD 4
+constexpr int kRbCodeTiles = 8, kRbDirTiles = 6;
+constexpr int kRbCodeQ = 8, kRbDirQ = 4;                        // k-step groups per tile (32 and 14 -> 16 k-steps, the last 2 zero)
+constexpr int kRbDirKs = 14;
+constexpr int kRbAFloats = (kRbCodeTiles * kRbCodeQ + kRbDirTiles * kRbDirQ) * 256;       // 22,528
+constexpr int kRbMatFloats = kRbAFloats + kRayBiasFloats;
+// first float of tile T in the stream, and its place (offset in the per-ray vector, tile index m inside its layer)
+OBJ_HD constexpr int rb_tile_start(int T) { return (T < kRbCodeTiles ? T * kRbCodeQ : kRbCodeTiles * kRbCodeQ + (T - kRbCodeTiles) * kRbDirQ) * 256; }
+OBJ_HD constexpr int rb_tile_off(int T) { return T < 4 ? 32 * T : (T < 8 ? 128 + 32 * (T - 4) : (T < 12 ? 256 + 32 * (T - 8) : 384 + 32 * (T - 12))); }
 
 // ---- backward weight stream (training: dgrad of the hidden chain, mlp_bwd_kernel.h) ------------------
 // d(input of layer) = W^T * d(pre-activation output): the same A-tile/chunk format with the roles swapped --

@@ -129,14 +129,23 @@ __global__ void sample_coarse4_kernel(const float* __restrict__ rays, const floa
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = S >> 2;
   if (idx >= n_rays * q) return;
-  const long ray = idx / q;
+  // (ray, quarter-row piece) of this thread without a 64-bit division (that division was a third of the kernel's instructions:
+  // 25 us = 0.44 of the store roofline in rounds 3-5): a shift when S / 4 is a power of two (every shipped config), else 32-bit
+  long ray;
+  if ((q & (q - 1)) == 0) ray = idx >> (31 - __builtin_clz(q));
+  else if (idx < (1L << 31)) ray = (long)((unsigned)idx / (unsigned)q);
+  else ray = idx / q;
   const int s = 4 * (int)(idx - ray * q);
   const float near = rays[ray * 8 + 6], far = rays[ray * 8 + 7];
   const f32x4 t = *(const f32x4*)(z_steps + s);
   f32x4 z;
 #pragma unroll
   for (int j = 0; j < 4; ++j) z[j] = coarse_z(near, far, t[j], use_disp);
+#ifdef OBJ_COARSE_NT
+  __builtin_nontemporal_store(z, (f32x4*)(z_vals + ray * S + s));
+#else
   *(f32x4*)(z_vals + ray * S + s) = z;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -668,6 +677,160 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __re
   }
 }
 
+// The shipped sample counts -- S = 64 coarse depths, I = 64 or 128 importance samples -- on a specialised form of the kernel
+// above (round 6; the generic kernel ran 206.7 us per 640x480 pass = 0.19 of its byte roofline, bound by INSTRUCTION ISSUE:
+// ~410 wave instructions per ray, two thirds of them the exec-mask loops of three divergent binary searches).  Same arithmetic,
+// same order, bit-equal results (tests/test_gpu_stages.py, test_gpu_render.py); what changes:
+//   * one element per lane and fixed trip counts: no strided loops, the searches are branch-free (6-8 probe / compare / select
+//     steps each), the neighbour depth comes through a DPP shift instead of a second load;
+//   * persistent waves: 8,192 waves walk the rays with the NEXT ray's depths and weights already in flight, the deterministic
+//     u table is loaded once per wave;
+//   * the unsorted cases (far < near, random u) keep the general code of the kernel above.
+// count of the elements of the ascending a[0..N) that are < v (or <= v): branch-free, N a power of two
+template <int N, bool OR_EQUAL>
+__device__ __forceinline__ int count_below_pow2(const float* a, float v) {
+  const float last = a[N - 1];
+  int pos = 0;
+#pragma unroll
+  for (int step = N / 2; step >= 1; step >>= 1) {
+    const float c = a[pos + step - 1];
+    pos = (OR_EQUAL ? c <= v : c < v) ? pos + step : pos;
+  }
+  return (OR_EQUAL ? last <= v : last < v) ? N : pos;
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) { return dpp<0x130>(fill, v); }     // v of the lane above
+
+// the unsorted cases of the merge (far < near: coarse depths not ascending; random u: new samples not ascending), as in the
+// generic kernel; out of line so that the common path keeps its registers
+__device__ __noinline__ void merge_unsorted(const float* all_lds, float* sorted_new, int S, int I, bool coarse_sorted, float* out,
+                                            bool do_clip, float clo, float chi, int lane) {
+  const int M = S + I;
+  auto put = [&](int pos, float val) { out[pos] = (do_clip && val > clo && val < chi) ? chi : val; };
+  if (!coarse_sorted) {
+    // general case: rank of every element among all M
+#pragma unroll 1
+    for (int i = lane; i < M; i += 64) {
+      const float val = all_lds[i];
+      int rank = 0;
+#pragma unroll 1
+      for (int j = 0; j < M; ++j) {
+        const float o = all_lds[j];
+        rank += (o < val || (o == val && j < i)) ? 1 : 0;
+      }
+      put(rank, val);
+    }
+    return;
+  }
+  // random u: order the new samples first by their rank among themselves, then the two-run merge
+  const float* nw_ = all_lds + S;
+#pragma unroll 1
+  for (int j = lane; j < I; j += 64) {
+    const float val = nw_[j];
+    int rank = 0;
+#pragma unroll 1
+    for (int k = 0; k < I; ++k) {
+      const float o = nw_[k];
+      rank += (o < val || (o == val && k < j)) ? 1 : 0;
+    }
+    sorted_new[rank] = val;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int i = lane; i < S; i += 64) put(i + count_below(sorted_new, I, all_lds[i], false), all_lds[i]);
+#pragma unroll 1
+  for (int r = lane; r < I; r += 64) put(r + count_below(all_lds, S, sorted_new[r], true), sorted_new[r]);
+}
+
+template <int NI>
+__global__ void __launch_bounds__(256) sample_pdf_merge64_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
+                                                                 const float* __restrict__ u, long u_stride, long n_rays, float eps,
+                                                                 float* __restrict__ z_samples, float* __restrict__ z_fine,
+                                                                 const float* __restrict__ clip) {
+  constexpr int S = 64, nb = 63, nw = 62, I = 64 * NI, M = S + I;
+  __shared__ float lds[4][192 + 2 * I];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* bins_lds = lds[wave];
+  float* cdf_lds = bins_lds + 64;
+  float* all_lds = cdf_lds + 64;        // [0, S) coarse depths, [S, S + I) new samples (contiguous: the general merge indexes both)
+  float* sorted_new = all_lds + M;
+  const long stride = (long)gridDim.x * 4;
+  long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= n_rays) return;
+  float zi = z_coarse[ray * S + lane];
+  float wi = lane < nw ? weights[ray * S + 1 + lane] : 0.f;
+  float uj[NI];
+  if (u_stride == 0) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) uj[k] = u[lane + 64 * k];
+  }
+  for (; ray < n_rays; ray += stride) {
+    const long nxt = ray + stride;
+    float zi_n = 0.f, wi_n = 0.f;
+    if (nxt < n_rays) {                 // (uniform) the next ray's row, in flight while this one is worked on
+      zi_n = z_coarse[nxt * S + lane];
+      wi_n = lane < nw ? weights[nxt * S + 1 + lane] : 0.f;
+    }
+    if (u_stride != 0) {
+#pragma unroll
+      for (int k = 0; k < NI; ++k) uj[k] = u[ray * u_stride + lane + 64 * k];
+    }
+    // z_vals_mid = 0.5 * (z[:-1] + z[1:])   (rendering.py:302-304)
+    all_lds[lane] = zi;
+    const float zn = wave_shl1(zi, zi);
+    const bool coarse_sorted = wave_all(lane < nb ? zn >= zi : true);
+    if (lane < nb) bins_lds[lane] = 0.5f * (zi + zn);
+    // pdf row sum and cdf exactly as sample_pdf_ray (float64 wave sum / scan, every prefix rounded to fp32)
+    const float we = wi + eps;
+    const float tot = (float)wave_sum_f64(lane < nw ? (double)we : 0.0);
+    double v = lane < nw ? (double)__fdiv_rn(we, tot) : 0.0;
+    v = wave_scan_add_f64(v) + 0.0;
+    if (lane == 0) cdf_lds[0] = 0.f;
+    if (lane < nw) cdf_lds[lane + 1] = (float)v;
+    __builtin_amdgcn_wave_barrier();
+    float smp[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      // searchsorted(cdf, u, right=True) over the nb = 63 entries: the number of entries <= u  (rendering.py:43)
+      int lo = 0;
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) lo = cdf_lds[lo + step - 1] <= uj[k] ? lo + step : lo;
+      const int below = lo - 1 < 0 ? 0 : lo - 1;       // clamp_min(inds-1, 0)
+      const int above = lo > nw ? nw : lo;             // clamp_max(inds, N_samples_)
+      const float c0 = cdf_lds[below], c1 = cdf_lds[above];
+      const float b0 = bins_lds[below], b1 = bins_lds[above];
+      float denom = c1 - c0;
+      if (denom < eps) denom = 1.f;                    // rendering.py:53-54
+      smp[k] = b0 + __fdiv_rn(uj[k] - c0, denom) * (b1 - b0);   // rendering.py:58-60
+      all_lds[S + lane + 64 * k] = smp[k];
+      if (z_samples) z_samples[ray * I + lane + 64 * k] = smp[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* out = z_fine + ray * M;
+    const bool do_clip = clip != nullptr;
+    const float clo = do_clip ? clip[ray * 2] : 0.f, chi = do_clip ? clip[ray * 2 + 1] : 0.f;
+    auto put = [&](int pos, float val) { out[pos] = (do_clip && val > clo && val < chi) ? chi : val; };
+    const float* nw_ = all_lds + S;
+    bool new_sorted = true;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int j = lane + 64 * k;
+      new_sorted = new_sorted && (j == 0 || smp[k] >= nw_[j == 0 ? 0 : j - 1]);
+    }
+    new_sorted = wave_all(new_sorted);
+    if (coarse_sorted && new_sorted) {
+      // z_fine = torch.sort(torch.cat([z, z_]))[0], ties in concatenation order (stable): a coarse depth goes behind the new
+      // samples strictly below it, a new sample behind the coarse depths <= it
+      put(lane + count_below_pow2<I, false>(nw_, zi), zi);
+#pragma unroll
+      for (int k = 0; k < NI; ++k) put(lane + 64 * k + count_below_pow2<S, true>(all_lds, smp[k]), smp[k]);
+    } else {
+      merge_unsorted(all_lds, sorted_new, S, I, coarse_sorted, out, do_clip, clo, chi, lane);     // (rare: kept out of line)
+    }
+    __builtin_amdgcn_wave_barrier();
+    zi = zi_n; wi = wi_n;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // multi-object path (render_tools/multi_rendering.py)
 // ------------------------------------------------------------------------------------------
@@ -890,9 +1053,9 @@ __global__ void ray_box_kernel(const float* __restrict__ rays_o, const float* __
 // along a ray -- the object code in instance_encoding_1 / _3 (nerf_model.py:128-138), the direction embedding in
 // dir_encoding / inst_dir_encoding (116, 147) -- out[ray] = bias + W[:, columns of x] . x, written in the layer's
 // D-register order so that a lane of the MLP kernel reads its 16 values as one 64-byte piece.
-// Two steps: a one-workgroup gather of the weight columns into a compact matrix, then lane = ray with the weights as
-// wave-uniform operands (round 3 first tried thread = output row with the rays' inputs broadcast from LDS: 1.07 ms per
-// frame pass, bound by one wave-level LDS read per 4 terms).
+// Two steps: the weight columns are gathered into an MFMA A-operand stream when the weights are packed (pack_all_kernel), then
+// ray_bias_kernel forms the product on the matrix pipe (round 6; rounds 3-5: lane = ray on the VALU with wave-uniform weight
+// operands, 353 us per frame pass; round 3 first tried thread = output row with the rays' inputs broadcast from LDS: 1.07 ms).
 // ------------------------------------------------------------------------------------------
 struct RayBiasArgs {
   const float* blob; const float* aux; const float* rays; const float* codes;
@@ -937,63 +1100,142 @@ __device__ __forceinline__ int rb_bias_src(int o) {
   const int off = o < 128 ? 0 : (o < 256 ? 128 : (o < 384 ? 256 : 384));
   return aux_bias_off(l) + (o - off);
 }
-// Step 2: lane = ray (its code and direction embedding in registers), the weights of 16 outputs at a time as wave-uniform
-// (scalar) operands; every lane stores the 16 outputs as one 64-byte piece of its ray's vector.  One wave per workgroup and
-// the 28 groups in 7 parts (blockIdx.y): a 1,024-ray chunk of the editor still spreads over 112 workgroups.
-constexpr int kRbParts = 7;                                     // 28 groups of 16 outputs in 7 parts of 4 (blockIdx.y); small batches: 28 parts of 1
-__global__ void __launch_bounds__(64) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ wm) {
-  const long slot = (long)blockIdx.x * 64 + threadIdx.x;
-  if (slot >= (a.n_active ? (long)*a.n_active : a.n_rays)) return;
-  const long ray = a.ray_index ? (long)a.ray_index[slot] : slot;      // vectors stay indexed by the ray's own number
-  const int gpp = kRbGroups / (int)gridDim.y;                   // groups per part (gridDim.y = 7 or 28)
-  const int g0 = blockIdx.y * gpp;
-  float x[64], pe[28];
-  if (a.do_object) {
-    const float* cp = a.codes + ray * a.code_stride;
+// Step 2 (round 6): out^T[448, rays] = A[448, 91] X^T[91, rays] on the matrix pipe.  A workgroup (4 waves) takes 32 rays at a
+// time; wave w owns the out tiles {2w, 2w+1} of the code product and {8+2w, 9+2w} (w < 2) / {12 + w - 2} (w >= 2) of the
+// direction product -- 92 / 92 / 78 / 78 MFMAs -- and keeps ITS tiles' A operands in its own slice of LDS (staged once per
+// workgroup, no block-wide barrier: a wave only reads what it wrote).  Lane (ray, h) holds the B operands in registers: the 32
+// code floats 32 h .. 32 h + 31 and the 28 direction-embedding values (the MLP kernel's own sin / cos).  The D layout of a tile
+// IS the 16-float piece [m][h][0..15] of the ray's vector: four 16-byte stores per lane and tile.  Rounds 3-5 computed the same
+// sums lane = ray on the VALU (29 k FMAs per ray, 353 us per frame pass at 0.9 of the plain-FMA rate).
+constexpr int kRbWaveFloats = (2 * kRbCodeQ + 2 * kRbDirQ) * 256;       // the largest per-wave A slice: 24 KB
+__device__ __forceinline__ f32x4 rb_lds16(const float* p) { return *(const __attribute__((address_space(3))) f32x4*)p; }
+
+template <int NT, int NQ, int KS>
+__device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_lds, const int (&off)[2], int lane, bool store, float* out,
+                                         const float (&bop)[KS]) {
+  // NT tiles side by side (independent accumulators between dependent MFMAs), NQ groups of 4 k-steps, KS valid k-steps
+  f32x16 acc[NT];
+  const int h = lane >> 5;
 #pragma unroll
-    for (int c4 = 0; c4 < 16; ++c4) {
-      const f32x4 v = *(const f32x4u*)(cp + 4 * c4);
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[4 * c4 + j] = v[j];
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 b = rb_lds16(bias_lds + off[t] + 16 * h + 4 * q4);
+      acc[t][4 * q4] = b[0]; acc[t][4 * q4 + 1] = b[1]; acc[t][4 * q4 + 2] = b[2]; acc[t][4 * q4 + 3] = b[3];
     }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    f32x4 a4[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a4[t] = rb_lds16(a_lds + ((t * NQ + q) * 64 + lane) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * q + j < KS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][j], bop[4 * q + j], acc[t], 0, 0, 0);
+      }
   }
-  // Embedding(3, 4): [d, sin(2^k d), cos(2^k d)] (embedding_helper.py:69-74), the MLP kernel's own sin / cos
-  const float d[3] = {a.rays[ray * 8 + 3], a.rays[ray * 8 + 4], a.rays[ray * 8 + 5]};
+  // the D layout of a tile is the 16-float piece [m][h][0..15] of the ray's vector.  (Turning the pieces into whole 128-byte
+  // lines through an LDS patch first was measured: 244 -> 239 us, i.e. nothing -- the kernel is bound by its VALU work, not by
+  // the store requests -- and taken out again.)
+  if (store) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) pe[c] = d[c];
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-  for (int k = 0; k < kFreqDir; ++k)
+      for (int q4 = 0; q4 < 4; ++q4)
+        *(f32x4u*)(out + off[t] + 16 * h + 4 * q4) = f32x4{acc[t][4 * q4], acc[t][4 * q4 + 1], acc[t][4 * q4 + 2], acc[t][4 * q4 + 3]};
+  }
+}
+
+__global__ void __launch_bounds__(256) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ rbA) {
+  __shared__ __attribute__((aligned(16))) float a_lds[4 * kRbWaveFloats];
+  __shared__ __attribute__((aligned(16))) float bias_lds[kRayBiasFloats];
+  const long n = a.n_active ? (long)*a.n_active : a.n_rays;
+  const long groups = (n + 31) >> 5;
+  if ((long)blockIdx.x >= groups) return;                       // (uniform) the grid is sized for n_rays, a culled subset may need less
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  // this wave's tiles
+  const int tc = 2 * wave;                                      // code tiles tc, tc + 1
+  const int td = wave < 2 ? kRbCodeTiles + 2 * wave : kRbCodeTiles + 2 + wave;      // direction tiles td (, td + 1 when wave < 2)
+  const int nd = wave < 2 ? 2 : 1;
+  const bool code_live = a.do_object != 0;
+  const bool dir_live = td < 12 ? a.do_scene != 0 : a.do_object != 0;
+  float* my = a_lds + wave * kRbWaveFloats;
+  {
+    // stage: [code tile tc | code tile tc + 1 | direction tile(s)] -- contiguous runs of the stream, 16 bytes per lane and step
+    const float* src_c = rbA + rb_tile_start(tc);
+    const float* src_d = rbA + rb_tile_start(td);
+    const int n_c = 2 * kRbCodeQ * 64, n_d = nd * kRbDirQ * 64;           // float4 counts
+    if (code_live)
+      for (int i = lane; i < n_c; i += 64) *(f32x4*)(my + 4 * i) = gload4(src_c + 4 * i);
+    if (dir_live)
+      for (int i = lane; i < n_d; i += 64) *(f32x4*)(my + 2 * kRbCodeQ * 256 + 4 * i) = gload4(src_d + 4 * i);
+    for (int i = tid; i < kRayBiasFloats; i += 256) bias_lds[i] = rbA[kRbAFloats + i];
+  }
+  __syncthreads();                                              // (the biases are shared; the A slices are wave-private)
+  const int off_c[2] = {rb_tile_off(tc), rb_tile_off(tc + 1)};
+  const int off_d[2] = {rb_tile_off(td), rb_tile_off(td + (nd == 2 ? 1 : 0))};
+  // the inputs of a 32-ray group: this lane's half of the ray's code and the ray's direction; the NEXT group's are in flight
+  // while the current group's products run (one wave per SIMD: nothing else hides the round trip)
+  float x[32], d[3];
+  long ray = 0;
+  bool valid = false;
+  auto fetch = [&](long grp, float (&xo)[32], float (&dout)[3], long& ray_o, bool& valid_o) __attribute__((always_inline)) {
+    const long slot = grp * 32 + (lane & 31);
+    valid_o = slot < n;
+    const long sl = valid_o ? slot : n - 1;
+    ray_o = a.ray_index ? (long)a.ray_index[sl] : sl;        // vectors stay indexed by the ray's own number
+    if (code_live) {
+      const float* cp = a.codes + ray_o * a.code_stride + 32 * h;
 #pragma unroll
-    for (int coord = 0; coord < 3; ++coord) {
-      const SinCos sc = psincos(d[coord] * (float)(1 << k));
-      pe[3 + 6 * k + coord] = sc.s;
-      pe[3 + 6 * k + 3 + coord] = sc.c;
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const f32x4 v = *(const f32x4u*)(cp + 4 * c4);
+        xo[4 * c4] = v[0]; xo[4 * c4 + 1] = v[1]; xo[4 * c4 + 2] = v[2]; xo[4 * c4 + 3] = v[3];
+      }
     }
-  pe[27] = 0.f;
-  float* out = a.out + ray * kRayBiasFloats;
-  const float* bias = wm + kRbGroups * 64 * 16;
-#pragma unroll 1
-  for (int g = g0; g < g0 + gpp; ++g) {
-    const bool is_code = g < 16;
-    const bool live = is_code ? a.do_object != 0 : (g < 24 ? a.do_scene != 0 : a.do_object != 0);
-    if (!live) continue;                       // uniform
-    const float* w = wm + (long)g * 64 * 16;
-    float acc[16];
+    if (dir_live) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = bias[g * 16 + j];
-    if (is_code) {
+      for (int c = 0; c < 3; ++c) dout[c] = a.rays[ray_o * 8 + 3 + c];
+    }
+  };
+  fetch(blockIdx.x, x, d, ray, valid);
+  for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    float xn[32], dn[3];
+    long ray_n = 0;
+    bool valid_n = false;
+    const long nxt = grp + gridDim.x;
+    if (nxt < groups) fetch(nxt, xn, dn, ray_n, valid_n);              // (uniform)
+    float* out = a.out + ray * kRayBiasFloats;
+    if (code_live) rb_tiles<2, kRbCodeQ, 32>(my, bias_lds, off_c, lane, valid, out, x);
+    if (dir_live) {
+      // Embedding(3, 4): [d, sin(2^k d), cos(2^k d)] (embedding_helper.py:69-74), the MLP kernel's own sin / cos.  Lane half h feeds
+      // columns 14 h .. 14 h + 13 of the 27 (+ one zero): half 0 = [d | sin, cos of 2^0 d | sin 2 d | cos 2 d (x, y)], half 1 =
+      // [cos 2 d (z) | sin, cos of 4 d | sin, cos of 8 d | 0] -- so a lane evaluates the two octaves of ITS half (argument 2^(2h) d
+      // and twice that) plus cos 2 d_z: 7 sin/cos pairs instead of all 12 (the counters showed 5.9 other VALU instructions per
+      // MFMA, most of them these polynomials; fp32 MFMA and VALU share the SIMD's ALUs)
+      const float f0 = h ? 4.f : 1.f;
+      float s0[3], c0[3], s1[3], c1[3];
 #pragma unroll
-      for (int c = 0; c < 64; ++c)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(w[c * 16 + j], x[c], acc[j]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 27; ++c)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(w[c * 16 + j], pe[c], acc[j]);
+      for (int coord = 0; coord < 3; ++coord) {
+        const SinCos a0 = psincos(d[coord] * f0), a1 = psincos(d[coord] * (2.f * f0));
+        s0[coord] = a0.s; c0[coord] = a0.c; s1[coord] = a1.s; c1[coord] = a1.c;
+      }
+      const float cz = psincos(d[2] * 2.f).c;                    // column 14 = cos(2 d_z)
+      float b[kRbDirKs];
+      b[0] = h ? cz : d[0];     b[1] = h ? s0[0] : d[1];   b[2] = h ? s0[1] : d[2];
+      b[3] = h ? s0[2] : s0[0]; b[4] = h ? c0[0] : s0[1];  b[5] = h ? c0[1] : s0[2];
+      b[6] = h ? c0[2] : c0[0]; b[7] = h ? s1[0] : c0[1];  b[8] = h ? s1[1] : c0[2];
+      b[9] = h ? s1[2] : s1[0]; b[10] = h ? c1[0] : s1[1]; b[11] = h ? c1[1] : s1[2];
+      b[12] = h ? c1[2] : c1[0]; b[13] = h ? 0.f : c1[1];
+      const float* ad = my + 2 * kRbCodeQ * 256;
+      if (nd == 2) rb_tiles<2, kRbDirQ, kRbDirKs>(ad, bias_lds, off_d, lane, valid, out, b);
+      else rb_tiles<1, kRbDirQ, kRbDirKs>(ad, bias_lds, off_d, lane, valid, out, b);
     }
 #pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) *(f32x4u*)(out + g * 16 + 4 * j4) = f32x4{acc[4 * j4], acc[4 * j4 + 1], acc[4 * j4 + 2], acc[4 * j4 + 3]};
+    for (int i = 0; i < 32; ++i) x[i] = xn[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = dn[i];
+    ray = ray_n; valid = valid_n;
   }
 }
 
@@ -1109,11 +1351,18 @@ struct PackJobs { PackJob j[kPackModels]; };
 __global__ void __launch_bounds__(256) pack_all_kernel(const uint32_t* __restrict__ blob_idx, long nb, const uint32_t* __restrict__ aux_idx,
                                                        long na, int use_voxel, const PackJobs jobs) {
   const PackJob& job = jobs.j[blockIdx.y];
-  const long nbB = (nb + 255) / 256, naB = (na + 255) / 256;
+  // four consecutive stream floats per thread: one 16-byte read of the gather map, four gathers, one 16-byte store (the stream
+  // length is a multiple of the chunk size; the map and the stream come from the caching allocator: 16-byte aligned)
+  const long nbB = (nb / 4 + 255) / 256, naB = (na + 255) / 256;
   long b = blockIdx.x;
   if (b < nbB) {
     const long i = b * 256 + threadIdx.x;
-    if (i < nb) job.blob[i] = pack_fetch(job.pp, blob_idx[i]);
+    if (i < nb / 4) {
+      const uint4 e = *(const uint4*)(blob_idx + 4 * i);
+      f32x4 v;
+      v[0] = pack_fetch(job.pp, e.x); v[1] = pack_fetch(job.pp, e.y); v[2] = pack_fetch(job.pp, e.z); v[3] = pack_fetch(job.pp, e.w);
+      *(f32x4*)(job.blob + 4 * i) = v;
+    }
     return;
   }
   b -= nbB;
@@ -1124,14 +1373,22 @@ __global__ void __launch_bounds__(256) pack_all_kernel(const uint32_t* __restric
   }
   b -= naB;
   const long t = b * 256 + threadIdx.x;
-  float* wm = job.aux + kAuxFloats;
-  if (t < 64L * kRayBiasFloats) {
-    const int c = (int)(t / kRayBiasFloats), o = (int)(t % kRayBiasFloats);
-    const long src = rb_matrix_src(use_voxel != 0, o, c);
-    wm[((long)(o >> 4) * 64 + c) * 16 + (o & 15)] = src < 0 ? 0.f : pack_fetch(job.pp, blob_idx[src]);
-  } else if (t < 65L * kRayBiasFloats) {
-    const int o = (int)(t - 64L * kRayBiasFloats);
-    wm[kRbGroups * 64 * 16 + o] = pack_fetch(job.pp, aux_idx[rb_bias_src(o)]);
+  float* rbA = job.aux + kAuxFloats;
+  if (t < kRbAFloats) {
+    // element (T, q, lane, j) of ray_bias_kernel's A stream (layout.h): row 32 m + (lane & 31) of tile T, k-step 4 q + j, half h
+    const int blk = (int)(t >> 8), lane = (int)(t >> 2) & 63, j = (int)t & 3;
+    const bool code = blk < kRbCodeTiles * kRbCodeQ;
+    const int T = code ? blk / kRbCodeQ : kRbCodeTiles + (blk - kRbCodeTiles * kRbCodeQ) / kRbDirQ;
+    const int q = code ? blk % kRbCodeQ : (blk - kRbCodeTiles * kRbCodeQ) % kRbDirQ;
+    const int ks = 4 * q + j, h = lane >> 5, row = lane & 31;
+    const int c = code ? 32 * h + ks : (ks < kRbDirKs ? kRbDirKs * h + ks : 64);
+    // row of the tile -> its place in the per-ray vector (the D layout: row = (r & 3) + 8 (r >> 2) + 4 half)
+    const int o = rb_tile_off(T) + 16 * ((row >> 2) & 1) + (row & 3) + 4 * (row >> 3);
+    const long src = (code || c < kDirC) ? rb_matrix_src(use_voxel != 0, o, c) : -1;
+    rbA[t] = src < 0 ? 0.f : pack_fetch(job.pp, blob_idx[src]);
+  } else if (t < kRbMatFloats) {
+    const int o = (int)(t - kRbAFloats);
+    rbA[t] = pack_fetch(job.pp, aux_idx[rb_bias_src(o)]);
   }
 }
 
@@ -1230,6 +1487,17 @@ int objnerf_sample_pdf_merge_clip(const float* z_coarse, const float* weights, c
   if (!z_coarse || !weights || !u || !z_fine || S < 3 || S - 1 > kMaxBins || I < 1 || S + I > kMaxMerge)
     return set_error(-1, "sample_pdf_merge: bad arguments (3 <= S <= 1025, S + I <= 2048)");
   if (n_rays == 0) return 0;
+  if (S == 64 && (I == 64 || I == 128)) {           // the shipped sample counts: the specialised, persistent form
+    const long blocks = (n_rays + 3) / 4;
+    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);           // 8 workgroups of 4 waves per CU
+    if (I == 64)
+      hipLaunchKernelGGL(sample_pdf_merge64_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_coarse, weights, u, (long)u_stride,
+                         (long)n_rays, eps, z_samples, z_fine, clip);
+    else
+      hipLaunchKernelGGL(sample_pdf_merge64_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_coarse, weights, u, (long)u_stride,
+                         (long)n_rays, eps, z_samples, z_fine, clip);
+    return check_launch("sample_pdf_merge");
+  }
   const size_t per_wave = (size_t)(2 * (S - 1) + (S + I) + I) * sizeof(float);      // <= 6142 floats = 24 KiB
   const int nwb = waves_per_block(per_wave);
   const long blocks = (n_rays + nwb - 1) / nwb;
@@ -1313,10 +1581,9 @@ int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   if (m->n_rays == 0) return 0;
   RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out,
                 m->ray_index, m->n_active};
-  // a wave computes 64 rays x (28 / parts) groups: below ~8k rays 7 parts leave most of the 1,024 SIMDs without a wave and the one
-  // wave each busy has 4 groups to do back to back (12 us at 1,024 rays); 28 parts of one group fill the machine 4x better
-  const unsigned parts = m->n_rays <= 8192 ? (unsigned)kRbGroups : (unsigned)kRbParts;
-  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)((m->n_rays + 63) / 64), parts), dim3(64), 0, (hipStream_t)stream, a,
+  // a workgroup per 32 rays, at most 512 of them (one is resident per CU -- 98 KB of LDS -- and walks its groups with a stride)
+  const long groups = (m->n_rays + 31) / 32;
+  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)(groups < 512 ? groups : 512)), dim3(256), 0, (hipStream_t)stream, a,
                      m->aux + kAuxFloats);
   return check_launch("ray_bias");
 }
@@ -1448,7 +1715,8 @@ int objnerf_pack_models(int use_voxel, const uint32_t* blob_idx, const uint32_t*
   }
   for (int m = n_models; m < kPackModels; ++m) jobs.j[m] = jobs.j[0];
   const long nb = objnerf_blob_floats(use_voxel), na = kAuxFloats;       // the tail of the aux block is the compact matrix
-  const unsigned blocks = blocks_for(nb, 256) + blocks_for(na, 256) + blocks_for(65L * kRayBiasFloats, 256);
+  if (nb % 4 != 0) return set_error(-3, "pack_models: stream length not a multiple of 4");
+  const unsigned blocks = blocks_for(nb / 4, 256) + blocks_for(na, 256) + blocks_for(kRbMatFloats, 256);
   hipLaunchKernelGGL(pack_all_kernel, dim3(blocks, (unsigned)n_models), dim3(256), 0, (hipStream_t)stream, blob_idx, nb, aux_idx, na,
                      use_voxel, jobs);
   return check_launch("pack_models");

@@ -335,9 +335,9 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   // the main pass, the (P x 64) code-gradient product and the per-point copies of codes / direction embeddings disappear.
   // Needs whole 16-point segments inside a ray (S % 16 == 0) and the per-ray inputs; otherwise the per-point form below.
   const bool per_ray = a->emb_dir_ray != nullptr && a->S >= 16 && a->S % 16 == 0 && a->n_rays * (int64_t)a->S == a->n_points &&
-                       (!a->do_object || (a->codes != nullptr && a->code_stride == kCodeC)) &&
-                       [] { const char* e = getenv("OBJNERF_TRAIN_PER_RAY"); return !e || atoi(e) != 0; }() &&
-                       [] { const char* e = getenv("OBJNERF_WGRAD"); return !(e && !strcmp(e, "atomic")); }();
+                       (!a->do_object || (a->codes != nullptr && a->code_stride == kCodeC));
+  // (the CALLER chooses the form by passing emb_dir_ray or not -- object_nerf_amd/autograd.py decides once, at forward time, and
+  // sizes d_obj_code for it; rounds 4-5 re-read OBJNERF_TRAIN_PER_RAY / OBJNERF_WGRAD here and could disagree with the caller)
   if (!per_ray && (!a->emb_dir || (a->do_object && !a->obj_code)))
     return set_error(-1, "mlp_train_backward: emb_dir / obj_code (per point) or emb_dir_ray / codes / S (per ray) are required");
   if (a->blob_bwd && !a->aux) return set_error(-1, "mlp_train_backward: blob_bwd needs aux");

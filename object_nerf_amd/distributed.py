@@ -343,7 +343,7 @@ class GradientSync:
 
     def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
                  active_rows: Dict[torch.nn.Parameter, int] = None, reduce_at_world1: bool = False,
-                 check_inactive_rows: bool = False):
+                 check_inactive_rows: bool = False, groups: Sequence[Sequence[torch.nn.Parameter]] = None):
         """active_rows: {parameter: n} -- only the first n rows of that (2-D) parameter can ever receive a gradient, so only
         `grad[:n]` travels.  This is the sparse handling of the voxel feature table: the renderer only
         reads rows the index map points at, i.e. rows < number of occupied voxels (`EmbeddingVoxel.active_rows()`); the
@@ -354,6 +354,20 @@ class GradientSync:
         beyond the active prefix carry no gradient (a host synchronisation per parameter: off by default); call
         `set_active_rows` after the voxel index map changes (e.g. a checkpoint with another occupancy was loaded)."""
         self.check_inactive_rows = bool(check_inactive_rows)
+        # groups (round 6): parameter lists in the order their gradients become final during the backward -- with the two-node
+        # differentiable render_rays: [fine model], [coarse model], [codes, voxel table].  Buckets never straddle a group, and the
+        # bucket ORDER is the exchange order on every rank (see attach()).  `params` may then be None.
+        self._group_ends = None
+        if groups is not None:
+            flat = [p for g_ in groups for p in g_ if p.requires_grad]
+            if params is not None and {id(p) for p in params if p.requires_grad} != {id(p) for p in flat}:
+                raise ValueError("GradientSync: `groups` must partition `params`")
+            ends, c = set(), 0
+            for g_ in groups:
+                c += sum(1 for p in g_ if p.requires_grad)
+                ends.add(c)
+            self._group_ends = ends
+            params = flat
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.reduce_at_world1 = bool(reduce_at_world1)
@@ -368,7 +382,7 @@ class GradientSync:
         cur, cur_bytes = [], 0
         for i, p in enumerate(self.params):
             nbytes = self._numel(i) * 4
-            if cur and cur_bytes + nbytes > bucket_bytes:
+            if cur and (cur_bytes + nbytes > bucket_bytes or (self._group_ends is not None and i in self._group_ends)):
                 self.buckets.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(i)
@@ -376,6 +390,14 @@ class GradientSync:
         if cur:
             self.buckets.append(cur)
         self._flat: List[torch.Tensor] = [None] * len(self.buckets)
+        self._hooks = []
+        self._works: List = [None] * len(self.buckets)       # attach(): the all-reduce of bucket b once it has been started
+        self._ready = [0] * len(self.buckets)
+        self._bucket_of = {}
+        for b, idx in enumerate(self.buckets):
+            for i in idx:
+                self._bucket_of[i] = b
+        self.early_launches = 0                              # buckets whose exchange started from a gradient hook (last step)
 
     def set_active_rows(self, param: torch.nn.Parameter, n: int) -> None:
         """new travelling prefix of `param` (same value on every rank); the flat buffers are re-sized on the next sync"""
@@ -407,31 +429,75 @@ class GradientSync:
         """the part of params[i]-shaped tensor t that is exchanged, flattened"""
         return t.reshape(-1) if self.rows[i] < 0 else t[: self.rows[i]].reshape(-1)
 
+    def attach(self) -> "GradientSync":
+        """Start each bucket's all-reduce AS SOON AS its gradients are final instead of at sync(): a post-accumulate-grad hook per
+        parameter counts the bucket's arrivals.  With the two-node differentiable render_rays (object_nerf_amd/autograd.py) the fine
+        model's gradients arrive when the fine node's backward returns, i.e. their exchange travels while the coarse node's
+        backward runs -- what torch's DDP reducer does for the reference (train.py:261-262).  Buckets are started strictly in
+        bucket order (bucket b waits for b - 1), so every rank issues the same collectives in the same order whatever arrives
+        when; a bucket with a parameter that received no gradient on this rank is started by sync().  sync() stays mandatory: it
+        starts what is left, waits, averages and writes the gradients back."""
+        if self._hooks:
+            return self
+        for i, p in enumerate(self.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i)))
+        return self
+
+    def detach(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def _active(self) -> bool:
+        if not dist.is_initialized():
+            return False
+        return dist.get_world_size(self.group) > 1 or self.reduce_at_world1
+
+    def _on_grad(self, i: int) -> None:
+        if not self._active():
+            return
+        b = self._bucket_of[i]
+        self._ready[b] += 1
+        # in order: start every complete bucket whose predecessors have all been started
+        nb = 0
+        while nb < len(self.buckets) and self._works[nb] is not None:
+            nb += 1
+        while nb < len(self.buckets) and self._ready[nb] >= len(self.buckets[nb]):
+            self._start(nb)
+            self.early_launches += 1
+            nb += 1
+
+    @torch.no_grad()
+    def _start(self, b: int) -> None:
+        """pack bucket b's gradients into its flat message and issue the asynchronous all-reduce"""
+        idx = self.buckets[b]
+        flat = self._buffer(b)
+        off = 0
+        for i in idx:
+            p = self.params[i]
+            n = self._numel(i)
+            view = flat[off:off + n]
+            if p.grad is None:
+                view.zero_()
+            else:
+                view.copy_(self._travelling(i, p.grad))
+                if self.check_inactive_rows and self.rows[i] >= 0 and bool(p.grad[self.rows[i]:].any()):
+                    raise RuntimeError("GradientSync: a row beyond active_rows = %d received a gradient (the voxel index "
+                                       "map changed after construction?): ranks would diverge" % self.rows[i])
+            off += n
+        self._works[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     @torch.no_grad()
     def sync(self) -> None:
         """In place: every rank's `.grad` becomes the mean over ranks.  No-op without a process group."""
-        if not dist.is_initialized():
+        if not self._active():
             return
         world = dist.get_world_size(self.group)
-        if world == 1 and not self.reduce_at_world1:
-            return
-        works = []
-        for b, idx in enumerate(self.buckets):
-            flat = self._buffer(b)
-            off = 0
-            for i in idx:
-                p = self.params[i]
-                n = self._numel(i)
-                view = flat[off:off + n]
-                if p.grad is None:
-                    view.zero_()
-                else:
-                    view.copy_(self._travelling(i, p.grad))
-                    if self.check_inactive_rows and self.rows[i] >= 0 and bool(p.grad[self.rows[i]:].any()):
-                        raise RuntimeError("GradientSync: a row beyond active_rows = %d received a gradient (the voxel index "
-                                           "map changed after construction?): ranks would diverge" % self.rows[i])
-                off += n
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        started_early = sum(w is not None for w in self._works)
+        for b in range(len(self.buckets)):          # whatever the hooks have not started (all of it without attach())
+            if self._works[b] is None:
+                self._start(b)
+        works = self._works
         inv = 1.0 / world
         for b, idx in enumerate(self.buckets):
             works[b].wait()
@@ -452,3 +518,6 @@ class GradientSync:
                 else:
                     p.grad[: self.rows[i]].copy_((g * inv).view(self.rows[i], -1))
                 off += n
+        self._works = [None] * len(self.buckets)
+        self._ready = [0] * len(self.buckets)
+        self.early_launches = started_early

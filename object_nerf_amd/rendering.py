@@ -97,6 +97,21 @@ def hoist_enabled():
     return m == "1"
 
 
+def train_nodes():
+    """How many autograd nodes the differentiable render_rays records (object_nerf_amd/autograd.py): 2 = coarse pass and fine pass
+    (the fine model's gradients are final when the fine node's backward returns, so a data-parallel wrapper exchanges them while
+    the coarse node's backward runs), 1 = one node for the whole call (rounds 1-5).  Same launches, same gradients (bit-equal,
+    tests/test_gpu_train.py).  OBJNERF_TRAIN_NODES = 1 | 2 forces a form; unset: 2 when a torch.distributed process group with
+    more than one rank is up (the only place the split buys anything), else 1."""
+    m = os.environ.get("OBJNERF_TRAIN_NODES", "auto")
+    if m in ("1", "2"):
+        return int(m)
+    if m != "auto":
+        raise RuntimeError("OBJNERF_TRAIN_NODES must be '1', '2' or 'auto', got %r" % m)
+    import torch.distributed as dist
+    return 2 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 1
+
+
 def fused_path_ok(models, embeddings, fine):
     """True when the persistent fused kernel can render this operator set: the default architecture (both models), 2^k
     frequency bands with the default counts, and -- in voxel mode -- the 16 + 8 channel / 6 frequency table layout.
@@ -226,7 +241,7 @@ def render_rays(
     plist = list(coarse._param_list()) + (list(models["fine"]._param_list()) if I > 0 else [])
     if torch.is_grad_enabled() and (embedding_instance.requires_grad or any(p.requires_grad for p in plist)
                                     or (table is not None and table.requires_grad)):
-        from .autograd import RenderRaysFn
+        from .autograd import RenderRaysFn, render_rays_nodes
         rnd = dict(randoms) if randoms else {}
         if perturb > 0:
             rnd.setdefault("perturb_rand", torch.rand(n, S, device=dev))
@@ -251,11 +266,16 @@ def render_rays(
                     # version of both / the forward / the dgrad chain instead, "mem" makes the forward kernel read the
                     # materialised embeddings back (same workspace layout in every mode; developer A/B switch)
                     packed=_train_packs(coarse, models["fine"] if I > 0 else None))
-        outs = RenderRaysFn.apply(meta, rays_c, embedding_instance, table, *plist)
-        keys = sorted(["%s_%s" % (k, t) for t in (("coarse", "fine") if I > 0 else ("coarse",))
-                       for k in (["weights", "opacity", "z_vals", "rgb", "depth"]
-                                 + (["rgb_instance", "depth_instance", "opacity_instance"] if forward_instance else []))])
-        return dict(zip(keys, outs))
+        if train_nodes() == 1:       # the single autograd node of rounds 1-5
+            outs = RenderRaysFn.apply(meta, rays_c, embedding_instance, table, *plist)
+            keys = sorted(["%s_%s" % (k, t) for t in (("coarse", "fine") if I > 0 else ("coarse",))
+                           for k in (["weights", "opacity", "z_vals", "rgb", "depth"]
+                                     + (["rgb_instance", "depth_instance", "opacity_instance"] if forward_instance else []))])
+            return dict(zip(keys, outs))
+        # two nodes (coarse pass, fine pass): the fine model's gradients are final when the fine node's backward returns, a
+        # data-parallel wrapper exchanges them while the coarse node's backward runs (object_nerf_amd/autograd.py)
+        npar = len(coarse._param_list())
+        return render_rays_nodes(meta, rays_c, embedding_instance, table, plist[:npar], plist[npar:])
 
     codes = _lib.as_f32(embedding_instance.detach())
 

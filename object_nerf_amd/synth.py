@@ -55,43 +55,72 @@ def dataset_extra(preset=SCANNET_LIKE, n_points=200_000, seed=0):
                     scale_factor=preset["scale_factor"], voxel_size=preset["voxel_size"], neighbor_marks=3)
 
 
-def camera_rays(W=640, H=480, fov_x_deg=60.0, near=0.15, far=3.0, origin=(0.5, 0.5, 0.6), yaw_deg=35.0,
-                pitch_deg=-15.0):
-    """Pinhole rays in the reference's layout [o(3), d(3), near, far]:
-    dirs = [(i - W/2)/f, -(j - H/2)/f, -1] (datasets/ray_utils.py:17-23, no +0.5), rotated by a
-    camera-to-world rotation, normalised (ray_utils.py:43-49); row-major pixel order."""
-    f = 0.5 * W / math.tan(0.5 * math.radians(fov_x_deg))
+def rotate_rows(v, R, normalise=False):
+    """rows of v (n, 3) times R^T, REPRODUCIBLY on any host: float64 element-wise products and sums in a fixed order (every one
+    of them a correctly rounded IEEE operation), optional normalisation by sqrt(x^2 + y^2 + z^2) the same way, rounded to fp32
+    once at the end.  A `v @ R.T` in fp32 goes through the host's BLAS and `v.norm(dim=-1)` through a vectorised reduction:
+    both round differently on different CPUs (measured, round 6: the same call gave directions one ulp apart on the Intel build
+    container and on the AMD host of the GPU box, i.e. the goldens and the GPU tests rendered different rays -- the whole
+    "coarse keys 1.6e-4 from the reference" of rounds 3-5 was that, tools/coarse_worst_ray.py)."""
+    v = v.double()
+    R = [[float(R[r][c]) for c in range(3)] for r in range(3)]
+    cols = []
+    for r in range(3):
+        a = v[:, 0] * R[r][0]
+        b = v[:, 1] * R[r][1]
+        c = v[:, 2] * R[r][2]
+        cols.append((a + b) + c)
+    if normalise:
+        n = torch.sqrt((cols[0] * cols[0] + cols[1] * cols[1]) + cols[2] * cols[2])
+        cols = [c / n for c in cols]
+    return torch.stack(cols, -1).float()
+
+
+def _matmul3(A, B):
+    """3x3 product in Python floats (float64, fixed order)"""
+    return [[(A[r][0] * B[0][c] + A[r][1] * B[1][c]) + A[r][2] * B[2][c] for c in range(3)] for r in range(3)]
+
+
+def _pinhole_rays(W, H, f, R, origin, near, far):
+    """[o(3), d(3), near, far] rows of a pinhole camera: dirs = [(i - W/2)/f, -(j - H/2)/f, -1] (datasets/ray_utils.py:17-23, no
+    +0.5) in fp32 like the reference's grid, rotated by the camera-to-world rotation R and normalised (ray_utils.py:43-49)
+    through `rotate_rows` (host-independent); row-major pixel order."""
     j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
     dirs = torch.stack([(i - W / 2) / f, -(j - H / 2) / f, -torch.ones_like(i)], -1).reshape(-1, 3)
-    # camera looks along -z; tilt it to look across the room
+    d = rotate_rows(dirs, R, normalise=True)
+    n = d.shape[0]
+    o = torch.tensor([float(x) for x in origin], dtype=torch.float64).float().expand_as(d)
+    return torch.cat([o, d, torch.full((n, 1), float(near)), torch.full((n, 1), float(far))], -1).contiguous()
+
+
+def camera_rays(W=640, H=480, fov_x_deg=60.0, near=0.15, far=3.0, origin=(0.5, 0.5, 0.6), yaw_deg=35.0,
+                pitch_deg=-15.0):
+    """Pinhole rays in the reference's layout [o(3), d(3), near, far] (see _pinhole_rays): the camera looks along -z, tilted
+    to look across the room."""
+    f = 0.5 * W / math.tan(0.5 * math.radians(fov_x_deg))
     cy, sy = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
     cp, sp = math.cos(math.radians(90 + pitch_deg)), math.sin(math.radians(90 + pitch_deg))
-    Rp = torch.tensor([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], dtype=torch.float32)
-    Ry = torch.tensor([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]], dtype=torch.float32)
-    R = Ry @ Rp
-    d = dirs @ R.T
-    d = d / d.norm(dim=-1, keepdim=True)
-    o = torch.tensor(origin, dtype=torch.float32).expand_as(d)
-    n = d.shape[0]
-    return torch.cat([o, d, torch.full((n, 1), near), torch.full((n, 1), far)], -1).contiguous()
+    Rp = [[1.0, 0.0, 0.0], [0.0, cp, -sp], [0.0, sp, cp]]
+    Ry = [[cy, -sy, 0.0], [sy, cy, 0.0], [0.0, 0.0, 1.0]]
+    return _pinhole_rays(W, H, f, _matmul3(Ry, Rp), origin, near, far)
 
 
 def look_at_rays(W, H, origin, target, near, far, fov_x_deg=60.0, up=(0.0, 0.0, 1.0)):
     """The same pinhole model as `camera_rays` with the pose given as eye point / look-at point (normalised units)."""
     f = 0.5 * W / math.tan(0.5 * math.radians(fov_x_deg))
-    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    dirs = torch.stack([(i - W / 2) / f, -(j - H / 2) / f, -torch.ones_like(i)], -1).reshape(-1, 3)
-    o = torch.tensor(origin, dtype=torch.float64)
-    fwd = torch.tensor(target, dtype=torch.float64) - o
-    fwd = fwd / fwd.norm()
-    right = torch.linalg.cross(fwd, torch.tensor(up, dtype=torch.float64))
-    right = right / right.norm()
-    upv = torch.linalg.cross(right, fwd)
-    R = torch.stack([right, upv, -fwd], 1).float()         # camera x, y, z axes as columns (camera looks along -z)
-    d = dirs @ R.T
-    d = d / d.norm(dim=-1, keepdim=True)
-    n = d.shape[0]
-    return torch.cat([o.float().expand_as(d), d, torch.full((n, 1), float(near)), torch.full((n, 1), float(far))], -1).contiguous()
+
+    def unit(v):
+        n = math.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+        return [v[0] / n, v[1] / n, v[2] / n]
+
+    def cross(a, b):
+        return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+    o = [float(x) for x in origin]
+    fwd = unit([float(t) - x for t, x in zip(target, o)])
+    right = unit(cross(fwd, [float(x) for x in up]))
+    upv = cross(right, fwd)
+    R = [[right[r], upv[r], -fwd[r]] for r in range(3)]     # camera x, y, z axes as columns (camera looks along -z)
+    return _pinhole_rays(W, H, f, R, o, near, far)
 
 
 def preset_rays(preset, W=640, H=480, yaw_offset_deg=0.0):

@@ -104,6 +104,14 @@ def frames(ref, scene):
             # the tests regenerate these ray sets with the oracle's generate_rays: it has to be bit-equal to the reference's
             for a, b in zip(sets, cases.frame_multi_sets(O.generate_rays, case)):
                 assert torch.equal(a, b), "oracle generate_rays differs from the reference's ray / box code"
+            # The sets themselves travel with the golden (round 6): the reference's get_rays is an fp32 matmul + a vector norm,
+            # which round differently on different host CPUs -- sets regenerated on the GPU box are NOT the rays this frame was
+            # rendered from (directions an ulp apart on some rays).  Directions + (near, far) per set; origins are one point each.
+            for k, st in enumerate(sets):
+                out["_set%d_o" % k] = st[0, 0:3].clone()
+                assert torch.equal(st[:, 0:3], st[0:1, 0:3].expand(st.shape[0], 3))
+                out["_set%d_d" % k] = st[:, 3:6].clone()
+                out["_set%d_nf" % k] = st[:, 6:8].clone()
             r = dict(ref.render_rays_multi(sc.models, sc.embeddings, sc.code_library, [s.clone() for s in sets], bm["obj_ids"],
                                            N_samples=bm["N_samples"], N_importance=bm["N_importance"], perturb=0, noise_std=0,
                                            chunk=32768, white_back=False, background_skip_bbox={4: helper}))
@@ -276,6 +284,17 @@ def sigma_grids(ref, scene):
     save("stage_sigma_grid", out)
 
 
+def write_input_digests():
+    """tests/golden/input_digests.json: bit digests of every synthetic input the goldens were made from, as generated HERE.
+    The tests regenerate the inputs on their own host and compare (tests/test_golden_inputs.py, and on the GPU box
+    tests/test_gpu_frames.py): a golden is only a golden for the inputs it was rendered from."""
+    import json
+    d = cases.input_digests()
+    path = os.path.join(cases.GOLDEN_DIR, "input_digests.json")
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path, "(%d digests)" % len(d))
+
+
 def main():
     torch.set_num_threads(8)
     ref = ref_import.load_reference()
@@ -303,6 +322,9 @@ def main():
         with torch.no_grad():
             multi_training_mode(ref, scene)
         other_architectures(ref, scene)
+        return
+    if "--digests" in sys.argv:     # only tests/golden/input_digests.json
+        write_input_digests()
         return
     if "--coarse-f64" in sys.argv:  # only the coarse-pass attribution vectors (a minute of CPU)
         with torch.no_grad():
@@ -439,6 +461,7 @@ def main():
 
         xyz = cases.voxel_points(600).view(20, 30, 3)
         save("stage_points_in_boxes", dict(inside=ref.check_in_any_boxes(ref_boxes, xyz)))
+    write_input_digests()
 
 
 if __name__ == "__main__":

@@ -191,9 +191,8 @@ def multi_inputs():
         r = bg.clone()
         r[:, 0:3] += torch.tensor(shift)
         ang = math.radians(10.0 * (k + 1))
-        R = torch.tensor([[math.cos(ang), -math.sin(ang), 0], [math.sin(ang), math.cos(ang), 0], [0, 0, 1]],
-                         dtype=torch.float32)
-        r[:, 3:6] = r[:, 3:6] @ R.T
+        R = [[math.cos(ang), -math.sin(ang), 0.0], [math.sin(ang), math.cos(ang), 0.0], [0.0, 0.0, 1.0]]
+        r[:, 3:6] = synth.rotate_rows(r[:, 3:6], R)       # host-independent (an fp32 `@` rounds differently on different CPUs)
         r[:, 6], r[:, 7] = near, far
         miss = (torch.arange(n) % (4 + k)) == 0        # rays that miss the object's box: near = far = 0
         r[miss, 6:8] = 0.0
@@ -320,3 +319,71 @@ def frame_multi_sets(gen, case="frame_edit_demo"):
     pre, bm = synth.SCANNET_LIKE, BENCH_MULTI
     return [gen(FRAME["H"], FRAME["W"], focal, torch.from_numpy(np.asarray(T)).float(), pre["near"], pre["far"],
                 box=None if k == 0 else box, bbox_enlarge=bm["bbox_enlarge"]) for k, T in enumerate(poses)]
+
+
+def golden_multi_sets(case="frame_edit_demo"):
+    """The ray sets the reference rendered the multi frame FROM, as stored with its golden (oracle/make_golden.py::frames): the
+    reference's get_rays is an fp32 matmul + a vector norm, which round differently on different host CPUs, so sets regenerated
+    on the test host are not bit-for-bit the rays of the golden frame (round 6)."""
+    g = load_golden(case)
+    sets = []
+    k = 0
+    while "_set%d_d" % k in g:
+        d, nf = g["_set%d_d" % k], g["_set%d_nf" % k]
+        sets.append(torch.cat([g["_set%d_o" % k].reshape(1, 3).expand(d.shape[0], 3), d, nf], 1).contiguous())
+        k += 1
+    return sets
+
+
+# ---- input digests -------------------------------------------------------------------------------------------------------------
+def _digest(t):
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.float32:
+        return int(t.view(torch.int32).to(torch.int64).sum().item())
+    if t.dtype == torch.float64:
+        return int((t.view(torch.int64) >> 8).sum().item())
+    return int(t.to(torch.int64).sum().item())
+
+
+def input_digests(A=None):
+    """{name: bit digest} of every synthetic input a golden depends on, as generated on THIS host: ray batches of every case,
+    model weights, voxel tables / index maps / geometry, code tables, random draws.  tests/golden/input_digests.json holds the
+    values of the host that made the goldens; a difference means a test would compare renders of different inputs (round 6: ray
+    directions one ulp apart between the build container and the GPU box made every frame-scale coarse key look 1.6e-4 off)."""
+    if A is None:
+        import object_nerf_amd as A
+    out = {}
+    seen = set()
+
+    def scene_digests(sname):
+        if sname in seen:
+            return
+        seen.add(sname)
+        sc = scene_for(A, sname)
+        for typ in ("coarse", "fine"):
+            out["scene.%s.%s.weights" % (sname, typ)] = sum(_digest(p) for p in sc.models[typ].parameters())
+        out["scene.%s.codes" % sname] = _digest(sc.code_library.embedding_instance.weight)
+        ev = sc.embeddings["xyz"]
+        if hasattr(ev, "voxel_idx_map"):
+            out["scene.%s.table" % sname] = _digest(ev.embedding_space_ftr.weight)
+            out["scene.%s.idx_map" % sname] = _digest(ev.voxel_idx_map)
+            out["scene.%s.geometry" % sname] = _digest(ev.voxel_offset) + _digest(ev.voxel_size.reshape(-1)) + _digest(ev.voxel_shape)
+    for case in sorted(FRAME_CASES):
+        fi = frame_inputs(case)
+        if FRAME_CASES[case]["kind"] == "single":
+            out["frame.%s.rays" % case] = _digest(fi[0])
+            out["frame.%s.ids" % case] = _digest(fi[1])
+        scene_digests(fi[3])
+    out["full_frame.rays"] = _digest(full_frame_inputs()[0])
+    for case in sorted(RENDER_CASES):
+        rays, ids, ptm, randoms = render_inputs(case)
+        out["render.%s.rays" % case] = _digest(rays)
+        out["render.%s.ids" % case] = _digest(ids)
+        if randoms is not None:
+            out["render.%s.randoms" % case] = sum(_digest(t) for v in randoms.values() for t in (v if isinstance(v, (list, tuple)) else [v]))
+        scene_digests(RENDER_CASES[case]["scene"])
+    sets, boxes = multi_inputs()
+    out["multi.sets"] = sum(_digest(t) for t in sets)
+    out["voxel_points"] = _digest(voxel_points())
+    return out
+

@@ -174,8 +174,9 @@ def test_c_abi_argument_validation():
     # per 32 samples when the passes composite in the MLP kernel's epilogue (no occlusion mask, no noise, S % 32 == 0);
     # plus, in fp32 arithmetic, the per-ray vectors of the hoisted terms (1792 B per ray) unless no_hoist
     rb = _lib.RAY_BIAS_FLOATS
-    rb_total = l.objnerf_ray_bias_floats(1000)                    # the vectors (the compact weight matrix sits behind aux since round 4)
-    assert rb_total == 1000 * rb and l.objnerf_aux_floats() == 4112 + 28 * 64 * 16 + 28 * 16
+    rb_total = l.objnerf_ray_bias_floats(1000)                    # the vectors (the hoisted weight columns sit behind aux since round 4;
+    # round 6: as the A-operand stream of the MFMA ray_bias kernel -- 8 tiles x 8 + 6 tiles x 4 groups of 256 floats -- + 448 biases)
+    assert rb_total == 1000 * rb and l.objnerf_aux_floats() == 4112 + (8 * 8 + 6 * 4) * 256 + 448
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64, separate_composite=1, no_hoist=1)
     assert l.objnerf_render_workspace_bytes(C.byref(cfg), 1000) == 4 * 1000 * 128 * 8 + 256
     cfg = _lib.RenderCfg(N_samples=64, N_importance=64, no_hoist=1)

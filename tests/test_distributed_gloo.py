@@ -264,3 +264,86 @@ def test_gradient_sync_without_process_group_is_a_noop():
     p.grad = torch.full((3,), 2.0)
     GradientSync([p]).sync()
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+class _Probe(torch.autograd.Function):
+    """y = 3 x whose backward records which buckets' exchanges have already been started (the "coarse node" of the test)"""
+    seen = None
+
+    @staticmethod
+    def forward(ctx, x, sync):
+        ctx.sync = sync
+        return x * 3.0
+
+    @staticmethod
+    def backward(ctx, g):
+        _Probe.seen = [w is not None for w in ctx.sync._works]
+        return g * 3.0, None
+
+
+def _attach_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(3)
+        fine = [torch.nn.Parameter(torch.randn(40, 7, generator=g)), torch.nn.Parameter(torch.randn(40, generator=g))]
+        coarse = [torch.nn.Parameter(torch.randn(30, 5, generator=g))]
+        shared = [torch.nn.Parameter(torch.randn(12, 24, generator=g))]           # gets a gradient from BOTH nodes (the voxel table)
+        x = torch.randn(5, generator=torch.Generator().manual_seed(100 + rank))   # a different batch per rank
+        sync = GradientSync(None, groups=[fine, coarse, shared], active_rows={shared[0]: 8}).attach()
+        chk = [(0, bool(len(sync.buckets) == 3 and [len(b) for b in sync.buckets] == [2, 1, 1]))]
+
+        def step(skip_fine_bias=False):
+            # recorded first -> runs LAST in the backward: the "coarse node"
+            yc = _Probe.apply(coarse[0], sync).sum() * x[0] + (shared[0][:8] * x[1]).sum()
+            # recorded last -> its backward runs FIRST: the "fine node"
+            yf = (fine[0] * x[2]).sum() + (shared[0][:8] * x[3]).sum()
+            if not skip_fine_bias:
+                yf = yf + (fine[1] * x[4]).sum()
+            for p in fine + coarse + shared:
+                p.grad = None
+            (yc + yf).backward()
+        step()
+        # when the coarse node ran, the fine bucket was already travelling; the coarse and the shared bucket were not ...
+        chk.append((1, bool(_Probe.seen == [True, False, False])))
+        # ... and by the end of the backward every bucket is on its way (the shared parameter's gradient is final last)
+        chk.append((2, bool([w is not None for w in sync._works] == [True, True, True])))
+        sync.sync()
+        chk.append((3, bool(sync.early_launches == 3 and all(w is None for w in sync._works))))
+        xs = [torch.randn(5, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        mean = lambda k: sum(float(v[k]) for v in xs) / world                   # noqa: E731
+        chk.append((4, bool(torch.allclose(fine[0].grad, torch.full((40, 7), mean(2)), atol=1e-6))))
+        chk.append((5, bool(torch.allclose(fine[1].grad, torch.full((40,), mean(4)), atol=1e-6))))
+        chk.append((6, bool(torch.allclose(coarse[0].grad, torch.full((30, 5), 3.0 * mean(0)), atol=1e-6))))
+        chk.append((7, bool(torch.allclose(shared[0].grad[:8], torch.full((8, 24), mean(1) + mean(3)), atol=1e-6))))
+        chk.append((8, bool(bool((shared[0].grad[8:] == 0).all()))))
+        # a parameter of the first bucket without a gradient on ONE rank: that rank starts nothing early, the collectives still
+        # pair up in bucket order on every rank and the missing gradient counts as zeros
+        step(skip_fine_bias=(rank == 1))
+        early = sum(w is not None for w in sync._works)
+        chk.append((9, bool(early == (0 if rank == 1 else 3))))
+        sync.sync()
+        chk.append((10, bool(torch.allclose(fine[1].grad, torch.full((40,), (sum(float(v[4]) for v in xs) - float(xs[1][4])) / world), atol=1e-6))))
+        chk.append((11, bool(torch.allclose(coarse[0].grad, torch.full((30, 5), 3.0 * mean(0)), atol=1e-6))))
+        sync.detach()
+        q.put((rank, all(c for _, c in chk), [i for i, c in chk if not c]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_sync_attach_starts_buckets_in_order_during_the_backward():
+    """round 6: with the coarse and the fine pass as two autograd nodes, GradientSync.attach() starts the fine model's bucket when
+    the fine node's backward has returned -- before the coarse node runs -- and keeps the collectives in bucket order on every
+    rank even when a rank has no gradient for some parameter"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_attach_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res

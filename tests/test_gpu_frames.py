@@ -6,10 +6,10 @@ frame, so this -- not the 48-ray cases of test_gpu_render.py -- is where the BAS
 Per case:
   * PSNR(ours, reference) of rgb_fine over the frame >= 60 dB;
   * |PSNR(ours, T) - PSNR(reference, T)| <= 0.1 dB against a fixed synthetic target T;
-  * every pixel map (rgb / depth / opacity + the three instance maps, both passes): max-norm distance from the reference's
+  * every FINE-pass pixel map (rgb / depth / opacity + the three instance maps): max-norm distance from the reference's
     map <= 3x the distance between the reference's fp32 frame and the float64 oracle on the same inputs (its own fp32 noise
-    floor, stored with the golden), coarse maps additionally allowed the 1e-4 of the BASELINE contract; the same in
-    relative L2 (robust against a single moved ray);
+    floor, stored with the golden); the same in relative L2 (robust against a single moved ray);
+  * every COARSE-pass map (round 6, no floor allowance): <= 2e-5 on the single-ray-set frames, <= 1x the floor on the multi-set frame;
   * rays whose importance samples moved (helpers.moved_rays, on the stored subset of rays) <= the float64 oracle's count
     + 0.1 % of the subset (at least 1)."""
 import numpy as np
@@ -40,11 +40,30 @@ def test_frame_matches_reference_frame(case):
         rep["psnr"], rep["psnr64"], rep["dpsnr"], rep["moved"], rep["moved64"], rep["n_sub"]))
     assert rep["psnr"] >= 60.0
     assert rep["dpsnr"] <= 0.1
+    single = cases.FRAME_CASES[case]["kind"] == "single"
     for k, (err, floor, e2, f2) in rep["rows"].items():
-        slack = 1e-4 if k.endswith("coarse") else 2e-5
-        assert err <= max(H.FLOOR_FACTOR * floor, slack), "%s/%s: max-norm %.3e, floor %.3e" % (case, k, err, floor)
-        assert e2 <= max(H.FLOOR_FACTOR * f2, slack), "%s/%s: relative L2 %.3e, floor %.3e" % (case, k, e2, f2)
+        if k.endswith("coarse"):
+            # Round 6: NO floor allowance for the coarse pass.  Rounds 3-5 allowed max(3 x floor, 1e-4) because these keys sat at
+            # 1.2-1.6e-4 (1.13 x the floor on the headline config) -- which was the GPU box's host regenerating ray directions an ulp
+            # off the ones the reference had rendered (tests/test_golden_inputs.py), not the kernels.  On identical rays the
+            # single-ray-set frames measure 2.6-3.8e-6 (profiles/r06_frame_parity.md): held to 2e-5, i.e. 5 x inside the
+            # contract's 1e-4 and 8 x inside the reference's own fp32-vs-fp64 distance.  The multi-set frame's coarse maps
+            # inherit the joint depth sort's discontinuities (the reference itself is 7e-3 from its float64 run there): never
+            # further from the reference than the reference is from exact arithmetic (1 x floor, measured 0.10-0.13 x).
+            tol = 2e-5 if single else floor
+            assert err <= tol and e2 <= (2e-5 if single else f2), "%s/%s: max-norm %.3e, relative L2 %.3e (floors %.3e / %.3e)" % (
+                case, k, err, e2, floor, f2)
+            continue
+        assert err <= max(H.FLOOR_FACTOR * floor, 2e-5), "%s/%s: max-norm %.3e, floor %.3e" % (case, k, err, floor)
+        assert e2 <= max(H.FLOOR_FACTOR * f2, 2e-5), "%s/%s: relative L2 %.3e, floor %.3e" % (case, k, e2, f2)
     assert rep["moved"] <= rep["moved64"] + max(1, rep["n_sub"] // 1000), (rep["moved"], rep["moved64"])
+
+
+def test_inputs_regenerate_bit_identically_on_this_host():
+    """the GPU box's host CPU regenerates every synthetic input bit-for-bit as the host that made the goldens did
+    (tests/test_golden_inputs.py explains; the same check, run HERE because this is the host that differed in rounds 3-5)"""
+    from test_golden_inputs import check_input_digests
+    check_input_digests()
 
 
 def test_full_size_frame_matches_the_reference_frame():
@@ -75,6 +94,14 @@ def test_full_size_frame_matches_the_reference_frame():
     assert derr <= max(H.FLOOR_FACTOR * float(small["_floor_depth_fine"]), 2e-5)
     dl2 = H.rel_l2(out["depth_fine"][:: cases.FULL_FRAME["sub"]], g["depth_fine_sub"])
     assert dl2 <= H.FLOOR_FACTOR * float(small["_floor_l2_depth_fine"]), dl2
+    # the coarse pass at 640x480 (round 6): every 16th pixel of all six coarse maps against the reference's, tests/golden/coarse_f64.npz
+    gc = cases.load_golden("coarse_f64")
+    for m in cases.FRAME_MAPS:
+        k = m + "_coarse"
+        ref = gc["full_frame_toydesk2_sub__" + k]
+        err = H.normwise(out[k][:: cases.FULL_FRAME["sub"]], ref)
+        assert err <= 2e-5, "640x480 %s: %.3e from the reference (its own fp32-vs-fp64 distance: %.3e)" % (
+            k, err, H.normwise(ref, gc["full_frame_toydesk2_sub__" + k + "_f64"]))
 
 
 def test_edit_demo_frame_from_device_generated_rays():

@@ -448,6 +448,57 @@ def test_parameter_gradients_are_reproducible_run_to_run():
         assert torch.equal(a[k], b[k]), "gradient of %s differs between two identical backward passes" % k
 
 
+def test_two_autograd_nodes_give_the_gradients_of_the_single_node(monkeypatch):
+    """round 6: the coarse and the fine pass are two autograd nodes (object_nerf_amd/autograd.py; the fine model's gradients are
+    final when the fine node returns: a data-parallel wrapper exchanges them while the coarse node's backward runs).  Same
+    launches on the same data as the single node of rounds 1-5 (OBJNERF_TRAIN_NODES=1): every result tensor, every MLP parameter
+    gradient of both models and the code gradient are BIT-EQUAL; the voxel table's gradient (fp32 atomics, and now the sum of two
+    separately scattered tables) to 1e-6.  And the order is what the overlap needs: the fine model's gradients exist when the coarse
+    node's backward starts."""
+    sc = cases.scene_for(A, "voxel", device=DEV)
+    n = 256
+    rays = H.test_rays(n, w=256, h=192, stride=41).to(DEV)
+    ids = synth.per_ray_ids(n, seed=6).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    rd = dict(perturb_rand=torch.rand(n, 64, generator=g).to(DEV), u_rand=torch.rand(n, 64, generator=g).to(DEV),
+              noise=[torch.randn(n, s_, generator=g).to(DEV) for s_ in (64, 64, 128, 128)])
+    mods = (sc.models["coarse"], sc.models["fine"], sc.code_library, sc.embeddings["xyz"])
+    ptm = (ids == 1).view(-1, 1)
+    order = []
+
+    def run(nodes):
+        monkeypatch.setenv("OBJNERF_TRAIN_NODES", nodes)
+        for m in mods:
+            m.zero_grad()
+        hooks = []
+        if nodes == "2":
+            pf, pc = sc.models["fine"].sigma.weight, sc.models["coarse"].sigma.weight
+            hooks = [pf.register_post_accumulate_grad_hook(lambda p: order.append("fine")),
+                     pc.register_post_accumulate_grad_hook(lambda p: order.append("coarse"))]
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        res = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                            embedding_instance=codes, frustum_bound_th=0.025, pass_through_mask=ptm, _randoms=rd)
+        _loss(res).backward()
+        torch.cuda.synchronize()
+        for h_ in hooks:
+            h_.remove()
+        grads = {"%d.%s" % (i, k): p.grad.clone() for i, m in enumerate(mods) for k, p in m.named_parameters()}
+        return {k: v.detach().clone() for k, v in res.items()}, grads
+    r1, g1 = run("1")
+    r2, g2 = run("2")
+    assert sorted(r1) == sorted(r2) and len(r1) == 16
+    for k in r1:
+        assert torch.equal(r1[k], r2[k]), k
+    table_key = [k for k in g1 if k.endswith("embedding_space_ftr.weight")]
+    assert len(table_key) == 1
+    for k in g1:
+        if k in table_key:
+            assert H.normwise(g2[k], g1[k]) < 1e-6, k
+        else:
+            assert torch.equal(g1[k], g2[k]), "gradient of %s differs between the one-node and the two-node form" % k
+    assert order == ["fine", "coarse"], order
+
+
 def test_stream_k_weight_gradients_match_the_atomic_split_k_path(monkeypatch):
     """Two independent implementations of the same 28 products dW = dY^T X: the grouped deterministic stream-K pass
     (csrc/wgrad.hip: branch-free k loops with software-pipelined global loads) against round 2's one split-K GEMM launch per

@@ -1,5 +1,5 @@
 import os, sys, torch
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["OBJNERF_PATH"] = "layerwise"
 import object_nerf_amd as A

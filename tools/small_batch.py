@@ -27,7 +27,10 @@ def main(out=None):
              "| hipGraph replay: device ms / call | of frame rate |",
              "|---|---|---|---|---|---|---|---|---|"]
     frame_rate = None
-    for n in (307200, 32768, 8192, 4096, 2048, 1024):
+    sizes = (307200, 32768, 8192, 4096, 2048, 1024)
+    if os.environ.get("SMALL_BATCH_ONLY"):        # e.g. under rocprofv3 --kernel-trace: one size only (the first is the "frame rate")
+        sizes = tuple(int(x) for x in os.environ["SMALL_BATCH_ONLY"].split(","))
+    for n in sizes:
         idx = torch.linspace(0, rays_all.shape[0] - 1, n).long().to(DEV)
         rays = rays_all[idx].contiguous()
         codes = sc.code_library({"instance_ids": torch.ones(n, dtype=torch.long, device=DEV)})["embedding_instance"].detach()
