@@ -71,6 +71,8 @@ int objnerf_pack_models(int use_voxel, const uint32_t* blob_idx, const uint32_t*
  * features and k = output features; the gradients w.r.t. the embeddings are not part of it. */
 int64_t objnerf_bwd_blob_floats(void);
 int objnerf_pack_index_bwd(int use_voxel, uint32_t* h_blob_idx);
+/* objnerf_pack_index_bwd(mode, ...): 0 = plain-PE model, 1 = voxel model, 2 = voxel model + the embedding-gradient blocks
+ * (objnerf_train_args.bwd_dx); objnerf_bwd_blob_floats() is the size of the longest of them. */
 int objnerf_pack_weights_bwd(const uint32_t* blob_idx, const float* const* h_param_ptrs, float* blob, void* stream);
 /* ---- stage entry points ---- */
 
@@ -481,7 +483,12 @@ typedef struct {
   /* optional, forward only, with blob/aux: the un-embedded inputs of the same points (points = rays x S in ray-major
    * order, exactly what emb_xyz / emb_dir / obj_voxel / obj_code were computed from).  When rays != NULL the forward
    * computes the embeddings in registers like objnerf_mlp_eval's fused form instead of reading them back. */
-  const float* rays; const float* z_vals; int64_t n_rays; int32_t S; int32_t _pad;
+  const float* rays; const float* z_vals; int64_t n_rays; int32_t S;
+  /* (ABI 10; was padding) read by objnerf_mlp_train_backward only: blob_bwd was packed through objnerf_pack_index_bwd MODE 2, i.e.
+   * it also carries the embedding-column blocks of xyz_encoding_1 / _5 and instance_encoding_1 / _3, and the fused chain forms
+   * d_emb_xyz / d_obj_voxel itself while those layers' gradient tiles are in registers (needs the forward's masks: blob given to
+   * the forward too).  0: the mode-1 stream, the embedding gradients are two segmented GEMMs after the chain (rounds 2-5). */
+  int32_t bwd_dx;
   const float* codes; int64_t code_stride;
   objnerf_voxel_grid grid;
   /* optional (ABI 8), read by objnerf_mlp_train_backward only, voxel mode: the sample positions (P,3) the embeddings were

@@ -95,7 +95,7 @@ class TrainArgs(C.Structure):
         ("sigma", C.c_void_p), ("rgb", C.c_void_p), ("inst_sigma", C.c_void_p), ("inst_rgb", C.c_void_p),
         ("workspace", C.c_void_p),
         ("blob", C.c_void_p), ("aux", C.c_void_p), ("blob_bwd", C.c_void_p),
-        ("rays", C.c_void_p), ("z_vals", C.c_void_p), ("n_rays", C.c_int64), ("S", C.c_int32), ("_pad", C.c_int32),
+        ("rays", C.c_void_p), ("z_vals", C.c_void_p), ("n_rays", C.c_int64), ("S", C.c_int32), ("bwd_dx", C.c_int32),
         ("codes", C.c_void_p), ("code_stride", C.c_int64),
         ("grid", VoxelGrid),
         ("scatter_xyz", C.c_void_p), ("scatter_table_grad", C.c_void_p),

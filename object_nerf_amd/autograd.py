@@ -77,7 +77,8 @@ def _composite_args(meta, ps, outs=None):
 def _train_args(meta, ps, params, packed=None, rays=None, codes=None, ray_bias_ws=None):
     a = _lib.TrainArgs()
     if packed is not None:
-        blob, aux, blob_bwd = packed
+        blob, aux, blob_bwd = packed[:3]
+        a.bwd_dx = int(bool(packed[3])) if len(packed) > 3 else 0
         a.aux = aux.data_ptr()
         if blob is not None:
             a.blob = blob.data_ptr()

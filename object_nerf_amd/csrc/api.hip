@@ -129,25 +129,30 @@ int objnerf_pack_index(int use_voxel, uint32_t* blob_idx, uint32_t* aux_idx) {
   return 0;
 }
 
-int64_t objnerf_bwd_blob_floats(void) { return (int64_t)bwd_total_chunks() * kChunkFloats; }
+int64_t objnerf_bwd_blob_floats(void) { return (int64_t)bwd_total_chunks(true) * kChunkFloats; }       // (the voxel-mode stream: the longer one)
 
 int objnerf_pack_index_bwd(int use_voxel, uint32_t* blob_idx) {
   if (!blob_idx) return set_error(-1, "pack_index_bwd: null output");
+  if (use_voxel < 0 || use_voxel > 2) return set_error(-1, "pack_index_bwd: mode 0 (plain), 1 (voxel) or 2 (voxel + embedding-gradient blocks)");
   const bool vox = use_voxel != 0;
+  const bool dx = use_voxel == 2;      // the embedding-gradient blocks ride in the stream (layout.h, BL_X*; objnerf_train_args.bwd_dx)
   const long nblob = objnerf_bwd_blob_floats();
   for (long i = 0; i < nblob; ++i) blob_idx[i] = kPackZero;
   for (int l = 0; l < BL_COUNT; ++l) {
-    const int nt = bwd_nt(l), kg = kChunkTiles / nt, ks_n = bwd_ks(l);
+    if (bwd_is_x(l) && !dx) continue;
+    const int nt = bwd_nt(l), kg = chunk_ksteps(nt), ks_n = bwd_ks(l);
     const int p = bwd_param(l);
     const ParamShape sh = param_shape(vox, p);
-    const int col0 = bwd_col0(vox, l);
-    if (2 * ks_n != sh.out || col0 + 32 * nt > sh.in) return set_error(-3, "pack_index_bwd: layout self-check failed");
-    const long base = (long)bwd_chunk_start(l) * kChunkFloats;
+    const int col0 = bwd_col0(vox, l), rows = bwd_rows(l);
+    if (2 * ks_n != sh.out || col0 + rows > sh.in || rows > 32 * nt) return set_error(-3, "pack_index_bwd: layout self-check failed");
+    const long base = (long)bwd_chunk_start(dx, l) * kChunkFloats;
     for (int ks = 0; ks < ks_n; ++ks) {
       const int chunk = ks / kg, kl = ks % kg, g4 = kl / 4, j = kl % 4;
       for (int m = 0; m < nt; ++m)
         for (int lane = 0; lane < 64; ++lane) {
-          const int in_feat = col0 + 32 * m + (lane & 31);       // tile row: a feature of the layer's input block
+          const int r = 32 * m + (lane & 31);
+          if (r >= rows) continue;                               // padding rows of the last tile stay zero
+          const int in_feat = col0 + r;                          // tile row: a feature of the layer's input block
           const int out_feat = hid_feat(ks, lane >> 5);          // k: the feature whose gradient the lane half holds
           const long o = base + (long)chunk * kChunkFloats + ((long)(g4 * nt + m) * 64 + lane) * 4 + j;
           blob_idx[o] = enc(2 * p, (long)out_feat * sh.in + in_feat);

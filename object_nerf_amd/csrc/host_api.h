@@ -20,7 +20,8 @@ int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hip
                       unsigned* mask_ws = nullptr);
 // training: fused dgrad chain through the hidden layers (mlp_bwd.hip); act / dz in the workspace layout of train.hip
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,
-                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, const unsigned* masks, hipStream_t s);
+                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, const unsigned* masks, bool dx,
+                   float* d_emb, long ld_emb, float* d_ov, hipStream_t s);
 // floats of the mask area behind the activation matrices of a training workspace (mlp_kernel.h: train_mask_floats)
 long train_mask_floats_host(long n_points);
 // persistent grid of the MLP kernel: one workgroup per CU

@@ -243,32 +243,62 @@ OBJ_HD constexpr int rb_tile_off(int T) { return T < 4 ? 32 * T : (T < 8 ? 128 +
 // Only hidden-to-hidden blocks are streamed (the gradients w.r.t. the embeddings are GEMMs, train.hip); in
 // execution order:
 enum BwdLayerId {
-  BL_SD = 0, BL_SF, BL_S8, BL_S7, BL_S6, BL_S5, BL_S4, BL_S3, BL_S2,     // scene: dir hidden -> ... -> layer 1 output
-  BL_OD, BL_OF, BL_O4, BL_O3, BL_O2, BL_COUNT                           // object
+  BL_SD = 0, BL_SF, BL_S8, BL_S7, BL_S6, BL_X5, BL_S5, BL_S4, BL_S3, BL_S2, BL_X1,     // scene: dir hidden -> ... -> layer 1 output
+  BL_OD, BL_OF, BL_O4, BL_XS3, BL_XO3, BL_O3, BL_O2, BL_XS1, BL_XO1, BL_COUNT      // object
 };
-OBJ_HD constexpr int bwd_nt(int l) { return l < BL_OD ? 8 : 4; }               // tiles of the produced gradient
-OBJ_HD constexpr int bwd_ks(int l) { return l == BL_SD ? kIW / 2 : (l < BL_OD ? kW / 2 : (l == BL_OD ? kIW / 4 : kIW / 2)); }
+// The X entries (round 6, voxel mode only: `dx` below) are the gradients w.r.t. the voxel-feature columns of the EMBEDDINGS, folded
+// into the chain: while the gradient of a layer that consumes the embedding is in registers (dZ5, dZ1, dB3, dB1), the same B operand
+// is contracted with that layer's embedding-column block -- X5 / X1: the 208 scene-voxel columns of xyz_encoding_5 / _1; XS3 / XS1:
+// the same columns of instance_encoding_3 / _1; XO3 / XO1: their 104 object-voxel columns -- into accumulators that stay in
+// registers until the end of the tile (7 + 4 tiles; rounds 2-5: two segmented GEMMs that re-read the four gradient matrices).
+OBJ_HD constexpr bool bwd_is_x(int l) { return l == BL_X5 || l == BL_X1 || l == BL_XS3 || l == BL_XO3 || l == BL_XS1 || l == BL_XO1; }
+OBJ_HD constexpr int bwd_nt(int l) {               // tiles of the produced gradient
+  if (l == BL_XO3 || l == BL_XO1) return 4;
+  if (bwd_is_x(l)) return 7;
+  return l < BL_OD ? 8 : 4;
+}
+OBJ_HD constexpr int bwd_ks(int l) {
+  if (l == BL_X5 || l == BL_X1) return kW / 2;
+  if (bwd_is_x(l)) return kIW / 2;
+  return l == BL_SD ? kIW / 2 : (l < BL_OD ? kW / 2 : (l == BL_OD ? kIW / 4 : kIW / 2));
+}
+// k-steps per chunk for a layer of nt out tiles: whole 4-k-step groups (7 tiles: 16 k-steps = 112 of the chunk's 128 tile slots)
+OBJ_HD constexpr int chunk_ksteps(int nt) { return (kChunkTiles / nt) & ~3; }
 OBJ_HD constexpr int bwd_chunks(int l) {
-  int kg = kChunkTiles / bwd_nt(l);
+  int kg = chunk_ksteps(bwd_nt(l));
   return (bwd_ks(l) + kg - 1) / kg;
 }
-OBJ_HD constexpr int bwd_chunk_start(int l) {
+OBJ_HD constexpr int bwd_chunk_start(bool dx, int l) {
   int s = 0;
-  for (int i = 0; i < l; ++i) s += bwd_chunks(i);
+  for (int i = 0; i < l; ++i) s += (bwd_is_x(i) && !dx) ? 0 : bwd_chunks(i);
   return s;
 }
-OBJ_HD constexpr int bwd_scene_chunks() { return bwd_chunk_start(BL_OD); }
-OBJ_HD constexpr int bwd_total_chunks() { return bwd_chunk_start(BL_COUNT); }
+OBJ_HD constexpr int bwd_scene_chunks(bool dx) { return bwd_chunk_start(dx, BL_OD); }
+OBJ_HD constexpr int bwd_total_chunks(bool dx) { return bwd_chunk_start(dx, BL_COUNT); }
 OBJ_HD constexpr int bwd_param(int l) {
   switch (l) {
     case BL_SD: return P_SD; case BL_SF: return P_SF;
     case BL_S8: return P_S8; case BL_S7: return P_S7; case BL_S6: return P_S6; case BL_S5: return P_S5;
     case BL_S4: return P_S4; case BL_S3: return P_S3; case BL_S2: return P_S2;
+    case BL_X5: return P_S5; case BL_X1: return P_S1;
     case BL_OD: return P_OD; case BL_OF: return P_OF; case BL_O4: return P_O4; case BL_O3: return P_O3;
+    case BL_XS3: case BL_XO3: return P_O3;
+    case BL_XS1: case BL_XO1: return P_O1;
     default: return P_O2;
   }
 }
-// first column of the streamed block inside the reference weight matrix (the hidden block of a skip layer)
-OBJ_HD constexpr int bwd_col0(bool voxel, int l) { return l == BL_S5 ? in_xyz(voxel) : (l == BL_O3 ? in_obj(voxel) : 0); }
+// first column of the streamed block inside the reference weight matrix (the hidden block of a skip layer; the scene-voxel
+// columns lead the embedding, the object-voxel columns follow its in_xyz columns, nerf_model.py:128-131) and the number of its rows
+// that exist (the rest of the last tile is zero)
+OBJ_HD constexpr int bwd_col0(bool voxel, int l) {
+  if (l == BL_XO3 || l == BL_XO1) return in_xyz(voxel);
+  if (bwd_is_x(l)) return 0;
+  return l == BL_S5 ? in_xyz(voxel) : (l == BL_O3 ? in_obj(voxel) : 0);
+}
+OBJ_HD constexpr int bwd_rows(int l) {
+  if (l == BL_XO3 || l == BL_XO1) return kObjVoxPE;
+  if (bwd_is_x(l)) return kScnVoxPE;
+  return 32 * bwd_nt(l);
+}
 
 }  // namespace objnerf

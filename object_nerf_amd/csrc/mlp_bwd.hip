@@ -31,6 +31,9 @@ struct BwdArgs {
   const float* d_isigma;
   const float* t2i;
   const unsigned* masks; // MASKS: the forward's sign masks (mlp_kernel.h layout)
+  float* d_emb;          // DX: gradient w.r.t. the embedding rows (P, ld_emb), only the kScnVoxPE voxel-feature columns are written
+  float* d_ov;           // DX (object branch): gradient w.r.t. the object voxel embedding (P, kObjVoxPE)
+  long ld_emb;
 };
 #ifndef OBJ_BWD_SPREAD_SAVE
 #define OBJ_BWD_SPREAD_SAVE 1   // MASKS: a layer's input-gradient tiles are stored one per MFMA group (the registers the raw
@@ -151,6 +154,24 @@ struct BwdHook {
     }
   }
 };
+// A tile of the embedding gradient to its rows of a (P, ld) matrix whose row stride is NOT a multiple of 16 bytes (ld = 271) and
+// whose last tile is only partly there (`cols` valid columns in all): through the wave's LDS patch like save_tile (8 lanes = one
+// point's 128 bytes), unaligned 16-byte stores, pieces beyond `cols` dropped.
+template <int NT>
+__device__ __forceinline__ void save_tile_cols(const f32x16 (&h)[NT], int t, float* mat, long ld, int cols, const Stage& sg) {
+  const int pt = sg.lane & 31, half = sg.lane >> 5, q = sg.lane >> 3, k = sg.lane & 7;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = {h[t][4 * g], h[t][4 * g + 1], h[t][4 * g + 2], h[t][4 * g + 3]};
+    *(f32x4*)(sg.buf + pt * kStageLd + 8 * g + 4 * half) = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + q;
+    const f32x4 v = *(const f32x4*)(sg.buf + row * kStageLd + 4 * k);
+    if (sg.p0 + row < sg.P && 32 * t + 4 * k + 4 <= cols) *(f32x4u*)(mat + (sg.p0 + row) * ld + 32 * t + 4 * k) = v;
+  }
+}
 template <int NT>
 __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT]) {
 #pragma unroll
@@ -169,8 +190,14 @@ __device__ __forceinline__ void add_head(f32x16 (&acc)[NT], const float* w, int 
   }
 }
 
-template <bool DO_OBJ, bool MASKS>
+// DX (voxel mode, MASKS): the gradients w.r.t. the voxel-feature columns of the embeddings are formed HERE -- while dZ5 / dZ1 / dB3 /
+// dB1 are in registers they are also contracted with those layers' embedding-column blocks (BL_X* of the stream) into accx / accxo,
+// which stay in registers to the end of the tile and are written once (312 floats per point).  Rounds 2-5 ran two segmented GEMMs
+// over the four gradient matrices afterwards (1.5 ms of an 18.6 ms step at 0.61 of peak, co-bound by re-reading what this kernel had
+// just written).
+template <bool DO_OBJ, bool MASKS, bool DX>
 __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const long ntiles) {
+  static_assert(!DX || MASKS, "the embedding-gradient fold rides on the mask-fed chain");
   constexpr int kCB = kChunkBytes;
   __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kCB + kAuxFloats * 4 + kStageBytes];
   const int tid = threadIdx.x;
@@ -178,7 +205,7 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
   const int half = lane >> 5;
   const int wave = tid >> 6;
   WeightStreamT<kCB> st;
-  st.init((const char*)a.blob_bwd, DO_OBJ ? bwd_total_chunks() : bwd_scene_chunks(), (lds_char*)ring_mem, tid);
+  st.init((const char*)a.blob_bwd, DO_OBJ ? bwd_total_chunks(DX) : bwd_scene_chunks(DX), (lds_char*)ring_mem, tid);
   float* aux_lds = (float*)(ring_mem + kRingSlots * kCB);
   for (int i = tid; i < kAuxFloats; i += 256) aux_lds[i] = a.aux[i];
   __syncthreads();
@@ -202,6 +229,7 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
     auto mrow_of = [&](int grp) __attribute__((always_inline)) {
       return MASKS ? a.masks + (sg_scene.p0 >> 5) * kMaskDwordsPerWave + ((long)grp * 64 + lane) * 4 : nullptr;
     };
+    f32x16 accx[DX ? 7 : 1];             // d(scene voxel embedding): 208 columns (7 tiles), live from X5 to the end of the tile
     // ---------------- scene branch ----------------
     {
       const Stage& sg = sg_scene;
@@ -235,6 +263,12 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
       // BL_S8 .. BL_S2 (BL_S5 streams the hidden block of the skip layer): dZ_l -> dZ_{l-1}
 #pragma unroll 1
       for (int l = 8; l >= 2; --l) {
+        if constexpr (DX) {
+          if (l == 5) {                 // (uniform) BL_X5: h = dZ5 also meets the skip layer's embedding columns
+            HidSrc<8> s{h};
+            layer_mac<7, bwd_ks(BL_X5), HidSrc<8>, NoHook, true>(accx, st, s);
+          }
+        }
         {
           HidSrc<8> s{h};
           layer_mac<8, 128, HidSrc<8>, BwdHook<8, 8, MASKS>, true>(acc, st, s, {h, dz.A(l), 256, act.A(l - 1), 256, mrow_of(kMaskGrpA + l - 2), raw, bits, sg});
@@ -242,6 +276,14 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
         mask_tiles<8>(acc, bits, h);
       }
       save_tiles<8>(h, dz.A(1), 256, sg);
+      if constexpr (DX) {               // BL_X1: h = dZ1
+        HidSrc<8> s{h};
+        layer_mac<7, bwd_ks(BL_X1), HidSrc<8>, NoHook, false>(accx, st, s);
+        if constexpr (!DO_OBJ) {
+#pragma unroll
+          for (int t = 0; t < 7; ++t) save_tile_cols<7>(accx, t, a.d_emb, a.ld_emb, kScnVoxPE, sg);
+        }
+      }
     }
 
     // ---------------- object branch ----------------
@@ -274,8 +316,16 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
       }
       add_head<4>(acc, aux + kAuxOSig, half, a.d_isigma[p]);
       mask_tiles<4>(acc, bits, h);
+      f32x16 accxo[DX ? 4 : 1];         // d(object voxel embedding): 104 columns (4 tiles)
 #pragma unroll 1
       for (int l = 4; l >= 2; --l) {
+        if constexpr (DX) {
+          if (l == 3) {                 // (uniform) BL_XS3, BL_XO3: h = dB3 meets the skip layer's scene- / object-voxel columns
+            HidSrc<4> s{h};
+            layer_mac<7, bwd_ks(BL_XS3), HidSrc<4>, NoHook, false>(accx, st, s);
+            layer_mac<4, bwd_ks(BL_XO3), HidSrc<4>, NoHook, true>(accxo, st, s);
+          }
+        }
         {
           HidSrc<4> s{h};
           layer_mac<4, 64, HidSrc<4>, BwdHook<4, 4, MASKS>, true>(acc, st, s, {h, dz.B(l), 128, act.B(l - 1), 128, mrow_of(kMaskGrpB + l - 2), raw, bits, sg});
@@ -283,6 +333,15 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
         mask_tiles<4>(acc, bits, h);
       }
       save_tiles<4>(h, dz.B(1), 128, sg);
+      if constexpr (DX) {               // BL_XS1, BL_XO1: h = dB1; then the finished embedding gradients leave the registers
+        HidSrc<4> s{h};
+        layer_mac<7, bwd_ks(BL_XS1), HidSrc<4>, NoHook, false>(accx, st, s);
+        layer_mac<4, bwd_ks(BL_XO1), HidSrc<4>, NoHook, false>(accxo, st, s);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) save_tile_cols<7>(accx, t, a.d_emb, a.ld_emb, kScnVoxPE, sg);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) save_tile_cols<4>(accxo, t, a.d_ov, kObjVoxPE, kObjVoxPE, sg);
+      }
     }
   }
 }
@@ -290,17 +349,25 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(const BwdArgs a, const 
 long train_mask_floats_host(long n_points) { return train_mask_floats(n_points); }
 
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,
-                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, const unsigned* masks, hipStream_t s) {
-  static_assert(bwd_scene_chunks() == 68 || kChunkTiles != 128, "backward stream layout");
-  const BwdArgs a{blob_bwd, aux, P, act, dz, d_sigma, t2, d_isigma, t2i, masks};
+                   const float* t2, const float* d_isigma, const float* t2i, bool do_object, const unsigned* masks, bool dx,
+                   float* d_emb, long ld_emb, float* d_ov, hipStream_t s) {
+  static_assert(bwd_scene_chunks(false) == 68 || kChunkTiles != 128, "backward stream layout");
+  // dx: the stream carries the embedding-gradient blocks (objnerf_pack_index_bwd mode 2) and the kernel walks them, i.e. forms
+  // those gradients itself: needs the mask-fed chain and the two destinations
+  if (dx && (!masks || !d_emb || (do_object && !d_ov)))
+    return set_error(-1, "mlp_train_backward(fused): a blob_bwd with the embedding-gradient blocks needs the forward's masks, d_emb_xyz (and d_obj_voxel)");
+  const BwdArgs a{blob_bwd, aux, P, act, dz, d_sigma, t2, d_isigma, t2i, masks, d_emb, d_ov, ld_emb};
   const long ntiles = (P + 127) / 128;
   const unsigned grid = mlp_grid(ntiles);
-  if (masks) {
-    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
-    else hipLaunchKernelGGL((mlp_bwd_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  if (dx) {
+    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+  } else if (masks) {
+    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<false, true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
   } else {
-    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
-    else hipLaunchKernelGGL((mlp_bwd_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+    if (do_object) hipLaunchKernelGGL((mlp_bwd_kernel<true, false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<false, false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
   }
   return check_launch("mlp_train_backward(fused)");
 }

@@ -160,7 +160,7 @@ struct ATiles { f32x4 v[NT]; };
 
 template <int NT, int G, class Stream>
 __device__ __forceinline__ void load_group(ATiles<NT>& a, Stream& st) {
-  constexpr int KG = kChunkTiles / NT;
+  constexpr int KG = chunk_ksteps(NT);      // (= kChunkTiles / NT for 1, 2, 4, 8 tiles)
   constexpr int ks0 = G * 4;
   if constexpr (ks0 % KG == 0) st.next_chunk();
   constexpr int g4 = (ks0 % KG) / 4;
@@ -192,7 +192,7 @@ __device__ __forceinline__ void layer_mac(f32x16 (&acc)[NT], Stream& st, Src& sr
   constexpr int SK0 = SkipT::k0, SK1 = SkipT::k1;
   static_assert(SK0 == SK1 || SK0 > 0, "group 0 is never skipped");
   constexpr int NG4 = (KS + 3) / 4;
-  constexpr int KG = kChunkTiles / NT;
+  constexpr int KG = chunk_ksteps(NT);      // (= kChunkTiles / NT for 1, 2, 4, 8 tiles)
   // spread mode: the 8 DMA pieces of the chunk after the current one are issued in front of the chunk's MFMA groups
   constexpr int GPC = KG / 4;                                  // groups per chunk
   // pieces per group, front-loaded into the first half of the chunk's groups: the chunk is opened (barrier, vmcnt(0))

@@ -1147,13 +1147,17 @@ __device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_l
   }
 }
 
-__global__ void __launch_bounds__(256) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ rbA) {
+// Eight waves: the A slices (96 KB: one workgroup per CU) leave room for only ONE wave per SIMD with four -- nothing then overlaps a
+// wave's own sin / cos, operand selects, stores and input round trips with its MFMAs (matrix pipe 0.35 busy, 235 us).  Waves w and
+// w + 4 share tile set w's slice and take alternate 32-ray groups: two waves per SIMD, one's MFMAs under the other's VALU / memory.
+__global__ void __launch_bounds__(512) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ rbA) {
   __shared__ __attribute__((aligned(16))) float a_lds[4 * kRbWaveFloats];
   __shared__ __attribute__((aligned(16))) float bias_lds[kRayBiasFloats];
   const long n = a.n_active ? (long)*a.n_active : a.n_rays;
   const long groups = (n + 31) >> 5;
-  if ((long)blockIdx.x >= groups) return;                       // (uniform) the grid is sized for n_rays, a culled subset may need less
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  if (2 * (long)blockIdx.x >= groups) return;                   // (uniform) the grid is sized for n_rays, a culled subset may need less
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), sub = __builtin_amdgcn_readfirstlane(tid >> 8);
   // this wave's tiles
   const int tc = 2 * wave;                                      // code tiles tc, tc + 1
   const int td = wave < 2 ? kRbCodeTiles + 2 * wave : kRbCodeTiles + 2 + wave;      // direction tiles td (, td + 1 when wave < 2)
@@ -1167,12 +1171,12 @@ __global__ void __launch_bounds__(256) ray_bias_kernel(const RayBiasArgs a, cons
     const float* src_d = rbA + rb_tile_start(td);
     const int n_c = 2 * kRbCodeQ * 64, n_d = nd * kRbDirQ * 64;           // float4 counts
     if (code_live)
-      for (int i = lane; i < n_c; i += 64) *(f32x4*)(my + 4 * i) = gload4(src_c + 4 * i);
+      for (int i = lane + 64 * sub; i < n_c; i += 128) *(f32x4*)(my + 4 * i) = gload4(src_c + 4 * i);
     if (dir_live)
-      for (int i = lane; i < n_d; i += 64) *(f32x4*)(my + 2 * kRbCodeQ * 256 + 4 * i) = gload4(src_d + 4 * i);
-    for (int i = tid; i < kRayBiasFloats; i += 256) bias_lds[i] = rbA[kRbAFloats + i];
+      for (int i = lane + 64 * sub; i < n_d; i += 128) *(f32x4*)(my + 2 * kRbCodeQ * 256 + 4 * i) = gload4(src_d + 4 * i);
+    for (int i = tid; i < kRayBiasFloats; i += 512) bias_lds[i] = rbA[kRbAFloats + i];
   }
-  __syncthreads();                                              // (the biases are shared; the A slices are wave-private)
+  __syncthreads();                                              // (the biases are shared; an A slice belongs to one pair of waves)
   const int off_c[2] = {rb_tile_off(tc), rb_tile_off(tc + 1)};
   const int off_d[2] = {rb_tile_off(td), rb_tile_off(td + (nd == 2 ? 1 : 0))};
   // the inputs of a 32-ray group: this lane's half of the ray's code and the ray's direction; the NEXT group's are in flight
@@ -1198,12 +1202,12 @@ __global__ void __launch_bounds__(256) ray_bias_kernel(const RayBiasArgs a, cons
       for (int c = 0; c < 3; ++c) dout[c] = a.rays[ray_o * 8 + 3 + c];
     }
   };
-  fetch(blockIdx.x, x, d, ray, valid);
-  for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+  fetch(2 * (long)blockIdx.x + sub, x, d, ray, valid);
+  for (long grp = 2 * (long)blockIdx.x + sub; grp < groups; grp += 2 * (long)gridDim.x) {
     float xn[32], dn[3];
     long ray_n = 0;
     bool valid_n = false;
-    const long nxt = grp + gridDim.x;
+    const long nxt = grp + 2 * (long)gridDim.x;
     if (nxt < groups) fetch(nxt, xn, dn, ray_n, valid_n);              // (uniform)
     float* out = a.out + ray * kRayBiasFloats;
     if (code_live) rb_tiles<2, kRbCodeQ, 32>(my, bias_lds, off_c, lane, valid, out, x);
@@ -1581,9 +1585,10 @@ int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   if (m->n_rays == 0) return 0;
   RayBiasArgs a{m->blob, m->aux, m->rays, m->codes, (long)m->code_stride, (long)m->n_rays, m->use_voxel, m->do_scene, m->do_object, out,
                 m->ray_index, m->n_active};
-  // a workgroup per 32 rays, at most 512 of them (one is resident per CU -- 98 KB of LDS -- and walks its groups with a stride)
-  const long groups = (m->n_rays + 31) / 32;
-  hipLaunchKernelGGL(ray_bias_kernel, dim3((unsigned)(groups < 512 ? groups : 512)), dim3(256), 0, (hipStream_t)stream, a,
+  // a workgroup (two sets of four waves) per 64 rays, at most one per CU (98 KB of LDS: one is resident) -- it walks its pairs of
+  // 32-ray groups with a stride
+  const long pairs = (m->n_rays + 63) / 64;
+  hipLaunchKernelGGL(ray_bias_kernel, dim3(mlp_grid(pairs)), dim3(512), 0, (hipStream_t)stream, a,
                      m->aux + kAuxFloats);
   return check_launch("ray_bias");
 }

@@ -361,6 +361,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
 
   PhaseClock clk(c.s);
   struct EndClock { PhaseClock& c; ~EndClock() { c.end(); } } end_clock{clk};
+  bool dx_fused = false;                  // the fused chain also formed d_emb_xyz / d_obj_voxel (objnerf_train_args.bwd_dx)
   // ---- phase A: the dgrad chain through the hidden layers -> d.* ----
   clk.begin(PH_DGRAD);
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(3 * P)), dim3(256), 0, c.s, t2, d_rgb, a->rgb, 3 * P);
@@ -377,8 +378,12 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     const bool use_masks = a->blob != nullptr && [] { const char* e = getenv("OBJNERF_BWD_MASKS"); return !e || atoi(e) != 0; }();
 #endif
     const unsigned* masks = use_masks ? (const unsigned*)(a->workspace + ws_act_floats(obj, P)) : nullptr;
-    if (!c.rc) c.rc = launch_mlp_bwd(a->blob_bwd, a->aux, P, a->workspace, scratch, d_sigma, t2, d_inst_sigma, t2i, obj, masks, c.s);
+    dx_fused = a->bwd_dx != 0;
+    if (dx_fused && !vox) return set_error(-1, "mlp_train_backward: bwd_dx marks a voxel-mode stream");
+    if (!c.rc) c.rc = launch_mlp_bwd(a->blob_bwd, a->aux, P, a->workspace, scratch, d_sigma, t2, d_inst_sigma, t2i, obj, masks, dx_fused,
+                                     d_emb_xyz, cx, obj ? d_obj_voxel : nullptr, c.s);
   } else {
+    if (a->bwd_dx) return set_error(-1, "mlp_train_backward: bwd_dx without blob_bwd");
     // layer by layer: dX = dY W as a GEMM with the LeakyReLU backward in its epilogue
     lin_dgrad(c, t2, 3, Wt(P_SRGB), 128, P, 3, 128, d.dirh(), 128, 0, w.dirh());
     lin_dgrad(c, d.dirh(), 128, Wt(P_SD), 256 + kDirC, P, 128, 256, d.final_(), 256, 0);
@@ -407,10 +412,11 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
     const int ov = vox ? kObjVoxPE : 0;
     const DgradSeg emb[4] = {{d.A(5), 256, Wt(P_S5), cx + 256, 256}, {d.A(1), 256, Wt(P_S1), cx, 256},
                              {d.B(3), 128, Wt(P_O3), co + 128, 128}, {d.B(1), 128, Wt(P_O1), co, 128}};
-    if (ce) lin_dgrad_multi(c, emb, obj ? 4 : 2, P, ce, d_emb_xyz, cx);       // only the voxel-feature columns (see above)
+    // (dx_fused: the chain kernel has formed both already, from the gradient tiles while they were in registers)
+    if (ce && !dx_fused) lin_dgrad_multi(c, emb, obj ? 4 : 2, P, ce, d_emb_xyz, cx);       // only the voxel-feature columns (see above)
     if (obj) {
       const DgradSeg ovs[2] = {{d.B(3), 128, Wt(P_O3) + cx, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx, co, 128}};
-      if (vox) lin_dgrad_multi(c, ovs, 2, P, kObjVoxPE, d_obj_voxel, kObjVoxPE);
+      if (vox && !dx_fused) lin_dgrad_multi(c, ovs, 2, P, kObjVoxPE, d_obj_voxel, kObjVoxPE);
       const DgradSeg cds[2] = {{d.B(3), 128, Wt(P_O3) + cx + ov, co + 128, 128}, {d.B(1), 128, Wt(P_O1) + cx + ov, co, 128}};
       if (!per_ray) lin_dgrad_multi(c, cds, 2, P, kCodeC, d_obj_code, kCodeC);
     }

@@ -52,7 +52,8 @@ def _pack_index(use_voxel, device):
 
 
 def _pack_index_bwd(use_voxel, device):
-    key = ("bwd", bool(use_voxel), str(device))
+    """use_voxel: objnerf_pack_index_bwd's mode -- 0 plain, 1 voxel, 2 voxel + embedding-gradient blocks"""
+    key = ("bwd", int(use_voxel), str(device))
     if key not in _index_cache:
         l = _lib.lib()
         bi = torch.empty(l.objnerf_bwd_blob_floats(), dtype=torch.int32)
@@ -177,15 +178,18 @@ class ObjectNeRF(nn.Module):
         """(blob, aux) device tensors for the kernels, gathered from the parameters as they are NOW (on the current stream)."""
         return pack_models([self])[0]
 
-    def packed_bwd(self):
+    def packed_bwd(self, dx=False):
         """Training only: device tensor with the transposed hidden-block weight stream of the fused backward
-        (objnerf_pack_weights_bwd), gathered from the parameters as they are now."""
+        (objnerf_pack_weights_bwd), gathered from the parameters as they are now.  dx (voxel mode): the stream also carries the
+        embedding-column blocks, the chain kernel then forms the embedding gradients itself (objnerf_train_args.bwd_dx)."""
         params = self._param_list()
         dev = params[0].device
         _lib.require_cuda(params[0], "ObjectNeRF parameters")
         l = _lib.lib()
         srcs = [_lib.as_f32(p.detach()) for p in params]
-        idx = _pack_index_bwd(int(self.use_voxel_embedding), dev)
+        if dx and not self.use_voxel_embedding:
+            raise RuntimeError("packed_bwd(dx=True) is a voxel-mode stream")
+        idx = _pack_index_bwd(2 if dx else int(self.use_voxel_embedding), dev)
         blob = torch.empty(l.objnerf_bwd_blob_floats(), dtype=torch.float32, device=dev)
         table = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
         _lib.check(l.objnerf_pack_weights_bwd(_lib.ptr(idx), table, _lib.ptr(blob), _lib.stream_ptr()), "pack_weights_bwd")

@@ -141,7 +141,13 @@ def _train_packs(coarse, fine):
         if m is None:
             return None
         blob, aux = m.packed()          # gathered from the parameters as they are now (nothing is cached)
-        return (None if mode == "fwd" else blob, aux, None if mode == "bwd" else m.packed_bwd())
+        fwd_blob = None if mode == "fwd" else blob
+        # voxel mode with fused forward AND fused backward (the default): the backward's stream carries the embedding-column blocks and
+        # the chain kernel forms the embedding gradients itself (round 6; OBJNERF_BWD_DX=0: the two GEMMs after the chain, rounds 2-5).
+        # It rides on the mask-fed chain, i.e. on the masks the fused forward leaves.
+        dx = (bool(m.use_voxel_embedding) and fwd_blob is not None and mode != "bwd" and os.environ.get("OBJNERF_BWD_DX", "1") != "0"
+              and os.environ.get("OBJNERF_BWD_MASKS", "1") != "0")
+        return (fwd_blob, aux, None if mode == "bwd" else m.packed_bwd(dx=dx), dx)
     return (one(coarse), one(fine))
 
 

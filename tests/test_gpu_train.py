@@ -333,9 +333,12 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
     d_sigma, d_rgb = torch.randn(P, device=DEV, generator=g), torch.randn(P, 3, device=DEV, generator=g)
     d_isig, d_irgb = (torch.randn(P, device=DEV, generator=g), torch.randn(P, 3, device=DEV, generator=g)) if fi else (None, None)
 
-    def backward(fused, a_l=a_l):
+    blob_bwd_dx = m.packed_bwd(dx=True) if use_voxel else None
+
+    def backward(fused, a_l=a_l, dx=False):
         a_l.aux = aux.data_ptr()
-        a_l.blob_bwd = blob_bwd.data_ptr() if fused else None
+        a_l.blob_bwd = (blob_bwd_dx if dx else blob_bwd).data_ptr() if fused else None
+        a_l.bwd_dx = int(dx)
         grads = [torch.zeros_like(p) for p in params]
         gt = (C.c_void_p * len(grads))(*[t.data_ptr() for t in grads])
         d_emb = torch.zeros_like(x["emb"])        # only the voxel-feature columns are written
@@ -372,6 +375,25 @@ def test_training_kernels_against_layerwise_gemms(sname, fi):
     g_gemm_f = backward(False, a_f)
     worst = max(rel_l2(u, v) for u, v in zip(g_masks, g_gemm_f) if v.abs().max().item() > 0)
     assert worst < 1e-5, worst
+
+    # round 6 (objnerf_train_args.bwd_dx, voxel mode): the chain also contracts dZ5 / dZ1 / dB3 / dB1 with those layers' voxel-feature
+    # columns while the tiles are in registers, instead of two segmented GEMMs re-reading the four matrices afterwards.  The chain
+    # itself is untouched -- every parameter gradient and d_code bit-equal -- and d_emb_xyz / d_obj_voxel are the same sums in another
+    # association; only the voxel-feature columns of d_emb_xyz are written.
+    if use_voxel:
+        g_dx = backward(True, a_f, dx=True)
+        n_par = len(params)
+        for i in range(n_par):
+            assert torch.equal(g_dx[i], g_masks[i]), "parameter gradient %d changed under bwd_dx" % i
+        assert rel_l2(g_dx[n_par], g_masks[n_par]) < 1e-5 and rel_l2(g_dx[n_par], g_gemm_f[n_par]) < 1e-5
+        assert g_dx[n_par][:, 208:].abs().max().item() == 0 and g_dx[n_par][:, :208].abs().max().item() > 0
+        assert not torch.equal(g_dx[n_par], g_masks[n_par]), "bwd_dx did not select the folded form"
+        if fi:
+            assert rel_l2(g_dx[n_par + 1], g_masks[n_par + 1]) < 1e-5, rel_l2(g_dx[n_par + 1], g_masks[n_par + 1])
+            assert torch.equal(g_dx[n_par + 2], g_masks[n_par + 2])
+        print(sname, fi, "embedding gradients formed inside the chain vs the two GEMMs: rel L2 %.2e" % rel_l2(g_dx[n_par], g_masks[n_par]))
+        with pytest.raises(RuntimeError, match="masks"):      # a layer-wise forward left no masks: refused, not computed from garbage
+            backward(True, a_l, dx=True)
 
 
 @pytest.mark.parametrize("S", [128, 192])
@@ -806,6 +828,44 @@ def test_per_ray_terms_match_the_per_point_contraction(monkeypatch):
         elif k not in ("codes", "table"):
             assert torch.equal(a[k], b[k]), k
     assert changed > 0, "the per-ray form was not selected"
+
+
+def test_embedding_gradients_folded_into_the_chain_match_the_gemms(monkeypatch):
+    """render_rays end to end, voxel mode: the default backward forms d_emb_xyz / d_obj_voxel inside the fused dgrad chain (round 6,
+    objnerf_train_args.bwd_dx) -- against the two segmented GEMMs after the chain (OBJNERF_BWD_DX=0, rounds 2-5).  Only the voxel
+    table's gradient sits downstream of those matrices: it agrees to 2e-5 relative L2 and is NOT bit-equal (the switch selected
+    another path); every MLP gradient of both models and the code gradient are bit-equal."""
+    sc = cases.scene_for(A, "voxel", device=DEV)
+    n = 512
+    rays = H.test_rays(n, w=256, h=192, stride=23).to(DEV)
+    ids = synth.per_ray_ids(n, seed=5).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    rd = dict(perturb_rand=torch.rand(n, 64, generator=g).to(DEV), u_rand=torch.rand(n, 64, generator=g).to(DEV),
+              noise=[torch.randn(n, s, generator=g).to(DEV) for s in (64, 64, 128, 128)])
+    mods = (sc.models["coarse"], sc.models["fine"])
+
+    def grads():
+        for m in mods + (sc.code_library, sc.embeddings["xyz"]):
+            m.zero_grad()
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        res = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                            embedding_instance=codes, frustum_bound_th=0.025, _randoms=rd)
+        _loss(res).backward()
+        torch.cuda.synchronize()
+        out = {"%d.%s" % (i, k): p.grad.clone() for i, m in enumerate(mods) for k, p in m.named_parameters()}
+        out["codes"] = sc.code_library.embedding_instance.weight.grad.clone()
+        out["table"] = sc.embeddings["xyz"].embedding_space_ftr.weight.grad.clone()
+        return out
+    monkeypatch.delenv("OBJNERF_BWD_DX", raising=False)
+    a = grads()
+    monkeypatch.setenv("OBJNERF_BWD_DX", "0")
+    b = grads()
+    monkeypatch.delenv("OBJNERF_BWD_DX", raising=False)
+    for k in a:
+        if k != "table":
+            assert torch.equal(a[k], b[k]), k
+    assert rel_l2(a["table"], b["table"]) < 2e-5, rel_l2(a["table"], b["table"])
+    assert not torch.equal(a["table"], b["table"]), "OBJNERF_BWD_DX did not select another path"
 
 
 def test_hoisted_training_forward_matches_the_per_sample_contraction(monkeypatch):
