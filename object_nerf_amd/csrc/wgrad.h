@@ -49,7 +49,8 @@ struct WgradArgs {             // passed by value (2.5 KB of kernel arguments: n
   int nprod, ntile, nfull;     // tile[0 .. nfull) are full tiles, tile[nfull .. ntile) ragged ones
   int nbig;                    // tile[0 .. nbig) (a multiple of 4): the quadrants (0,0) (0,1) (1,0) (1,1) of 256 x 256 tiles, one
                                // workgroup each (wgrad_big_kernel); wgrad_units_kernel<false> takes tile[nbig .. nfull)
-  int nz;                      // k slices per tile
+  int nz;                      // k slices per tile (and the slot stride of every tile)
+  int nzb;                     // k slices per 256 x 256 tile, <= nz (round 6): as many as make ONE round of workgroups, see launch()
   int xcd;                     // XCD-aware unit map (tuning switch OBJNERF_WGRAD_XCD)
   long P;
   float* partials;             // slot (tile t, slice z) at (t * slices + z) * kWgradSlotFloats

@@ -341,9 +341,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const long P = uni(a.P);
   const long KT = (P + GBK - 1) / GBK;
-  const int nz = uni(a.nz);
-  const long L = (KT + nz - 1) / nz;                       // k iterations per slice
-  const int b = uni((int)(blockIdx.x / (unsigned)nz)), z = uni((int)(blockIdx.x % (unsigned)nz));   // product by product, slice by slice
+  const int nz = uni(a.nz), nzb = uni(a.nzb);              // (nz: the slot stride; nzb: this kernel's slices per tile)
+  const long L = (KT + nzb - 1) / nzb;                     // k iterations per slice
+  const int b = uni((int)(blockIdx.x / (unsigned)nzb)), z = uni((int)(blockIdx.x % (unsigned)nzb));   // product by product, slice by slice
   const int t0 = 4 * b;                                    // first quadrant's tile
   const WgProduct& prv = a.prod[a.tile[t0].prod];
   const float* A = uni(prv.A); const float* B = uni(prv.B);
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
 __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __restrict__ ap) {
   const WgradArgs& a = *ap;
   const int t = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
-  const int nz = a.nz;
+  const int nz = a.nz, nzt = t < a.nbig ? a.nzb : a.nz;          // slot stride; slices this tile was cut into
   const WgTile tl = a.tile[t];
   const WgProduct pr = a.prod[tl.prod];
   float acc[8];
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __res
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   float rs = 0.f;
   const bool want_rs = part == 0 && pr.rowsum && tl.bx == 0 && tid < 128;
-  for (int z = 0; z < nz; ++z) {
+  for (int z = 0; z < nzt; ++z) {
     const float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] += gload(slot + (part * 8 + i) * 256 + tid);
@@ -693,12 +693,31 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s, int slices) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
     const long KTl = (P + GBK - 1) / GBK;
-    const int nz = a.nz = slices > 0 ? (int)(slices < KTl ? slices : KTl) : wgrad_pick_slices(P, a.nbig / 4, a.nfull - a.nbig);
+    // 256 x 256 tiles (round 6): ONE round of workgroups -- cus / tiles slices per tile, one workgroup per CU for the whole launch --
+    // instead of the ~6 rounds the 64-k-tile slices make at the reference batch: a quarter of the partial tiles to write and to
+    // add up again (1,530 x 256 KB per fine pass before), one prologue / epilogue per CU.  The 128 x 128 tiles keep their slices
+    // (two workgroups per CU, operand panels shared through L2 by the tiles of a slice).  OBJNERF_WGRAD_BIG_ROUNDS=many: as before.
+    static const bool one_round = [] { const char* e = getenv("OBJNERF_WGRAD_BIG_ROUNDS"); return !e || strcmp(e, "many") != 0; }();
+    static const int cus_n = [] {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n > 0 ? n : 256;
+    }();
+    const bool split = one_round && slices <= 0 && a.nbig > 0;
+    const int nz = a.nz = slices > 0 ? (int)(slices < KTl ? slices : KTl)
+                                     : wgrad_pick_slices(P, split ? 0 : a.nbig / 4, a.nfull - a.nbig);
+    int nzb = nz;
+    if (split) {
+      nzb = cus_n / (a.nbig / 4);
+      if (nzb > nz) nzb = nz;              // (the slot area is strided by nz)
+      if (nzb < 1) nzb = 1;
+    }
+    a.nzb = nzb;
     static const int xcd = [] { const char* e = getenv("OBJNERF_WGRAD_XCD"); return e ? atoi(e) : 0; }();
     static const int prio = [] { const char* e = getenv("OBJNERF_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
     a.xcd = (xcd & 1) | ((prio & 3) << 1);
     hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
-    if (a.nbig > 0) hipLaunchKernelGGL(wgrad_big_kernel, dim3((a.nbig / 4) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
+    if (a.nbig > 0) hipLaunchKernelGGL(wgrad_big_kernel, dim3((a.nbig / 4) * nzb), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.nfull > a.nbig) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3((a.nfull - a.nbig) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
     hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);
