@@ -1110,9 +1110,10 @@ __device__ __forceinline__ int rb_bias_src(int o) {
 constexpr int kRbWaveFloats = (2 * kRbCodeQ + 2 * kRbDirQ) * 256;       // the largest per-wave A slice: 24 KB
 __device__ __forceinline__ f32x4 rb_lds16(const float* p) { return *(const __attribute__((address_space(3))) f32x4*)p; }
 
+constexpr int kRbPatchLd = 36;                       // floats per ray row of a wave's store patch (32 + 4: rows land on distinct banks)
 template <int NT, int NQ, int KS>
-__device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_lds, const int (&off)[2], int lane, bool store, float* out,
-                                         const float (&bop)[KS]) {
+__device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_lds, const int (&off)[2], int lane, float* patch,
+                                         const int (&rayrow)[4], float* out_base, const float (&bop)[KS]) {
   // NT tiles side by side (independent accumulators between dependent MFMAs), NQ groups of 4 k-steps, KS valid k-steps
   f32x16 acc[NT];
   const int h = lane >> 5;
@@ -1132,38 +1133,67 @@ __device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_l
     for (int j = 0; j < 4; ++j)
       if (4 * q + j < KS) {
 #pragma unroll
+#ifdef OBJ_RB_PROBE_NO_MFMA    // attribution probe: the stores and loads alone (one FMA per k-step keeps operands and reads alive)
+        for (int t = 0; t < NT; ++t) acc[t][j] = fmaf(a4[t][j], bop[4 * q + j], acc[t][j]);
+#else
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][j], bop[4 * q + j], acc[t], 0, 0, 0);
+#endif
       }
   }
-  // the D layout of a tile is the 16-float piece [m][h][0..15] of the ray's vector.  (Turning the pieces into whole 128-byte
-  // lines through an LDS patch first was measured: 244 -> 239 us, i.e. nothing -- the kernel is bound by its VALU work, not by
-  // the store requests -- and taken out again.)
-  if (store) {
+  // The D layout of a tile is the 16-float piece [m][h][0..15] of the ray's vector: 64 bytes per lane, a ray's two halves 128
+  // contiguous bytes.  Stored straight from the registers, an instruction writes 16 bytes into each of 64 different 64-byte
+  // segments -- 34 M quarter-filled write requests per frame pass, which is what the kernel then waits for (probes,
+  // profiles/r06_ray_bias_probe.txt: 253 us with the stores, 139 without, 125 without stores and input loads).  Through the wave's
+  // own LDS patch 8 consecutive lanes write one ray's whole 128-byte line (a quarter of the requests).
+  // EVERY lane stores, no branch around the stores: a row past the end of the batch carries the LAST ray's inputs (fetch clamps its
+  // slot) and re-writes that ray's row with the same bits.  A `valid` predicate made the stores a skippable block, the wait-count
+  // pass then priced every wait for the next group's inputs by the path without them: vmcnt(0), a full drain per iteration.
+#ifdef OBJ_RB_PROBE_NO_STORE      // attribution probe (tools/ray_bias_probe.py): only a value-dependent, never-true store keeps the MFMAs alive
+  if (acc[0][0] == 1.2345e-31f) out_base[0] = acc[NT - 1][5];
+#else
+  const int pt = lane & 31, rq = lane >> 3, k = lane & 7;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
-        *(f32x4u*)(out + off[t] + 16 * h + 4 * q4) = f32x4{acc[t][4 * q4], acc[t][4 * q4 + 1], acc[t][4 * q4 + 2], acc[t][4 * q4 + 3]};
+    for (int q4 = 0; q4 < 4; ++q4)
+      *(f32x4*)(patch + pt * kRbPatchLd + 16 * h + 4 * q4) = f32x4{acc[t][4 * q4], acc[t][4 * q4 + 1], acc[t][4 * q4 + 2], acc[t][4 * q4 + 3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = *(const f32x4*)(patch + (8 * i + rq) * kRbPatchLd + 4 * k);
+      *(f32x4u*)(out_base + (long)rayrow[i] * kRayBiasFloats + off[t] + 4 * k) = v;
+    }
   }
+#endif
 }
 
 // Eight waves: the A slices (96 KB: one workgroup per CU) leave room for only ONE wave per SIMD with four -- nothing then overlaps a
 // wave's own sin / cos, operand selects, stores and input round trips with its MFMAs (matrix pipe 0.35 busy, 235 us).  Waves w and
 // w + 4 share tile set w's slice and take alternate 32-ray groups: two waves per SIMD, one's MFMAs under the other's VALU / memory.
+// SCENE / OBJ are template parameters so that the usual call (both) has no uniform branch around the input loads or the stores: the
+// wait-count pass prices a wait by the path with the FEWEST memory operations behind the awaited one, and a skippable block of
+// stores or loads between a load and its use turns the wait into vmcnt(0).
+template <bool SCENE, bool OBJ>
 __global__ void __launch_bounds__(512) ray_bias_kernel(const RayBiasArgs a, const float* __restrict__ rbA) {
   __shared__ __attribute__((aligned(16))) float a_lds[4 * kRbWaveFloats];
   __shared__ __attribute__((aligned(16))) float bias_lds[kRayBiasFloats];
+  __shared__ __attribute__((aligned(16))) float patch_lds[8 * 32 * kRbPatchLd];       // a 32-ray x 128-byte store patch per wave
   const long n = a.n_active ? (long)*a.n_active : a.n_rays;
   const long groups = (n + 31) >> 5;
   if (2 * (long)blockIdx.x >= groups) return;                   // (uniform) the grid is sized for n_rays, a culled subset may need less
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), sub = __builtin_amdgcn_readfirstlane(tid >> 8);
+  // The two waves of a SIMD do identical work from an identical start: at equal priority they share the matrix pipe round-robin,
+  // finish their MFMAs together and then store together -- chip-wide, product phases and store phases alternate instead of
+  // overlapping (probes: 144 us of products, 138 us of stores at the write path's 4 TB/s, 225 us together).  With set 0 above set 1
+  // the first runs its products at full rate while the second waits, then stores while the second computes: anti-phase from then on.
+  if (sub == 0) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
   // this wave's tiles
   const int tc = 2 * wave;                                      // code tiles tc, tc + 1
   const int td = wave < 2 ? kRbCodeTiles + 2 * wave : kRbCodeTiles + 2 + wave;      // direction tiles td (, td + 1 when wave < 2)
   const int nd = wave < 2 ? 2 : 1;
-  const bool code_live = a.do_object != 0;
-  const bool dir_live = td < 12 ? a.do_scene != 0 : a.do_object != 0;
+  constexpr bool code_live = OBJ;
+  const bool dir_live = (SCENE && OBJ) ? true : (td < 12 ? SCENE : OBJ);
   float* my = a_lds + wave * kRbWaveFloats;
   {
     // stage: [code tile tc | code tile tc + 1 | direction tile(s)] -- contiguous runs of the stream, 16 bytes per lane and step
@@ -1181,65 +1211,83 @@ __global__ void __launch_bounds__(512) ray_bias_kernel(const RayBiasArgs a, cons
   const int off_d[2] = {rb_tile_off(td), rb_tile_off(td + (nd == 2 ? 1 : 0))};
   // the inputs of a 32-ray group: this lane's half of the ray's code and the ray's direction; the NEXT group's are in flight
   // while the current group's products run (one wave per SIMD: nothing else hides the round trip)
-  float x[32], d[3];
-  long ray = 0;
-  bool valid = false;
-  auto fetch = [&](long grp, float (&xo)[32], float (&dout)[3], long& ray_o, bool& valid_o) __attribute__((always_inline)) {
+  struct In { float x[32]; float d[3]; long ray; };
+  auto fetch = [&](long grp, In& o) __attribute__((always_inline)) {
     const long slot = grp * 32 + (lane & 31);
-    valid_o = slot < n;
-    const long sl = valid_o ? slot : n - 1;
-    ray_o = a.ray_index ? (long)a.ray_index[sl] : sl;        // vectors stay indexed by the ray's own number
+    const long sl = slot < n ? slot : n - 1;                 // lanes past the end repeat the last ray (and re-write its row, see rb_tiles)
+    o.ray = a.ray_index ? (long)a.ray_index[sl] : sl;        // vectors stay indexed by the ray's own number
     if (code_live) {
-      const float* cp = a.codes + ray_o * a.code_stride + 32 * h;
+      const float* cp = a.codes + o.ray * a.code_stride + 32 * h;
 #pragma unroll
       for (int c4 = 0; c4 < 8; ++c4) {
+#ifdef OBJ_RB_PROBE_NO_LOAD
+        const f32x4 v = {(float)c4, 1.f, (float)lane, 0.5f};
+#else
         const f32x4 v = *(const f32x4u*)(cp + 4 * c4);
-        xo[4 * c4] = v[0]; xo[4 * c4 + 1] = v[1]; xo[4 * c4 + 2] = v[2]; xo[4 * c4 + 3] = v[3];
+#endif
+        o.x[4 * c4] = v[0]; o.x[4 * c4 + 1] = v[1]; o.x[4 * c4 + 2] = v[2]; o.x[4 * c4 + 3] = v[3];
       }
     }
     if (dir_live) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) dout[c] = a.rays[ray_o * 8 + 3 + c];
+      for (int c = 0; c < 3; ++c) o.d[c] = a.rays[o.ray * 8 + 3 + c];
     }
   };
-  fetch(2 * (long)blockIdx.x + sub, x, d, ray, valid);
-  for (long grp = 2 * (long)blockIdx.x + sub; grp < groups; grp += 2 * (long)gridDim.x) {
-    float xn[32], dn[3];
-    long ray_n = 0;
-    bool valid_n = false;
-    const long nxt = grp + 2 * (long)gridDim.x;
-    if (nxt < groups) fetch(nxt, xn, dn, ray_n, valid_n);              // (uniform)
-    float* out = a.out + ray * kRayBiasFloats;
-    if (code_live) rb_tiles<2, kRbCodeQ, 32>(my, bias_lds, off_c, lane, valid, out, x);
+  float* const patch = patch_lds + (tid >> 6) * 32 * kRbPatchLd;
+  auto compute = [&](const In& in) __attribute__((always_inline)) {
+    // the ray numbers of the four rows this lane stores for (row 8 i + lane / 8 of the group: lane `row` holds it)
+    int rayrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rayrow[i] = __shfl((int)in.ray, 8 * i + (lane >> 3));
+    float* const out = a.out;
+    if (code_live) rb_tiles<2, kRbCodeQ, 32>(my, bias_lds, off_c, lane, patch, rayrow, out, in.x);
     if (dir_live) {
       // Embedding(3, 4): [d, sin(2^k d), cos(2^k d)] (embedding_helper.py:69-74), the MLP kernel's own sin / cos.  Lane half h feeds
       // columns 14 h .. 14 h + 13 of the 27 (+ one zero): half 0 = [d | sin, cos of 2^0 d | sin 2 d | cos 2 d (x, y)], half 1 =
       // [cos 2 d (z) | sin, cos of 4 d | sin, cos of 8 d | 0] -- so a lane evaluates the two octaves of ITS half (argument 2^(2h) d
-      // and twice that) plus cos 2 d_z: 7 sin/cos pairs instead of all 12 (the counters showed 5.9 other VALU instructions per
-      // MFMA, most of them these polynomials; fp32 MFMA and VALU share the SIMD's ALUs)
+      // and twice that) plus cos 2 d_z: 7 sin/cos pairs instead of all 12
       const float f0 = h ? 4.f : 1.f;
       float s0[3], c0[3], s1[3], c1[3];
 #pragma unroll
       for (int coord = 0; coord < 3; ++coord) {
-        const SinCos a0 = psincos(d[coord] * f0), a1 = psincos(d[coord] * (2.f * f0));
+        const SinCos a0 = psincos(in.d[coord] * f0), a1 = psincos(in.d[coord] * (2.f * f0));
         s0[coord] = a0.s; c0[coord] = a0.c; s1[coord] = a1.s; c1[coord] = a1.c;
       }
-      const float cz = psincos(d[2] * 2.f).c;                    // column 14 = cos(2 d_z)
+      const float cz = psincos(in.d[2] * 2.f).c;                 // column 14 = cos(2 d_z)
       float b[kRbDirKs];
-      b[0] = h ? cz : d[0];     b[1] = h ? s0[0] : d[1];   b[2] = h ? s0[1] : d[2];
+      b[0] = h ? cz : in.d[0];  b[1] = h ? s0[0] : in.d[1]; b[2] = h ? s0[1] : in.d[2];
       b[3] = h ? s0[2] : s0[0]; b[4] = h ? c0[0] : s0[1];  b[5] = h ? c0[1] : s0[2];
       b[6] = h ? c0[2] : c0[0]; b[7] = h ? s1[0] : c0[1];  b[8] = h ? s1[1] : c0[2];
       b[9] = h ? s1[2] : s1[0]; b[10] = h ? c1[0] : s1[1]; b[11] = h ? c1[1] : s1[2];
       b[12] = h ? c1[2] : c1[0]; b[13] = h ? 0.f : c1[1];
       const float* ad = my + 2 * kRbCodeQ * 256;
-      if (nd == 2) rb_tiles<2, kRbDirQ, kRbDirKs>(ad, bias_lds, off_d, lane, valid, out, b);
-      else rb_tiles<1, kRbDirQ, kRbDirKs>(ad, bias_lds, off_d, lane, valid, out, b);
+      if (nd == 2) rb_tiles<2, kRbDirQ, kRbDirKs>(ad, bias_lds, off_d, lane, patch, rayrow, out, b);
+      else rb_tiles<1, kRbDirQ, kRbDirKs>(ad, bias_lds, off_d, lane, patch, rayrow, out, b);
     }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) x[i] = xn[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) d[i] = dn[i];
-    ray = ray_n; valid = valid_n;
+  };
+  // Two input sets, used alternately (no register copies at the loop end: the copies of a single-buffered form were scheduled right
+  // behind the loads, each with its own vmcnt(0)): the inputs of the group after this one are requested before this group's products
+  // and stores, and first read one whole iteration later.  (Three sets -- the awaited loads then sit behind stores two iterations
+  // old instead of one, vmcnt counting loads and stores in issue order -- measured the same 220 us and spilled: two stay.)
+  const long stride = 2 * (long)gridDim.x;
+  In i0, i1;
+  long grp = 2 * (long)blockIdx.x + sub;
+  if (grp >= groups) return;                                 // (wave-uniform; no barrier follows)
+  fetch(grp, i0);
+  // the first group's inputs are waited for HERE: entering the loop with them in flight, the loop's own waits for set 0 would be
+  // priced by this entry path (8 younger operations) instead of by the back edge (~20 stores younger) on every iteration
+  __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0)
+  // (the fetch is unconditional -- past the last group every lane clamps to the last ray: a skipped fetch made the two sets merge
+  // through register copies placed right behind the loads, each copy waiting with vmcnt(0))
+  while (true) {
+    fetch(grp + stride, i1);
+    compute(i0);
+    grp += stride;
+    if (grp >= groups) break;
+    fetch(grp + stride, i0);
+    compute(i1);
+    grp += stride;
+    if (grp >= groups) break;
   }
 }
 
@@ -1588,8 +1636,11 @@ int objnerf_ray_bias(const objnerf_mlp_args* m, float* out, void* stream) {
   // a workgroup (two sets of four waves) per 64 rays, at most one per CU (98 KB of LDS: one is resident) -- it walks its pairs of
   // 32-ray groups with a stride
   const long pairs = (m->n_rays + 63) / 64;
-  hipLaunchKernelGGL(ray_bias_kernel, dim3(mlp_grid(pairs)), dim3(512), 0, (hipStream_t)stream, a,
-                     m->aux + kAuxFloats);
+  const dim3 grid(mlp_grid(pairs));
+  if (m->do_scene && m->do_object) hipLaunchKernelGGL((ray_bias_kernel<true, true>), grid, dim3(512), 0, (hipStream_t)stream, a, m->aux + kAuxFloats);
+  else if (m->do_scene) hipLaunchKernelGGL((ray_bias_kernel<true, false>), grid, dim3(512), 0, (hipStream_t)stream, a, m->aux + kAuxFloats);
+  else if (m->do_object) hipLaunchKernelGGL((ray_bias_kernel<false, true>), grid, dim3(512), 0, (hipStream_t)stream, a, m->aux + kAuxFloats);
+  else return 0;
   return check_launch("ray_bias");
 }
 

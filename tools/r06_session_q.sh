@@ -1,0 +1,3 @@
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06q; mkdir -p $O; cd $R; export TMPDIR=/tmp
+for rep in 1 2; do python tools/ray_bias_probe.py 2>&1 | tail -1; done | tee $O/ray_bias_probe.txt
+timeout 900 python -m pytest tests -x -q -m gpu -k "stages or render or edges" > $O/tests_k.txt 2>&1; echo "tests rc=$?"; tail -3 $O/tests_k.txt | cut -c1-250
