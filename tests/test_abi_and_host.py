@@ -59,26 +59,41 @@ def test_pack_index_is_a_bijection(use_voxel):
     assert set(((bi.to(torch.int64) & 0xFFFFFFFF)[bi != -1] >> 24).unique().tolist()) <= set(range(0, 40, 2))
 
 
-@pytest.mark.parametrize("use_voxel", [1, 0])
-def test_backward_weight_stream_references_the_right_elements(use_voxel):
-    """backward stream: exactly the hidden-to-hidden blocks, each element once."""
+@pytest.mark.parametrize("mode", [1, 0, 2])
+def test_backward_weight_stream_references_the_right_elements(mode):
+    """backward stream: exactly the hidden-to-hidden blocks, each element once, as a padding-free prefix of the buffer (modes 0 / 1);
+    mode 2 (ABI 10, objnerf_train_args.bwd_dx) adds the embedding-column blocks of xyz_encoding_5 / _1 and instance_encoding_3 / _1
+    -- 208 scene-voxel and 104 object-voxel columns -- each element once as well, zero padding where a 7-tile layer's chunk has no
+    tile (16 of its 128 slots) and in the rows past column 208 / 104 of a block's last tile."""
     l = _lib.lib()
     nbw = l.objnerf_bwd_blob_floats()
     bw = torch.empty(nbw, dtype=torch.int32)
-    _lib.check(l.objnerf_pack_index_bwd(use_voxel, C.c_void_p(bw.data_ptr())), "pack_index_bwd")
-    w = bw.numpy().view("uint32")
-    assert (w != 0xFFFFFFFF).all()                                       # whole tiles, no padding
+    _lib.check(l.objnerf_pack_index_bwd(mode, C.c_void_p(bw.data_ptr())), "pack_index_bwd")
+    w_all = bw.numpy().view("uint32")
+    w = w_all[w_all != 0xFFFFFFFF]
     assert np.unique(w).size == w.size                                   # every streamed element exactly once
     # expected element count: SD[:, :256], SF, S8..S6, S5[:, hidden], S4..S2 (256 x 256 each, SD 128 x 256) and
     # OD[:, :128] (64 x 128), OF, O4, O3[:, hidden], O2 (128 x 128 each)
-    assert w.size == 128 * 256 + 8 * 256 * 256 + 64 * 128 + 4 * 128 * 128
-    # pointer ids: weights only (even ids) of the layers named above
-    ids = set((w >> 24).tolist())
+    hidden = 128 * 256 + 8 * 256 * 256 + 64 * 128 + 4 * 128 * 128
     names = [n for n in PARAM_LAYERS]
     want = {"dir_encoding.0", "xyz_encoding_final", "xyz_encoding_8.0", "xyz_encoding_7.0", "xyz_encoding_6.0",
             "xyz_encoding_5.0", "xyz_encoding_4.0", "xyz_encoding_3.0", "xyz_encoding_2.0", "inst_dir_encoding.0",
             "instance_encoding_final.0", "instance_encoding_4.0", "instance_encoding_3.0", "instance_encoding_2.0"}
-    assert ids == {2 * names.index(n) for n in want}
+    if mode < 2:
+        assert w.size == hidden
+        assert (w_all[:hidden] != 0xFFFFFFFF).all() and (w_all[hidden:] == 0xFFFFFFFF).all()       # whole tiles, then the unused tail
+    else:
+        assert w.size == hidden + 2 * 208 * 256 + 2 * 208 * 128 + 2 * 104 * 128
+        want |= {"xyz_encoding_1.0", "instance_encoding_1.0"}
+        # the embedding-column blocks reference exactly columns [0, 208) of the four layers and [271, 375) of the instance layers
+        for lname, in_features, cols in (("xyz_encoding_1.0", 271, range(0, 208)), ("instance_encoding_1.0", 439, list(range(0, 208)) + list(range(271, 375)))):
+            pid = 2 * names.index(lname)
+            offs = (w[(w >> 24) == pid] & 0xFFFFFF).astype(np.int64)
+            assert sorted(set((offs % in_features).tolist())) == sorted(cols), lname
+        with pytest.raises(RuntimeError):
+            _lib.check(l.objnerf_pack_index_bwd(3, C.c_void_p(bw.data_ptr())), "pack_index_bwd")
+    # pointer ids: weights only (even ids) of the layers named above
+    assert set((w >> 24).tolist()) == {2 * names.index(n) for n in want}
 
 
 def test_module_types_and_state_dict_names():
