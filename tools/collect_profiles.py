@@ -41,7 +41,8 @@ if have("bench.json"):
     b = line(os.path.join(O, "bench.json"))
     print("headline %.2f M ray-samples/s, %.1f ms, frac %.4f; train_step %.2f ms" % (
         b["value"] / 1e6, b["ms_per_step"], b["roofline"]["frac"], b.get("train_step", {}).get("ms_per_step", float("nan"))))
-for src, dst in (("bench_two_ranks_one_gpu.json", "_bench_two_ranks_one_gpu.json"), ("small_batch.md", "_small_batch.md"),
+for src, dst in (("bench_two_ranks_one_gpu.json", "_bench_two_ranks_one_gpu.json"), ("bench_eight_ranks_one_gpu.json", "_bench_eight_ranks_one_gpu.json"),
+                 ("train_timeline.md", "_train_timeline.md"), ("arch_bench.md", "_arch_bench.md"), ("parity.md", "_parity.md"), ("small_batch.md", "_small_batch.md"),
                  ("mesh_query.md", "_mesh_query.md")):
     if have(src):
         shutil.copy(os.path.join(O, src), os.path.join(P, TAG + dst))
@@ -55,9 +56,9 @@ if have("trace_bench_kernel_stats.md") and have("bench.json"):
     hbm = ["| kernel | calls | avg us | algorithmic MB / launch | GB/s | of 8 TB/s | note |", "|---|---|---|---|---|---|---|"]
     for key, bytes_, note in (
             ("composite_finish", n * (10 * (S + S + I) / 2.0 + 40), "mean of the coarse (S) and fine (S + I) launch"),
-            ("ray_bias_kernel", n * (268 + 1792), "lane = ray, weight columns as wave-uniform operands, 64-byte stores"),
+            ("ray_bias_kernel", n * (268 + 1792), "round 6: the 448 x 91 product per ray on the matrix pipe, whole-line stores through an LDS patch; products 144 us and stores 138 us overlap by a third (r06_ray_bias_probe.txt)"),
             ("sample_coarse", n * (32 + 4 * S), ""),
-            ("sample_pdf_merge", n * (8 * S + 4 * (S + I)), "one wave per ray: float64 prefix scan of the cdf, per-lane binary searches, merge -- latency, not bandwidth")):
+            ("sample_pdf_merge", n * (8 * S + 4 * (S + I)), "round 6: persistent waves, one element per lane, branch-free fixed-trip searches, next ray prefetched; float64 prefix scan of the cdf")):
         r = next((x for x in rr if key in x["name"]), None)
         if r:
             rate = bytes_ / (r["avg"] * 1e-3)
@@ -70,8 +71,8 @@ if have("trace_bench_kernel_stats.md") and have("bench.json"):
         "bench.py line of the same session (`profiles/%s_bench.json`): %.2f M ray-samples/s, %.1f ms per step; HIP-event average of an MLP launch "
         "in the JSON's roofline block %.2f ms (%.3f of the fp32-MFMA peak on ALGORITHMIC FLOP); rocprof average of the same kernel below: %.2f ms -> "
         "%.2f TFLOP / %.4f s = %.1f TFLOP/s = %.3f.  Per frame: 2 launches of the persistent MLP kernel (HOIST instantiation, compositing in the "
-        "epilogue), `ray_bias_kernel` x 2 (the compact weight matrix is gathered at pack time since round 4: `ray_bias_weights_kernel` appears once "
-        "per model, not per call), `composite_finish_kernel` x 2, `sample_pdf_merge_kernel`, `sample_coarse4_kernel`.\n\n"
+        "epilogue), `ray_bias_kernel` x 2 (its A-operand stream is gathered by `pack_all_kernel`, the one launch that re-gathers both models' "
+        "weight streams at every call since round 6), `composite_finish_block_kernel` x 2, `sample_pdf_merge64_kernel`, `sample_coarse4_kernel`.\n\n"
         % (TAG, os.path.basename(O), TAG, b["value"] / 1e6, b["ms_per_step"], roof["avg_launch_ms"], roof["frac"], mlp["avg"], flop_launch / 1e12,
            mlp["avg"] / 1e3, flop_launch / (mlp["avg"] / 1e3) / 1e12, flop_launch / (mlp["avg"] / 1e3) / PEAK)
         + head(ks, 16) + "\n## HBM-bound stages of the same trace (algorithmic bytes of SURVEY.md 8d / time)\n\n" + "\n".join(hbm) + "\n")
@@ -87,7 +88,7 @@ if have("trace_train_kernel_stats.md"):
     g = [("fused forward with saved activations (`mlp_kernel<..., SAVE>`)", grp("mlp_kernel")), ("dgrad chain (`mlp_bwd_kernel`)", grp("mlp_bwd_kernel")),
          ("weight gradients, 256 x 256 tiles (`wgrad_big_kernel`)", grp("wgrad_big")), ("weight gradients, 128 x 128 tiles (`wgrad_units_kernel<false>`)", grp("wgrad_units_kernel<false>")),
          ("weight gradients, ragged tiles (`wgrad_units_kernel<true>`)", grp("wgrad_units_kernel<true>")), ("weight gradients, fix-up + heads", grp("fixup", "heads_wgrad")),
-         ("gradients w.r.t. the embeddings (`gemm_kernel<true, false, *>`)", grp("gemm_kernel")), ("voxel embedding forward + table scatter", grp("voxel_embed"))]
+         ("per-ray code gradient (`gemm_kernel`; the embedding gradients are formed inside the chain since round 6)", grp("gemm_kernel")), ("voxel embedding forward + table scatter", grp("voxel_embed"))]
     g.append(("everything else (compositing / sampling forward + backward, sigmoid, per-ray sums, Adam, fills, the loss's torch element-wise kernels)", tot / steps - sum(v for _, v in g)))
     txt = "Kernel time per step by group (the table below, / %d steps):\n\n| group | ms per step |\n|---|---|\n" % steps
     txt += "".join("| %s | %.2f |\n" % x for x in g) + "| sum of kernel time | %.2f |\n\n" % (tot / steps)

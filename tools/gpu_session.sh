@@ -6,7 +6,8 @@
 #   tests       pytest -m gpu (whole suite, -x)            tests:EXPR   only the tests matching -k EXPR
 #   smoke       __graft_entry__.smoke()
 #   bench       python bench.py (driver's default: steps 20, warmup 5)       bench:K   with --config K
-#   dist2       bench.py --gpus 2 --one-gpu (two ranks on cuda:0 over gloo: the N > 1 code path on one GPU)
+#   dist2       bench.py --gpus 2 --one-gpu (two ranks on cuda:0 over gloo: the N > 1 code path on one GPU)      dist8  the same with 8 ranks
+#   trainpmc    tools/train_pmc.sh (counter passes of the training step)     timeline   launch-order timeline of one training step
 #   train       tools/train_bench.py                       mesh   tools/mesh_query_bench.py 512
 #   trace       rocprofv3 --kernel-trace --stats of bench.py (headline) -> kernel table
 #   trace:train the same of tools/train_bench.py           trace:mesh  of the density query
@@ -34,6 +35,10 @@ for step in "$@"; do
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.txt ;;
     bench) timeout 900 python bench.py --steps 20 --warmup 5 ${arg:+--config $arg} > $O/bench${arg:+_c$arg}.json 2> $O/bench${arg:+_c$arg}.err; echo "bench $arg rc=$?"; tail -1 $O/bench${arg:+_c$arg}.json | cut -c1-400 ;;
     dist2) timeout 900 python bench.py --gpus 2 --one-gpu --steps 5 --warmup 2 > $O/bench_two_ranks_one_gpu.json 2> $O/bench_two_ranks_one_gpu.err; echo "dist2 rc=$?"; tail -1 $O/bench_two_ranks_one_gpu.json | cut -c1-300 ;;
+    dist8) timeout 900 python bench.py --gpus 8 --one-gpu --steps 2 --warmup 1 > $O/bench_eight_ranks_one_gpu.json 2> $O/bench_eight_ranks_one_gpu.err; echo "dist8 rc=$?"; tail -1 $O/bench_eight_ranks_one_gpu.json | cut -c1-300 ;;
+    trainpmc) timeout 1500 bash tools/train_pmc.sh $O/train_pmc.md > $O/train_pmc.log 2>&1; echo "trainpmc rc=$?"; tail -3 $O/train_pmc.log | cut -c1-200 ;;
+    timeline) (cd /tmp && TRAIN_BENCH_FREE_STEPS=24 timeout 600 rocprofv3 --kernel-trace -d $O/trace_tl -o tr -- python $R/tools/train_bench.py > $O/trace_tl.log 2>&1); echo "timeline rc=$?"
+              db=$(find $O/trace_tl -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_timeline.py "$db" "mlp_kernel" 2 -3 > $O/train_timeline.md; rm -rf $O/trace_tl; tail -1 $O/train_timeline.md ;;
     train) timeout 300 python tools/train_bench.py > $O/train_bench.txt 2>&1; echo "train rc=$?"; tail -2 $O/train_bench.txt ;;
     mesh)  timeout 600 python tools/mesh_query_bench.py 512 $O/mesh_query.md > $O/mesh_query.log 2>&1; echo "mesh rc=$?"; tail -8 $O/mesh_query.log ;;
     small) timeout 600 python tools/small_batch.py $O/small_batch.md > $O/small_batch.log 2>&1; echo "small rc=$?"; tail -8 $O/small_batch.log ;;
