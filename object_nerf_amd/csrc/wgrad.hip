@@ -9,6 +9,9 @@
 namespace objnerf {
 
 // ---- ragged tiles (1..3 live 32-column sub-tiles): 4 x 1 waves, gemm.h's operand staging, single LDS buffer ----------------
+// (Round 6 tried two register sets per operand -- the tile after next in flight under two tiles' MFMAs: ~190 VGPRs, i.e. two waves
+// per SIMD instead of three, and the step measured 18.19 vs 18.07 ms without it (three waves with the spills: 18.66),
+// profiles/r06_train_ab_fixup.txt -- the occupancy it costs hides as much latency as the deeper prefetch.)
 __device__ __forceinline__ void wgrad_tail_piece(const WgProduct& pr, const WgTile& tl, long kbeg, long kend,
                                                  float* slot, float* lds, int tid, long P) {
   const long nseg16 = (P + 15) >> 4;
@@ -525,7 +528,26 @@ __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __res
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   float rs = 0.f;
   const bool want_rs = part == 0 && pr.rowsum && tl.bx == 0 && tid < 128;
-  for (int z = 0; z < nzt; ++z) {
+  // four slices' values are fetched before they are added, in the same ascending order (the same bits): one slice at a time the
+  // loop was a chain of up to 153 dependent round trips per thread (round 6: step -0.19 ms, profiles/r06_train_ab_fixup.txt)
+  int z = 0;
+  for (; z + 4 <= nzt; z += 4) {
+    float v[4][8], r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* slot = a.partials + ((long)t * nz + z + u) * kWgradSlotFloats;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[u][i] = gload(slot + (part * 8 + i) * 256 + tid);
+      r[u] = want_rs ? gload(slot + 128 * 128 + tid) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[u][i];
+      if (want_rs) rs += r[u];
+    }
+  }
+  for (; z < nzt; ++z) {
     const float* slot = a.partials + ((long)t * nz + z) * kWgradSlotFloats;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] += gload(slot + (part * 8 + i) * 256 + tid);
@@ -578,7 +600,17 @@ __global__ void __launch_bounds__(256) heads_wgrad_kernel(const HeadArgs a) {
       if (no > 1) { s1 += dys[p * no + 1] * xv; s2 += dys[p * no + 2] * xv; }
     }
   }
-  if (tid < no) for (int p = 0; p < np; ++p) b += dys[p * no + tid];
+  if (tid < no) {                        // (sixteen LDS reads in flight per trip, added in ascending order: the same bits)
+    int p = 0;
+    for (; p + 16 <= np; p += 16) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = dys[(p + u) * no + tid];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) b += t[u];
+    }
+    for (; p < np; ++p) b += dys[p * no + tid];
+  }
   float* slot = a.partials + ((long)blockIdx.y * a.nchunks + blockIdx.x) * kHeadSlotFloats;
   gstore(slot + tid, s0); gstore(slot + 256 + tid, s1); gstore(slot + 512 + tid, s2);
   if (tid < 3) gstore(slot + 768 + tid, b);
