@@ -22,6 +22,9 @@ int launch_mlp_memory(const objnerf_mlp_args& a, long ntiles, unsigned grid, hip
 int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float* act, float* dz, const float* d_sigma,
                    const float* t2, const float* d_isigma, const float* t2i, bool do_object, const unsigned* masks, bool dx,
                    float* d_emb, long ld_emb, float* d_ov, hipStream_t s);
+// training: positional-encoding backward + trilinear scatter into the table gradient (train_kernels.hip); emb_xyz / obj_voxel optional
+int launch_voxel_embed_bwd(const objnerf_voxel_grid* grid, const float* xyz, long n, const float* d_scene_ftr, const float* d_obj_ftr,
+                           float* table_grad, const float* emb_xyz, const float* obj_voxel, hipStream_t s);
 // floats of the mask area behind the activation matrices of a training workspace (mlp_kernel.h: train_mask_floats)
 long train_mask_floats_host(long n_points);
 // persistent grid of the MLP kernel: one workgroup per CU

@@ -426,8 +426,8 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   // MFMA-bound kernels that already run at the part's power limit), so it is simply enqueued here ----
   clk.begin(PH_SCATTER);
   if (vox && a->scatter_xyz && a->scatter_table_grad && !c.rc)
-    c.rc = objnerf_voxel_embed_backward(&a->grid, a->scatter_xyz, P, d_emb_xyz, obj ? d_obj_voxel : nullptr,
-                                        a->scatter_table_grad, c.s);
+    c.rc = launch_voxel_embed_bwd(&a->grid, a->scatter_xyz, P, d_emb_xyz, obj ? d_obj_voxel : nullptr, a->scatter_table_grad,
+                                  a->emb_xyz, obj ? a->obj_voxel : nullptr, c.s);       // (the rows' identity blocks: the features)
 
   // ---- phase B: weight / bias gradients dW = dY^T X.  All products of the pass go into ONE work list and one persistent,
   // deterministic stream-K launch (wgrad.h); OBJNERF_WGRAD=atomic keeps round 2's one split-K launch with atomic

@@ -176,10 +176,17 @@ constexpr int kVbPoints = OBJ_VB_POINTS;    // points per workgroup (the aggrega
 // 32 lanes per point, lane = voxel channel (0..15 scene, 16..23 object; 24..31 idle), 8 points per pass of a
 // 256-thread workgroup: a corner's features and every (frequency, sin|cos) block of the incoming gradient row are
 // contiguous across the lanes, and the 24 lanes of a point add to 24 different LDS words of its row's slot.
+// SAVED (round 6, the training path): the interpolated feature f of every channel is READ BACK -- the forward stored it as the
+// identity block of the positional encoding (embedding_helper.py:69-74: [f, sin, cos, ...]; columns 0..15 of the emb_xyz row, 0..7 of
+// the obj_voxel row: the same bits this kernel would recompute) -- instead of gathered again from the 8 corner rows of the table:
+// the 8 x 96-byte random reads per point and one of the kernel's three dependent round trips (position -> index map -> table rows)
+// disappear; the index-map reads remain (the scatter's destinations).
+template <bool SAVED>
 __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxel_grid g, const float* __restrict__ xyz,
                                                                long n, const float* __restrict__ d_scene,
                                                                const float* __restrict__ d_obj,
-                                                               float* __restrict__ table_grad) {
+                                                               float* __restrict__ table_grad,
+                                                               const float* __restrict__ f_scene, const float* __restrict__ f_obj) {
   __shared__ int keys[kVbSlots];
   __shared__ float vals[kVbSlots * kVbStride];
   for (int i = threadIdx.x; i < kVbSlots; i += 256) keys[i] = -1;
@@ -207,6 +214,7 @@ __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxe
     int row[8];
     const float X = (float)g.shape[0], Y = (float)g.shape[1], Z = (float)g.shape[2];
     float f = 0.f;                                                  // this channel's interpolated feature (forward value)
+    if constexpr (SAVED) f = scn ? f_scene[p * (long)(kScnVoxPE + kXyzPE) + cc] : f_obj[p * (long)kObjVoxPE + cc];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float cx = qx + (float)((k >> 2) & 1), cy = qy + (float)((k >> 1) & 1), cz = qz + (float)(k & 1);
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxe
         if (r >= g.n_rows) r = -1;
       }
       row[k] = r;
-      if (r >= 0) f = f + g.table[(size_t)r * kVoxC + sub] * wt[k];
+      if constexpr (!SAVED) { if (r >= 0) f = f + g.table[(size_t)r * kVoxC + sub] * wt[k]; }
     }
     // d/df [f, sin(2^k f), cos(2^k f)]: 1, 2^k cos, -2^k sin
     const float* d = dbase + p * dld;
@@ -380,14 +388,31 @@ int objnerf_composite_backward(const objnerf_composite_args* fwd, const float* g
   return check_launch("composite_backward");
 }
 
-int objnerf_voxel_embed_backward(const objnerf_voxel_grid* grid, const float* xyz, int64_t n, const float* d_scene_ftr,
-                                 const float* d_obj_ftr, float* table_grad, void* stream) {
+}  // extern "C"
+namespace objnerf {
+// emb_xyz / obj_voxel (optional, both or neither when d_obj_ftr is given): the forward's embedding rows of the same points -- their
+// identity blocks are the interpolated features (SAVED above)
+int launch_voxel_embed_bwd(const objnerf_voxel_grid* grid, const float* xyz, long n, const float* d_scene_ftr, const float* d_obj_ftr,
+                           float* table_grad, const float* emb_xyz, const float* obj_voxel, hipStream_t s) {
   if (!grid || !grid->idx_map || !grid->table || !xyz || !d_scene_ftr || !table_grad)
     return set_error(-1, "voxel_embed_backward: bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(voxel_embed_bwd_kernel, dim3(blk(n, kVbPoints)), dim3(256), 0, (hipStream_t)stream, *grid, xyz, (long)n,
-                     d_scene_ftr, d_obj_ftr, table_grad);
+  // (read on every call, not cached: tests/test_gpu_train.py switches it inside one process to cross-check the two forms)
+  const bool saved_on = [] { const char* e = getenv("OBJNERF_SCATTER_SAVED"); return !e || atoi(e) != 0; }();
+  if (saved_on && emb_xyz && (obj_voxel || !d_obj_ftr))
+    hipLaunchKernelGGL(voxel_embed_bwd_kernel<true>, dim3(blk(n, kVbPoints)), dim3(256), 0, s, *grid, xyz, n, d_scene_ftr, d_obj_ftr,
+                       table_grad, emb_xyz, obj_voxel);
+  else
+    hipLaunchKernelGGL(voxel_embed_bwd_kernel<false>, dim3(blk(n, kVbPoints)), dim3(256), 0, s, *grid, xyz, n, d_scene_ftr, d_obj_ftr,
+                       table_grad, nullptr, nullptr);
   return check_launch("voxel_embed_backward");
+}
+}  // namespace objnerf
+extern "C" {
+
+int objnerf_voxel_embed_backward(const objnerf_voxel_grid* grid, const float* xyz, int64_t n, const float* d_scene_ftr,
+                                 const float* d_obj_ftr, float* table_grad, void* stream) {
+  return launch_voxel_embed_bwd(grid, xyz, (long)n, d_scene_ftr, d_obj_ftr, table_grad, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int objnerf_sum_over_samples(const float* x, int64_t n_rays, int S, int C, float* out, void* stream) {

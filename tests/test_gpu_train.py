@@ -868,6 +868,44 @@ def test_embedding_gradients_folded_into_the_chain_match_the_gemms(monkeypatch):
     assert not torch.equal(a["table"], b["table"]), "OBJNERF_BWD_DX did not select another path"
 
 
+def test_table_scatter_reads_the_forward_features_back(monkeypatch):
+    """The voxel-table scatter takes each channel's interpolated feature from the identity block of the embedding row the forward
+    wrote (round 6) instead of gathering the 8 corner rows again (OBJNERF_SCATTER_SAVED=0): the same bits enter the positional
+    encoding's derivative, so the table gradient differs only by the order of its atomic additions (<= 2e-6 relative L2) and every
+    other gradient is bit-equal."""
+    sc = cases.scene_for(A, "voxel", device=DEV)
+    n = 300
+    rays = H.test_rays(n, w=256, h=192, stride=23).to(DEV)
+    ids = synth.per_ray_ids(n, seed=5).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    rd = dict(perturb_rand=torch.rand(n, 64, generator=g).to(DEV), u_rand=torch.rand(n, 64, generator=g).to(DEV),
+              noise=[torch.randn(n, s, generator=g).to(DEV) for s in (64, 64, 128, 128)])
+    mods = (sc.models["coarse"], sc.models["fine"])
+
+    def grads():
+        for m in mods + (sc.code_library, sc.embeddings["xyz"]):
+            m.zero_grad()
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        res = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                            embedding_instance=codes, frustum_bound_th=0.025, _randoms=rd)
+        _loss(res).backward()
+        torch.cuda.synchronize()
+        out = {"%d.%s" % (i, k): p.grad.clone() for i, m in enumerate(mods) for k, p in m.named_parameters()}
+        out["codes"] = sc.code_library.embedding_instance.weight.grad.clone()
+        out["table"] = sc.embeddings["xyz"].embedding_space_ftr.weight.grad.clone()
+        return out
+    monkeypatch.delenv("OBJNERF_SCATTER_SAVED", raising=False)
+    a = grads()
+    monkeypatch.setenv("OBJNERF_SCATTER_SAVED", "0")
+    b = grads()
+    monkeypatch.delenv("OBJNERF_SCATTER_SAVED", raising=False)
+    for k in a:
+        if k != "table":
+            assert torch.equal(a[k], b[k]), k
+    assert a["table"].abs().max().item() > 0
+    assert rel_l2(a["table"], b["table"]) < 2e-6, rel_l2(a["table"], b["table"])
+
+
 def test_hoisted_training_forward_matches_the_per_sample_contraction(monkeypatch):
     """the training forward with the per-ray constant terms hoisted (objnerf_train_args.ray_bias_ws: objnerf_ray_bias + skipped
     k-steps, as in the inference passes) against the same kernel contracting every term per sample point (OBJNERF_HOIST=0): the
