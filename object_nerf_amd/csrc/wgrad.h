@@ -51,6 +51,7 @@ struct WgradArgs {             // passed by value (2.5 KB of kernel arguments: n
                                // workgroup each (wgrad_big_kernel); wgrad_units_kernel<false> takes tile[nbig .. nfull)
   int nz;                      // k slices per tile (and the slot stride of every tile)
   int nzb;                     // k slices per 256 x 256 tile, <= nz (round 6): as many as make ONE round of workgroups, see launch()
+  int nzu, nzr;                // ... per 128 x 128 tile (two workgroups per CU) and per ragged tile (three); all <= nz
   int xcd;                     // XCD-aware unit map (tuning switch OBJNERF_WGRAD_XCD)
   long P;
   float* partials;             // slot (tile t, slice z) at (t * slices + z) * kWgradSlotFloats

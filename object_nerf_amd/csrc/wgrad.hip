@@ -473,8 +473,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
   const int tid = threadIdx.x;
   const long P = uni(a.P);
   const long KT = (P + GBK - 1) / GBK;
-  const int nz = uni(a.nz);
-  const long L = (KT + nz - 1) / nz;                       // k iterations per slice
+  const int nz = uni(a.nz), nzk = uni(TAIL ? a.nzr : a.nzu);      // (nz: the slot stride; nzk: this kernel's slices per tile)
+  const long L = (KT + nzk - 1) / nzk;                     // k iterations per slice
   const int t0 = TAIL ? a.nfull : a.nbig, t1 = TAIL ? a.ntile : a.nfull;
   // unit -> (tile, slice): walk the runs of tiles that belong to one product.  Workgroups are dealt round-robin to the 8
   // XCDs; with a.xcd every XCD takes one contiguous eighth of the units, so the tiles of one slice (which read the same
@@ -500,8 +500,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
   while (t < t1) {
     int run = 1;
     while (t + run < t1 && a.tile[t + run].prod == a.tile[t].prod) ++run;
-    if (u < (long)run * nz) { z = (int)(u / run); t += (int)(u % run); break; }
-    u -= (long)run * nz;
+    if (u < (long)run * nzk) { z = (int)(u / run); t += (int)(u % run); break; }
+    u -= (long)run * nzk;
     t += run;
   }
   if (t >= t1) return;
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ?
 __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __restrict__ ap) {
   const WgradArgs& a = *ap;
   const int t = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
-  const int nz = a.nz, nzt = t < a.nbig ? a.nzb : a.nz;          // slot stride; slices this tile was cut into
+  const int nz = a.nz, nzt = t < a.nbig ? a.nzb : (t < a.nfull ? a.nzu : a.nzr);          // slot stride; slices this tile was cut into
   const WgTile tl = a.tile[t];
   const WgProduct pr = a.prod[tl.prod];
   float acc[8];
@@ -528,20 +528,20 @@ __global__ void __launch_bounds__(256) wgrad_fixup_kernel(const WgradArgs* __res
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   float rs = 0.f;
   const bool want_rs = part == 0 && pr.rowsum && tl.bx == 0 && tid < 128;
-  // four slices' values are fetched before they are added, in the same ascending order (the same bits): one slice at a time the
+  // eight slices' values are fetched before they are added, in the same ascending order (the same bits): one slice at a time the
   // loop was a chain of up to 153 dependent round trips per thread (round 6: step -0.19 ms, profiles/r06_train_ab_fixup.txt)
   int z = 0;
-  for (; z + 4 <= nzt; z += 4) {
-    float v[4][8], r[4];
+  for (; z + 8 <= nzt; z += 8) {
+    float v[8][8], r[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const float* slot = a.partials + ((long)t * nz + z + u) * kWgradSlotFloats;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[u][i] = gload(slot + (part * 8 + i) * 256 + tid);
       r[u] = want_rs ? gload(slot + 128 * 128 + tid) : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += v[u][i];
       if (want_rs) rs += r[u];
@@ -619,18 +619,18 @@ __global__ void __launch_bounds__(256) heads_fixup_kernel(const HeadArgs a) {
   const HeadItem h = a.h[blockIdx.x];
   const int tid = threadIdx.x;
   float s[3] = {0.f, 0.f, 0.f}, b = 0.f;
-  // ascending chunks = ascending points; eight chunks' partial sums are fetched before they are added (same order of additions)
+  // ascending chunks = ascending points; sixteen chunks' partial sums are fetched before they are added (same order of additions)
   int c = 0;
-  for (; c + 8 <= a.nchunks; c += 8) {
-    float v[8][3], bv[8];
+  for (; c + 16 <= a.nchunks; c += 16) {
+    float v[16][3], bv[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const float* slot = a.partials + ((long)blockIdx.x * a.nchunks + c + u) * kHeadSlotFloats;
       v[u][0] = gload(slot + tid); v[u][1] = gload(slot + 256 + tid); v[u][2] = gload(slot + 512 + tid);
       bv[u] = tid < 3 ? gload(slot + 768 + tid) : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; b += bv[u]; }
+    for (int u = 0; u < 16; ++u) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; b += bv[u]; }
   }
   for (; c < a.nchunks; ++c) {
     const float* slot = a.partials + ((long)blockIdx.x * a.nchunks + c) * kHeadSlotFloats;
@@ -725,33 +725,45 @@ int WgradBatch::launch(long P, float* scratch, hipStream_t s, int slices) {
     static_assert(sizeof(WgradArgs) % 4 == 0 && sizeof(WgradArgs) <= 4096, "the lists travel as kernel arguments");
     WgradArgs* dev = (WgradArgs*)(scratch + wgrad_scratch_floats(P) - kWgradListFloats);
     const long KTl = (P + GBK - 1) / GBK;
-    // 256 x 256 tiles (round 6): ONE round of workgroups -- cus / tiles slices per tile, one workgroup per CU for the whole launch --
-    // instead of the ~6 rounds the 64-k-tile slices make at the reference batch: a quarter of the partial tiles to write and to
-    // add up again (1,530 x 256 KB per fine pass before), one prologue / epilogue per CU.  The 128 x 128 tiles keep their slices
-    // (two workgroups per CU, operand panels shared through L2 by the tiles of a slice).  OBJNERF_WGRAD_BIG_ROUNDS=many: as before.
-    static const bool one_round = [] { const char* e = getenv("OBJNERF_WGRAD_BIG_ROUNDS"); return !e || strcmp(e, "many") != 0; }();
+    // ONE round of workgroups per kernel (round 6) instead of the ~4-6 rounds the 64-k-tile slices make at the reference batch:
+    // cus / tiles slices per 256 x 256 tile (one workgroup per CU), 2 cus / tiles per 128 x 128 tile, 3 cus / tiles per ragged tile
+    // -- a quarter of the partial tiles to write and to add up again, one prologue / epilogue per resident workgroup, no
+    // part-empty last round.  Workgroups that run together still contract the same points for the neighbouring tiles of a
+    // product (the launch order is unchanged).  OBJNERF_WGRAD_ROUNDS=many: every tile cut into 64-k-tile slices as in rounds 3-5;
+    // =big: only the 256 x 256 tiles in one round (this round's first step).
+    static const int rounds_mode = [] {
+      const char* e = getenv("OBJNERF_WGRAD_ROUNDS");
+      const char* old = getenv("OBJNERF_WGRAD_BIG_ROUNDS");
+      if ((e && !strcmp(e, "many")) || (old && !strcmp(old, "many"))) return 0;
+      return (e && !strcmp(e, "big")) ? 1 : 2;
+    }();
     static const int cus_n = [] {
       int dev = 0, n = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
       return n > 0 ? n : 256;
     }();
-    const bool split = one_round && slices <= 0 && a.nbig > 0;
-    const int nz = a.nz = slices > 0 ? (int)(slices < KTl ? slices : KTl)
-                                     : wgrad_pick_slices(P, split ? 0 : a.nbig / 4, a.nfull - a.nbig);
-    int nzb = nz;
-    if (split) {
-      nzb = cus_n / (a.nbig / 4);
-      if (nzb > nz) nzb = nz;              // (the slot area is strided by nz)
-      if (nzb < 1) nzb = 1;
-    }
-    a.nzb = nzb;
+    const int nbt = a.nbig / 4, nut = a.nfull - a.nbig, nrt = a.ntile - a.nfull;
+    auto one_round = [&](int slots, int tiles) {          // slices per tile that fill `slots` resident workgroups once
+      if (tiles <= 0) return 1;
+      long v = slots / tiles;
+      const long cap = wgrad_slices(P) < KTl ? wgrad_slices(P) : KTl;      // (the slot area is sized for wgrad_slices(P) per tile)
+      if (v > cap) v = cap;
+      return (int)(v < 1 ? 1 : v);
+    };
+    int nzb, nzu, nzr;
+    if (slices > 0) nzb = nzu = nzr = (int)(slices < KTl ? slices : KTl);
+    else if (rounds_mode == 0) nzb = nzu = nzr = wgrad_pick_slices(P, nbt, nut);
+    else if (rounds_mode == 1) { nzu = nzr = wgrad_pick_slices(P, 0, nut); nzb = one_round(cus_n, nbt); if (nzb > nzu) nzb = nzu; }
+    else { nzb = one_round(cus_n, nbt); nzu = one_round(2 * cus_n, nut); nzr = one_round(3 * cus_n, nrt); }
+    a.nz = nzb > nzu ? (nzb > nzr ? nzb : nzr) : (nzu > nzr ? nzu : nzr);       // the slot stride
+    a.nzb = nzb; a.nzu = nzu; a.nzr = nzr;
     static const int xcd = [] { const char* e = getenv("OBJNERF_WGRAD_XCD"); return e ? atoi(e) : 0; }();
     static const int prio = [] { const char* e = getenv("OBJNERF_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
     a.xcd = (xcd & 1) | ((prio & 3) << 1);
     hipLaunchKernelGGL(wgrad_list_kernel, dim3(1), dim3(256), 0, s, a, dev);
     if (a.nbig > 0) hipLaunchKernelGGL(wgrad_big_kernel, dim3((a.nbig / 4) * nzb), dim3(256), 0, s, (const WgradArgs*)dev);
-    if (a.nfull > a.nbig) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3((a.nfull - a.nbig) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
-    if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nz), dim3(256), 0, s, (const WgradArgs*)dev);
+    if (a.nfull > a.nbig) hipLaunchKernelGGL(wgrad_units_kernel<false>, dim3((a.nfull - a.nbig) * nzu), dim3(256), 0, s, (const WgradArgs*)dev);
+    if (a.ntile > a.nfull) hipLaunchKernelGGL(wgrad_units_kernel<true>, dim3((a.ntile - a.nfull) * nzr), dim3(256), 0, s, (const WgradArgs*)dev);
     hipLaunchKernelGGL(wgrad_fixup_kernel, dim3(a.ntile, 8), dim3(256), 0, s, (const WgradArgs*)dev);
   }
   if (h.nheads > 0) {
