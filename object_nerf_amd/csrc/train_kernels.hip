@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
 }
 
 // ---- voxel embedding backward ---------------------------------------------------------------------
-// A workgroup holds 128 consecutive sample points = consecutive depths of one or two rays, and neighbouring depths
+// A workgroup holds 64..192 consecutive sample points = consecutive depths of one to three rays, and neighbouring depths
 // fall into the same voxel cell: sent straight to memory, their 8 x 24 atomics per point pile up on a few table rows
 // (the fine pass, whose samples cluster at surfaces, ran 8x slower per point than the coarse pass).  The workgroup
 // therefore first sums its contributions per table row in an LDS hash (row id -> 24 floats, ds_add_f32), then sends
@@ -169,10 +169,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const CompBwd b) {
 #endif
 constexpr int kVbSlots = 1 << OBJ_VB_SLOT_BITS;               // power of two
 constexpr int kVbStride = kVoxC + 1;        // odd stride: spreads the rows over the LDS banks
-#ifndef OBJ_VB_POINTS
-#define OBJ_VB_POINTS 128
-#endif
-constexpr int kVbPoints = OBJ_VB_POINTS;    // points per workgroup (the aggregation window)
+// (points per workgroup -- the aggregation window -- are chosen per launch: launch_voxel_embed_bwd)
 // 32 lanes per point, lane = voxel channel (0..15 scene, 16..23 object; 24..31 idle), 8 points per pass of a
 // 256-thread workgroup: a corner's features and every (frequency, sin|cos) block of the incoming gradient row are
 // contiguous across the lanes, and the 24 lanes of a point add to 24 different LDS words of its row's slot.
@@ -186,7 +183,8 @@ __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxe
                                                                long n, const float* __restrict__ d_scene,
                                                                const float* __restrict__ d_obj,
                                                                float* __restrict__ table_grad,
-                                                               const float* __restrict__ f_scene, const float* __restrict__ f_obj) {
+                                                               const float* __restrict__ f_scene, const float* __restrict__ f_obj,
+                                                               const int ppw) {          // points per workgroup: a multiple of 8
   __shared__ int keys[kVbSlots];
   __shared__ float vals[kVbSlots * kVbStride];
   for (int i = threadIdx.x; i < kVbSlots; i += 256) keys[i] = -1;
@@ -198,8 +196,8 @@ __global__ void __launch_bounds__(256) voxel_embed_bwd_kernel(const objnerf_voxe
   const long dld = scn ? (kScnVoxPE + kXyzPE) : kObjVoxPE;
   const int C = scn ? kScnVoxC : kObjVoxC;
   const int cc = scn ? sub : sub - kScnVoxC;
-  for (int it = 0; it < kVbPoints / 8; ++it) {
-    const long p = (long)blockIdx.x * kVbPoints + it * 8 + (threadIdx.x >> 5);
+  for (int it = 0; it < ppw / 8; ++it) {
+    const long p = (long)blockIdx.x * ppw + it * 8 + (threadIdx.x >> 5);
     if (p >= n || sub >= kVoxC || !dbase) continue;
     const float x = xyz[p * 3], y = xyz[p * 3 + 1], z = xyz[p * 3 + 2];
     const float sx = __fdiv_rn(x + g.offset[0], g.voxel_size);
@@ -399,12 +397,28 @@ int launch_voxel_embed_bwd(const objnerf_voxel_grid* grid, const float* xyz, lon
   if (n == 0) return 0;
   // (read on every call, not cached: tests/test_gpu_train.py switches it inside one process to cross-check the two forms)
   const bool saved_on = [] { const char* e = getenv("OBJNERF_SCATTER_SAVED"); return !e || atoi(e) != 0; }();
+  // The aggregation window (points per workgroup).  A workgroup's time is its trips through the point loop (8 points each, a chain
+  // of dependent round trips per trip), and six workgroups fit a CU (26 KB of LDS each): with the fixed 128-point window of rounds
+  // 3-5 the fine pass of the reference batch launched 2,048 workgroups on 1,536 slots -- two rounds of 16 trips, the second a third
+  // full -- and the coarse pass 1,024 (a third of the slots idle).  Now the window is what fills the slots ONCE: n / (6 CUs) points,
+  // between a quarter and three quarters of the hash's slot count: 64 and 192 (the 256-slot hash holds the rows of about that many neighbouring points; beyond it contributions go to
+  // memory one by one): 22 trips instead of 32, 11 instead of 16.  OBJNERF_VB_POINTS fixes it (tuning).
+  static const int cus_n = [] {
+    int dev = 0, c = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    return c > 0 ? c : 256;
+  }();
+  static const int fixed_ppw = [] { const char* e = getenv("OBJNERF_VB_POINTS"); return e ? atoi(e) : 0; }();
+  constexpr long kWgPerCu = (160 * 1024) / ((long)kVbSlots * (kVbStride + 1) * 4);      // resident workgroups per CU (LDS-bound): 6
+  long ppw = fixed_ppw > 0 ? fixed_ppw : (n + kWgPerCu * cus_n - 1) / (kWgPerCu * cus_n);
+  ppw = (ppw + 7) / 8 * 8;
+  if (fixed_ppw <= 0) ppw = ppw < kVbSlots / 4 ? kVbSlots / 4 : (ppw > 3 * kVbSlots / 4 ? 3 * kVbSlots / 4 : ppw);
   if (saved_on && emb_xyz && (obj_voxel || !d_obj_ftr))
-    hipLaunchKernelGGL(voxel_embed_bwd_kernel<true>, dim3(blk(n, kVbPoints)), dim3(256), 0, s, *grid, xyz, n, d_scene_ftr, d_obj_ftr,
-                       table_grad, emb_xyz, obj_voxel);
+    hipLaunchKernelGGL(voxel_embed_bwd_kernel<true>, dim3(blk(n, (int)ppw)), dim3(256), 0, s, *grid, xyz, n, d_scene_ftr, d_obj_ftr,
+                       table_grad, emb_xyz, obj_voxel, (int)ppw);
   else
-    hipLaunchKernelGGL(voxel_embed_bwd_kernel<false>, dim3(blk(n, kVbPoints)), dim3(256), 0, s, *grid, xyz, n, d_scene_ftr, d_obj_ftr,
-                       table_grad, nullptr, nullptr);
+    hipLaunchKernelGGL(voxel_embed_bwd_kernel<false>, dim3(blk(n, (int)ppw)), dim3(256), 0, s, *grid, xyz, n, d_scene_ftr, d_obj_ftr,
+                       table_grad, nullptr, nullptr, (int)ppw);
   return check_launch("voxel_embed_backward");
 }
 }  // namespace objnerf
