@@ -130,12 +130,10 @@ struct BwdHook {
   const Stage& sg;
   // MASKS = false: per-group spreading of the stores, as the forward's SaveHook does, overflows the register budget (gradient
   // in + gradient out + raw activation tiles leave no room for the store temporaries mid-layer)
-  // (every OBJ_SAVE_EVERY-th group: mlp_kernel.h SaveHook -- away from the chunk barriers)
-  static constexpr int min_groups = (MASKS && OBJ_BWD_SPREAD_SAVE) ? OBJ_SAVE_EVERY * (NTIN - 1) + 1 : 0;
+  static constexpr int min_groups = (MASKS && OBJ_BWD_SPREAD_SAVE) ? NTIN : 0;
   template <int GI>
   __device__ __forceinline__ void group() const {
-    if constexpr (MASKS && OBJ_BWD_SPREAD_SAVE && GI % OBJ_SAVE_EVERY == 0 && GI / OBJ_SAVE_EVERY < NTIN)
-      save_tile<NTIN>(hin, GI / OBJ_SAVE_EVERY, save_mat, save_ld, sg);
+    if constexpr (MASKS && OBJ_BWD_SPREAD_SAVE && GI < NTIN) save_tile<NTIN>(hin, GI, save_mat, save_ld, sg);
   }
   template <int C>
   __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {

@@ -176,13 +176,6 @@ __device__ __forceinline__ void load_group(ATiles<NT>& a, Stream& st) {
 // barrier drains vmcnt (LDS-DMA), so global loads/stores issued just BEFORE it are waited for in full, while ones
 // issued just AFTER it have a whole chunk of MFMAs to complete: the training kernels put their activation stores and
 // prefetches there.
-#ifndef OBJ_SAVE_EVERY
-// training kernels: MFMA groups between two tile stores of a layer's hook.  4 (every store right BEHIND a chunk barrier instead of
-// two of eight right in front of one, where the barrier's vmcnt(0) waits for them in full) was built and A/B'd in round 6: 18.237 vs
-// 18.242 ms per step over four alternating pairs (profiles/r06_train_ab_store_schedule.txt) -- the stores are not what the chunk
-// barriers wait for.  1 stays.
-#define OBJ_SAVE_EVERY 1
-#endif
 struct NoHook {
   static constexpr int min_groups = 0;      // groups the layer must have for the hook to have stored everything
   template <int C> __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {}
@@ -866,17 +859,20 @@ struct SaveHook {      // layer_mac after-barrier hook: write h (the layer's inp
   MaskBits<NT>& mb;
   template <int C>
   __device__ __forceinline__ void operator()(std::integral_constant<int, C>) const {}
-  // one tile per OBJ_SAVE_EVERY MFMA groups (a burst of all NT tiles' stores stalls the issuing wave like a burst of DMA pieces
-  // does); the mask word of a tile pair behind the pair's second tile, the mask store behind the last one
-  static constexpr int min_groups = ON ? OBJ_SAVE_EVERY * (NT - 1) + 1 : 0;
+  // one tile per MFMA group (a burst of all NT tiles' stores stalls the issuing wave like a burst of DMA pieces does); the
+  // mask word of a tile pair behind the pair's second tile, the mask store behind the last one.
+  // Round 6 measured what the saves cost and three other ways to do them (profiles/r06_train_probe_save.txt): without staging and
+  // stores the forward and the dgrad chain run 7 % faster, without the global stores alone 1.3 %; lane-native 16-byte pieces
+  // straight from the D layout (no LDS patch), every 4th group (away from the chunk barriers), and patch write / patch read /
+  // store spread over three groups all measured the same as this form -- none is kept.
+  static constexpr int min_groups = ON ? NT : 0;
   template <int GI>
   __device__ __forceinline__ void group() const {
-    if constexpr (ON && GI % OBJ_SAVE_EVERY == 0 && GI / OBJ_SAVE_EVERY < NT) {
-      constexpr int T = GI / OBJ_SAVE_EVERY;
-      save_tile<NT>(h, T, mat, ld, sg);
+    if constexpr (ON && GI < NT) {
+      save_tile<NT>(h, GI, mat, ld, sg);
       if (mrow) {
-        if constexpr (T & 1) sign_word<NT, T / 2>(h, mb);
-        if constexpr (T == NT - 1) store_masks<NT>(mb, mrow);
+        if constexpr (GI & 1) sign_word<NT, GI / 2>(h, mb);
+        if constexpr (GI == NT - 1) store_masks<NT>(mb, mrow);
       }
     }
   }
