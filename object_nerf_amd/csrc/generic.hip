@@ -245,7 +245,10 @@ static int check_arch(const objnerf_arch* a) {
 int64_t objnerf_mlp_generic_workspace_floats(const objnerf_arch* a, int64_t n_points) {
   if (check_arch(a) || n_points < 0) return -1;
   const int64_t wmax = a->W > a->inst_W ? a->W : a->inst_W;
-  return n_points * (2 * wmax + wmax + wmax / 2);          // two ping-pong hidden buffers | final | direction hidden
+  // two ping-pong hidden buffers | final | direction hidden | the packed weight stream of a run of plain layers (chain_generic.hip)
+  const int64_t chain = chain_scratch_floats(a->W, a->D) > chain_scratch_floats(a->inst_W, a->inst_D) ? chain_scratch_floats(a->W, a->D)
+                                                                                                        : chain_scratch_floats(a->inst_W, a->inst_D);
+  return n_points * (2 * wmax + wmax + wmax / 2) + chain + 4;
 }
 
 int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
@@ -272,6 +275,12 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
   float* buf[2] = {g->workspace, g->workspace + P * wmax};
   float* fin = g->workspace + 2 * P * wmax;
   float* dirh = fin + P * wmax;
+  float* chain_ws = dirh + P * (wmax / 2);
+  chain_ws += (4 - ((chain_ws - g->workspace) & 3)) & 3;           // 16-byte aligned behind the point buffers (the stream is DMA'd)
+  // Runs of plain hidden layers (not the first, not in `skips`) of a width that is a multiple of 32 from 96 to 256 go through ONE
+  // persistent kernel each (chain_generic.hip, round 6): rows read once, weights from the LDS ring, the layers chained in registers.
+  // OBJNERF_GENERIC_CHAIN=0: every layer its own GEMM as in rounds 4-5 (read on every call: the tests switch it inside a process).
+  const bool chain_on = [] { const char* e = getenv("OBJNERF_GENERIC_CHAIN"); return !e || atoi(e) != 0; }();
 
   // one branch: layers l = 0 .. D-1 (LeakyReLU; layer l in `skips` sees cat([input, h]), nerf_model.py:104-105, 137-138),
   // sigma head (no activation), final (no activation), direction layer cat([final, emb_dir]) -> W/2 LeakyReLU, rgb head
@@ -289,6 +298,7 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
       for (int i = 0; i < nin; ++i) { blk[nb++] = CatBlk{in[i].x, in[i].c, in[i].c, Wm + col}; col += in[i].c; }
       lin_cat(c, blk, nb, ldw, P, W, y, W, EPI_BIAS_LEAKY, bias);
     };
+    const bool chain_w = chain_on && W >= kChainMinWidth && W <= 256 && (W & 31) == 0;
     const float* h = nullptr;
     for (int l = 0; l < D; ++l) {
       float* y = buf[l & 1];
@@ -296,13 +306,23 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
       const float* b = q[2 * l + 1];
       if (l == 0) cat_layer(Wm, cin, nullptr, y, b);
       else if (has(skips, nsk, l)) cat_layer(Wm, cin + W, h, y, b);
-      else lin(c, h, W, Wm, W, P, W, W, y, W, 0, EPI_BIAS_LEAKY, b);
+      else if (chain_w) {
+        int l1 = l;                               // the run of plain layers l .. l1
+        while (l1 + 1 < D && !has(skips, nsk, l1 + 1) && l1 + 1 - l < kChainMaxLayers) ++l1;
+        const float* Ws[kChainMaxLayers];
+        const float* bs[kChainMaxLayers];
+        for (int i = l; i <= l1; ++i) { Ws[i - l] = q[2 * i]; bs[i - l] = q[2 * i + 1]; }
+        y = buf[l1 & 1];
+        if (!c.rc) c.rc = launch_chain(W, l1 - l + 1, Ws, bs, h, W, y, W, P, 1, chain_ws, c.s);
+        l = l1;
+      } else lin(c, h, W, Wm, W, P, W, W, y, W, 0, EPI_BIAS_LEAKY, b);
       h = y;
     }
     const float* const* t = q + 2 * D;          // final, dir, sigma, rgb
     lin(c, h, W, t[4], W, P, 1, W, sig, 1, 0, EPI_BIAS, t[5]);
     if (g->sigma_only) return;
-    lin(c, h, W, t[0], W, P, W, W, fin, W, 0, EPI_BIAS, t[1]);
+    if (chain_w) { if (!c.rc) c.rc = launch_chain(W, 1, &t[0], &t[1], h, W, fin, W, P, 0, chain_ws, c.s); }     // final: no activation
+    else lin(c, h, W, t[0], W, P, W, W, fin, W, 0, EPI_BIAS, t[1]);
     const CatBlk dblk[2] = {{fin, W, W, t[2]}, {g->emb_dir, a->in_dir, a->in_dir, t[2] + W}};       // cat([final, emb_dir])
     lin_cat(c, dblk, 2, W + a->in_dir, P, W / 2, dirh, W / 2, EPI_BIAS_LEAKY, t[3]);
     lin(c, dirh, W / 2, t[6], W / 2, P, 3, W / 2, rgb, 3, 0, EPI_BIAS_SIGMOID, t[7]);

@@ -25,6 +25,12 @@ int launch_mlp_bwd(const float* blob_bwd, const float* aux, long P, const float*
 // training: positional-encoding backward + trilinear scatter into the table gradient (train_kernels.hip); emb_xyz / obj_voxel optional
 int launch_voxel_embed_bwd(const objnerf_voxel_grid* grid, const float* xyz, long n, const float* d_scene_ftr, const float* d_obj_ftr,
                            float* table_grad, const float* emb_xyz, const float* obj_voxel, hipStream_t s);
+// any architecture: a run of plain (32 nt) -> (32 nt) hidden layers in one persistent kernel (chain_generic.hip)
+constexpr int kChainMaxLayers = 16;
+constexpr int kChainMinWidth = 96;      // three out tiles
+int64_t chain_scratch_floats(int width, int layers);
+int launch_chain(int width, int L, const float* const* Ws, const float* const* bs, const float* X, long ldx, float* Y, long ldy, long P,
+                 int act_last, float* scratch, hipStream_t s);
 // floats of the mask area behind the activation matrices of a training workspace (mlp_kernel.h: train_mask_floats)
 long train_mask_floats_host(long n_points);
 // persistent grid of the MLP kernel: one workgroup per CU
