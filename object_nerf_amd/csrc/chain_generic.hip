@@ -11,6 +11,7 @@
 // with one or two out tiles the compiler rejects layer_mac's DMA schedule, and such layers are a few microseconds of GEMM anyway), the D tile of
 // one layer is the B operand of the next, and only the last layer's output is written.  A single plain layer takes the same kernel
 // (L = 1): one read, one write, weights from LDS instead of a second operand panel per output tile.
+#include <string.h>
 #include "mlp_kernel.h"
 #include "host_api.h"
 
@@ -132,6 +133,243 @@ int launch_chain(int width, int L, const float* const* Ws, const float* const* b
     default: hipLaunchKernelGGL(chain_kernel<8>, grid, dim3(256), 0, s, a, ntiles); break;
   }
   return check_launch("chain");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A whole branch of any architecture in one persistent kernel (round 6): layers 0 .. D-1 -- the first layer and the skip layers read
+// their `torch.cat([emb_xyz (, obj_voxel, obj_code) (, h)])` input (nerf_model.py:100-105, 128-138) as 32-column BLOCKS of the
+// embedding rows straight from memory, the plain layers chain in registers as above -- then the 1-row density head on the VALU and the
+// activation-free `final` layer.  What is left to the GEMMs of generic.hip is the direction layer (W -> W / 2 on cat([final, dir]))
+// and the 3-row colour head.
+//
+// A memory block is a 16-k-step layer_mac of its own: lane (point, half) holds columns 8 g + 4 half .. + 3 (g = 0..3) of the block --
+// four 16-byte pieces of its point's row, the same feature <-> (k-step, half) map as hid_feat -- and the block's weights are one
+// chunk of the stream (its first 16 k-steps; columns past the tensor's width are zero).  The next block's pieces are requested
+// before the current block's MFMAs (two register sets).
+constexpr int kBrMaxLayers = 40;       // D + 1 (final)
+constexpr int kBrMaxBlocks = 24;       // 32-column blocks of the branch's input tensors
+struct BrLayer {
+  const float* W; const float* b;      // nn.Linear weight (out = width, in = ldw) and bias
+  int ldw;                             // in_features
+  int nblk;                            // > 0: the layer contracts the branch's input blocks (first layer, skip layers)
+  int hid_col0;                        // >= 0: ... and the previous layer's output, whose columns start here in W; -1: no hidden input
+  int flags;                           // 1: LeakyReLU, 2: the density head reads this layer's output
+  int chunk0;                          // first chunk of the layer in the stream
+  int pad;
+};
+struct BrBlock { const float* x; long ld; int wcol0, col0, ncols, pad; };     // columns [col0, col0 + ncols) of x = W columns wcol0 ..
+struct BrArgs {
+  BrLayer layer[kBrMaxLayers];
+  BrBlock blk[kBrMaxBlocks];
+  int nlayers, nblocks, nt, total_chunks;
+  const float* wsig; const float* bsig;          // density head: (1, width), (1)
+  float* sigma;                                  // (P)
+  float* Y; long ldy;                            // output rows of the LAST layer (null: not wanted, sigma_only)
+  long P;
+  float* blob; float* aux;                       // packed stream / biases + head, in the workspace
+};
+static_assert(sizeof(BrArgs) <= 3584, "the branch description travels as a kernel argument");
+constexpr int kBrAuxFloats(int layers) { return (layers + 1) * kChainAuxFloats + 4; }
+
+// grid (blocks over a layer's stream elements, layer): packs layer blockIdx.y's chunks; block (0, 0) also parks the description in
+// device memory for branch_kernel (indexing a by-value kernel argument with a run-time index would give that kernel a private copy
+// of the struct in scratch memory)
+__global__ void __launch_bounds__(256) branch_pack_kernel(const BrArgs a, BrArgs* __restrict__ parked) {
+  const int nt = a.nt, kg = chunk_ksteps(nt), ks_n = chain_ks(nt), l = blockIdx.y;
+  const BrLayer ly = a.layer[l];
+  const int nch = ly.nblk + (ly.hid_col0 >= 0 ? chain_cpl(nt) : 0);
+  float* out = a.blob + (long)ly.chunk0 * kChunkFloats;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)nch * kChunkFloats; i += (long)gridDim.x * 256) {
+    const int chunk = (int)(i / kChunkFloats), e = (int)(i % kChunkFloats);
+    const int slot = e >> 8, lane = (e >> 2) & 63, j = e & 3;
+    const int g4 = slot / nt, m = slot % nt, half = lane >> 5;
+    const long row = (long)(32 * m + (lane & 31)) * ly.ldw;
+    float v = 0.f;
+    if (chunk < ly.nblk) {                                  // a memory block: k-steps 0 .. 15 of its own chunk
+      const BrBlock b = a.blk[chunk];
+      const int ks = 4 * g4 + j, col = 8 * (ks >> 2) + (ks & 3) + 4 * half;
+      if (g4 < 4 && col < b.ncols) v = ly.W[row + b.wcol0 + col];
+    } else {
+      const int ks = (chunk - ly.nblk) * kg + 4 * g4 + j;
+      if (4 * g4 < kg && ks < ks_n) v = ly.W[row + ly.hid_col0 + hid_feat(ks, half)];
+    }
+    out[i] = v;
+  }
+  if (blockIdx.x == 0) {
+    for (int e = threadIdx.x; e < nt * 32; e += 256) {
+      const int m = e >> 5, half = (e >> 4) & 1, r = e & 15, f = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+      a.aux[l * kChainAuxFloats + e] = ly.b[f];
+      if (l == 0) a.aux[a.nlayers * kChainAuxFloats + e] = a.wsig[f];
+    }
+    if (l == 0 && threadIdx.x == 0) a.aux[a.nlayers * kChainAuxFloats + nt * 32] = a.bsig[0];
+    if (l == 0) {
+      const unsigned* src = (const unsigned*)&a;
+      unsigned* dst = (unsigned*)parked;
+      for (unsigned i = threadIdx.x; i < sizeof(BrArgs) / 4; i += 256) dst[i] = src[i];
+    }
+  }
+}
+
+struct RegSrc16 {
+  const float (&v)[16];
+  template <int I>
+  __device__ __forceinline__ float get() { return v[I]; }
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict__ ap, const long ntiles) {
+  constexpr int kCB = kChunkBytes;
+  constexpr int kAuxBytes = kBrAuxFloats(kBrMaxLayers) * 4;
+  __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kCB + kAuxBytes + kStageBytes];
+  __shared__ int lay_nblk[kBrMaxLayers], lay_hid[kBrMaxLayers], lay_flags[kBrMaxLayers];
+  __shared__ BrBlock blks[kBrMaxBlocks];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, wave = tid >> 6;
+  const int nl = __builtin_amdgcn_readfirstlane(ap->nlayers), nb = __builtin_amdgcn_readfirstlane(ap->nblocks);
+  const long P = ap->P;
+  for (int i = tid; i < nl; i += 256) { lay_nblk[i] = ap->layer[i].nblk; lay_hid[i] = ap->layer[i].hid_col0; lay_flags[i] = ap->layer[i].flags; }
+  for (int i = tid; i < nb; i += 256) blks[i] = ap->blk[i];
+  float* aux_lds = (float*)(ring_mem + kRingSlots * kCB);
+  const float* gaux = ap->aux;
+  for (int i = tid; i < kBrAuxFloats(nl); i += 256) aux_lds[i] = gaux[i];
+  WeightStreamT<kCB> st;
+  st.init((const char*)ap->blob, __builtin_amdgcn_readfirstlane(ap->total_chunks), (lds_char*)ring_mem, tid);
+  float* const sigma_out = ap->sigma;
+  float* const Y = ap->Y;
+  const long ldy = ap->ldy;
+  __syncthreads();
+  const float* aux_sig = aux_lds + nl * kChainAuxFloats;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const Stage sg{(float*)(ring_mem + kRingSlots * kCB + kAuxBytes) + wave * kStageFloats, tile * 128 + wave * 32, P, lane};
+    const long p_raw = sg.p0 + (lane & 31);
+    const long p = p_raw < P ? p_raw : P - 1;              // rows past the end repeat the last one; nothing of them is stored
+    f32x16 acc[NT], h[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[m][r] = 0.f;
+    // this lane's 16 values of input block e: columns 8 g + 4 half .. + 3 of the block are k-steps 4 g .. 4 g + 3
+    auto fetch = [&](int e, float (&v)[16]) __attribute__((always_inline)) {
+      const float* x = blks[e].x + p * blks[e].ld + blks[e].col0 + 4 * half;
+      const int ncols = blks[e].ncols;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 8 * g + 4 * half;
+        if (c + 4 <= ncols) {
+          const f32x4 q = *(const f32x4u*)(x + 8 * g);
+          v[4 * g] = q[0]; v[4 * g + 1] = q[1]; v[4 * g + 2] = q[2]; v[4 * g + 3] = q[3];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[4 * g + i] = c + i < ncols ? x[8 * g + i] : 0.f;
+        }
+      }
+    };
+#pragma unroll 1
+    for (int l = 0; l < nl; ++l) {
+      const int nblk = __builtin_amdgcn_readfirstlane(lay_nblk[l]), hid = __builtin_amdgcn_readfirstlane(lay_hid[l]);
+      const int flags = __builtin_amdgcn_readfirstlane(lay_flags[l]);
+      const float* b = aux_lds + l * kChainAuxFloats + half * 16;
+#pragma unroll
+      for (int m = 0; m < NT; ++m) acc[m] = *(const f32x16*)(b + m * 32);
+      if (nblk > 0) {                                      // (uniform) the branch's input blocks, two register sets in turn
+        float r0[16], r1[16];
+        int e = 0;
+        fetch(0, r0);
+        while (true) {
+          if (e + 1 < nblk) fetch(e + 1, r1);
+          { RegSrc16 s{r0}; layer_mac<NT, 16, RegSrc16>(acc, st, s); }
+          if (++e >= nblk) break;
+          if (e + 1 < nblk) fetch(e + 1, r0);
+          { RegSrc16 s{r1}; layer_mac<NT, 16, RegSrc16>(acc, st, s); }
+          if (++e >= nblk) break;
+        }
+      }
+      if (hid >= 0) {
+        HidSrc<NT> s{h};
+        layer_mac<NT, chain_ks(NT), HidSrc<NT>>(acc, st, s);
+      }
+      if (flags & 1) finish<NT, true>(acc, h);
+      else finish<NT, false>(acc, h);
+      if (flags & 2) {                                     // density head on this layer's output (nerf_model.py:111, 141)
+        const float sgm = head_dot<NT>(h, aux_sig, half) + aux_sig[NT * 32];
+        if (half == 0 && p_raw < P) sigma_out[p_raw] = sgm;
+      }
+    }
+    if (Y) save_tiles<NT>(h, Y, ldy, sg);
+  }
+}
+
+// chunks of a branch's stream: every block layer (the first + the skip layers) one chunk per input block, every layer with a hidden
+// input (all but the first; + final) chain_cpl chunks
+static long branch_chunks(int width, int D, int nskips, int nblocks, bool with_final) {
+  const int nt = width / 32;
+  return (long)(1 + nskips) * nblocks + (long)(D - 1 + (with_final ? 1 : 0)) * chain_cpl(nt);
+}
+static int blocks_of(int cols) { return (cols + 31) / 32; }
+int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c) {
+  if (width < kChainMinWidth || width > 256 || (width & 31) || D + 1 > kBrMaxLayers) return 0;
+  const int nb = blocks_of(in_a) + (in_b > 0 ? blocks_of(in_b) : 0) + (in_c > 0 ? blocks_of(in_c) : 0);
+  if (nb > kBrMaxBlocks) return 0;
+  return branch_chunks(width, D, nskips, nb, true) * kChunkFloats + kBrAuxFloats(D + 1) + (int64_t)(sizeof(BrArgs) + 3) / 4 + 8;
+}
+
+// One branch: q = the branch's parameter pointers in objnerf_arch order (D layers' weight, bias; then final, dir, sigma, rgb),
+// in[] = its input tensors (row-major, `c` columns each, concatenated in this order by the reference).  Writes sigma (P) and, unless
+// sigma_only, the final layer's rows to fin (P x width).  Returns 1 when the shape is not one this kernel takes (the caller then
+// runs its GEMMs), 0 on success, < 0 on error.
+int launch_branch(int width, int D, const int32_t* skips, int nskips, const float* const* q, const BranchInput* in, int nin, long P,
+                  float* sigma, float* fin, bool sigma_only, float* scratch, hipStream_t s) {
+  if (width < kChainMinWidth || width > 256 || (width & 31) || D + 1 > kBrMaxLayers || D < 1) return 1;
+  BrArgs a;
+  memset(&a, 0, sizeof(a));
+  int nb = 0, cin = 0;
+  for (int i = 0; i < nin; ++i) {
+    for (int c0 = 0; c0 < in[i].c; c0 += 32) {
+      if (nb >= kBrMaxBlocks) return 1;
+      a.blk[nb++] = BrBlock{in[i].x, (long)in[i].c, cin + c0, c0, in[i].c - c0 < 32 ? in[i].c - c0 : 32, 0};
+    }
+    cin += in[i].c;
+  }
+  const int nt = width / 32;
+  auto is_skip = [&](int l) { for (int i = 0; i < nskips; ++i) if (skips[i] == l) return true; return false; };
+  int chunk = 0, nl = 0;
+  for (int l = 0; l < D; ++l) {
+    const bool blk_layer = l == 0 || is_skip(l);
+    BrLayer& y = a.layer[nl++];
+    y.W = q[2 * l]; y.b = q[2 * l + 1];
+    y.nblk = blk_layer ? nb : 0;
+    y.hid_col0 = l == 0 ? -1 : (blk_layer ? cin : 0);
+    y.ldw = (blk_layer ? cin : 0) + (l == 0 ? 0 : width);
+    y.flags = 1 | (l == D - 1 ? 2 : 0);
+    y.chunk0 = chunk;
+    chunk += y.nblk + (y.hid_col0 >= 0 ? chain_cpl(nt) : 0);
+  }
+  const float* const* t = q + 2 * D;            // final, dir, sigma, rgb
+  if (!sigma_only) {
+    BrLayer& y = a.layer[nl++];
+    y.W = t[0]; y.b = t[1]; y.nblk = 0; y.hid_col0 = 0; y.ldw = width; y.flags = 0; y.chunk0 = chunk;
+    chunk += chain_cpl(nt);
+  }
+  a.nlayers = nl; a.nblocks = nb; a.nt = nt; a.total_chunks = chunk;
+  a.wsig = t[4]; a.bsig = t[5];
+  a.sigma = sigma; a.Y = sigma_only ? nullptr : fin; a.ldy = width; a.P = P;
+  a.blob = scratch;
+  a.aux = scratch + (long)chunk * kChunkFloats;
+  BrArgs* parked = (BrArgs*)(a.aux + kBrAuxFloats(nl) + ((4 - (kBrAuxFloats(nl) & 3)) & 3));
+  if (P <= 0) return 0;
+  const int max_ch = nb + chain_cpl(nt);
+  hipLaunchKernelGGL(branch_pack_kernel, dim3((unsigned)((max_ch * kChunkFloats + 4095) / 4096), (unsigned)nl), dim3(256), 0, s, a, parked);
+  const long ntiles = (P + 127) / 128;
+  const dim3 grid(mlp_grid(ntiles));
+  switch (nt) {
+    case 3: hipLaunchKernelGGL(branch_kernel<3>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
+    case 4: hipLaunchKernelGGL(branch_kernel<4>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
+    case 5: hipLaunchKernelGGL(branch_kernel<5>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
+    case 6: hipLaunchKernelGGL(branch_kernel<6>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
+    case 7: hipLaunchKernelGGL(branch_kernel<7>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
+    default: hipLaunchKernelGGL(branch_kernel<8>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
+  }
+  return check_launch("branch");
 }
 
 }  // namespace objnerf

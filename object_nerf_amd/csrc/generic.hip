@@ -246,8 +246,13 @@ int64_t objnerf_mlp_generic_workspace_floats(const objnerf_arch* a, int64_t n_po
   if (check_arch(a) || n_points < 0) return -1;
   const int64_t wmax = a->W > a->inst_W ? a->W : a->inst_W;
   // two ping-pong hidden buffers | final | direction hidden | the packed weight stream of a run of plain layers (chain_generic.hip)
-  const int64_t chain = chain_scratch_floats(a->W, a->D) > chain_scratch_floats(a->inst_W, a->inst_D) ? chain_scratch_floats(a->W, a->D)
-                                                                                                        : chain_scratch_floats(a->inst_W, a->inst_D);
+  int64_t chain = chain_scratch_floats(a->W, a->D) > chain_scratch_floats(a->inst_W, a->inst_D) ? chain_scratch_floats(a->W, a->D)
+                                                                                                  : chain_scratch_floats(a->inst_W, a->inst_D);
+  // ... or of a whole branch (first / skip layers as input blocks + plain layers + final)
+  const int64_t br_s = branch_scratch_floats(a->W, a->D, a->n_skips, a->in_xyz, 0, 0);
+  const int64_t br_o = branch_scratch_floats(a->inst_W, a->inst_D, a->n_inst_skips, a->in_xyz, a->obj_voxel_c, a->code_c);
+  if (br_s > chain) chain = br_s;
+  if (br_o > chain) chain = br_o;
   return n_points * (2 * wmax + wmax + wmax / 2) + chain + 4;
 }
 
@@ -280,7 +285,8 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
   // Runs of plain hidden layers (not the first, not in `skips`) of a width that is a multiple of 32 from 96 to 256 go through ONE
   // persistent kernel each (chain_generic.hip, round 6): rows read once, weights from the LDS ring, the layers chained in registers.
   // OBJNERF_GENERIC_CHAIN=0: every layer its own GEMM as in rounds 4-5 (read on every call: the tests switch it inside a process).
-  const bool chain_on = [] { const char* e = getenv("OBJNERF_GENERIC_CHAIN"); return !e || atoi(e) != 0; }();
+  const int chain_mode = [] { const char* e = getenv("OBJNERF_GENERIC_CHAIN"); return e ? atoi(e) : 2; }();      // 2: whole branches; 1: plain runs only
+  const bool chain_on = chain_mode != 0;
 
   // one branch: layers l = 0 .. D-1 (LeakyReLU; layer l in `skips` sees cat([input, h]), nerf_model.py:104-105, 137-138),
   // sigma head (no activation), final (no activation), direction layer cat([final, emb_dir]) -> W/2 LeakyReLU, rgb head
@@ -299,8 +305,17 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
       lin_cat(c, blk, nb, ldw, P, W, y, W, EPI_BIAS_LEAKY, bias);
     };
     const bool chain_w = chain_on && W >= kChainMinWidth && W <= 256 && (W & 31) == 0;
+    // the whole branch up to `final` in one persistent kernel when the shape allows it (chain_generic.hip: launch_branch)
+    bool branch_done = false;
+    if (chain_w && chain_mode >= 2 && !c.rc) {
+      BranchInput bin[3];
+      for (int i = 0; i < nin; ++i) bin[i] = BranchInput{in[i].x, in[i].c};
+      const int rc = launch_branch(W, D, skips, nsk, q, bin, nin, P, sig, fin, g->sigma_only != 0, chain_ws, c.s);
+      if (rc < 0) c.rc = rc;
+      branch_done = rc == 0;
+    }
     const float* h = nullptr;
-    for (int l = 0; l < D; ++l) {
+    for (int l = 0; l < D && !branch_done; ++l) {
       float* y = buf[l & 1];
       const float* Wm = q[2 * l];
       const float* b = q[2 * l + 1];
@@ -319,9 +334,10 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
       h = y;
     }
     const float* const* t = q + 2 * D;          // final, dir, sigma, rgb
-    lin(c, h, W, t[4], W, P, 1, W, sig, 1, 0, EPI_BIAS, t[5]);
+    if (!branch_done) lin(c, h, W, t[4], W, P, 1, W, sig, 1, 0, EPI_BIAS, t[5]);
     if (g->sigma_only) return;
-    if (chain_w) { if (!c.rc) c.rc = launch_chain(W, 1, &t[0], &t[1], h, W, fin, W, P, 0, chain_ws, c.s); }     // final: no activation
+    if (branch_done) {}
+    else if (chain_w) { if (!c.rc) c.rc = launch_chain(W, 1, &t[0], &t[1], h, W, fin, W, P, 0, chain_ws, c.s); }     // final: no activation
     else lin(c, h, W, t[0], W, P, W, W, fin, W, 0, EPI_BIAS, t[1]);
     const CatBlk dblk[2] = {{fin, W, W, t[2]}, {g->emb_dir, a->in_dir, a->in_dir, t[2] + W}};       // cat([final, emb_dir])
     lin_cat(c, dblk, 2, W + a->in_dir, P, W / 2, dirh, W / 2, EPI_BIAS_LEAKY, t[3]);

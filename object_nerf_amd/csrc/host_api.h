@@ -31,6 +31,12 @@ constexpr int kChainMinWidth = 96;      // three out tiles
 int64_t chain_scratch_floats(int width, int layers);
 int launch_chain(int width, int L, const float* const* Ws, const float* const* bs, const float* X, long ldx, float* Y, long ldy, long P,
                  int act_last, float* scratch, hipStream_t s);
+// any architecture: a whole branch (first / skip layers from 32-column blocks of the input tensors, plain layers chained, density
+// head, final layer) in one persistent kernel; returns 1 when the shape is outside what it takes (chain_generic.hip)
+struct BranchInput { const float* x; int c; };
+int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c);
+int launch_branch(int width, int D, const int32_t* skips, int nskips, const float* const* q, const BranchInput* in, int nin, long P,
+                  float* sigma, float* fin, bool sigma_only, float* scratch, hipStream_t s);
 // floats of the mask area behind the activation matrices of a training workspace (mlp_kernel.h: train_mask_floats)
 long train_mask_floats_host(long n_points);
 // persistent grid of the MLP kernel: one workgroup per CU

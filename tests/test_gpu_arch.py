@@ -240,7 +240,8 @@ def test_layerwise_training_path_agrees_with_the_fused_training_kernels(monkeypa
 def test_runs_of_plain_layers_in_one_kernel_match_the_per_layer_gemms(W, D, skips, inst_W, inst_D, inst_skips, monkeypatch):
     """csrc/chain_generic.hip (round 6): every run of plain hidden layers of a width 32 NT in [96, 256] -- and the activation-free
     `final` layer -- is one persistent kernel (weights packed per call into the LDS-ring chunk layout, layers chained in registers)
-    instead of a GEMM per layer.  Widths with 3, 5, 7, 8 (scene) and 3, 4, 6 (object) out tiles, runs of 1 to 7 layers, 700 points
+    instead of a GEMM per layer; by default the WHOLE branch up to `final` is one kernel (the first and the skip layers contract
+    32-column blocks of the embedding rows straight from memory, the density head runs on the VALU).  Widths with 3, 5, 7, 8 (scene) and 3, 4, 6 (object) out tiles, runs of 1 to 7 layers, 700 points
     (a ragged last tile), against the per-layer GEMMs of rounds 4-5 (OBJNERF_GENERIC_CHAIN=0) and against plain torch fp32 on the
     same parameters (models/nerf_model.py:97-152): fp32-roundoff class."""
     from object_nerf_amd import generic
@@ -255,11 +256,16 @@ def test_runs_of_plain_layers_in_one_kernel_match_the_per_layer_gemms(W, D, skip
         with torch.no_grad():
             return generic.mlp(m, ex, ed, None, code, True, True)
     monkeypatch.delenv("OBJNERF_GENERIC_CHAIN", raising=False)
-    a = run()
+    a = run()                                     # whole branches in one kernel each (first / skip layers from input blocks, density head)
+    monkeypatch.setenv("OBJNERF_GENERIC_CHAIN", "1")
+    a1 = run()                                    # only the runs of plain layers
     monkeypatch.setenv("OBJNERF_GENERIC_CHAIN", "0")
-    b = run()
+    b = run()                                     # a GEMM per layer
     monkeypatch.delenv("OBJNERF_GENERIC_CHAIN", raising=False)
-    assert any(not torch.equal(x, y) for x, y in zip(a, b)), "the switch did not select another path"
+    assert any(not torch.equal(x, y) for x, y in zip(a, b)) and any(not torch.equal(x, y) for x, y in zip(a1, b)) \
+        and any(not torch.equal(x, y) for x, y in zip(a, a1)), "the switch did not select another path"
+    for x, y in zip(a1, b):
+        assert H.normwise(x, y) < 1e-5, H.normwise(x, y)
     # plain torch on the same parameters
     mods = dict(m.named_modules())
     with torch.no_grad():
