@@ -163,6 +163,7 @@ struct BrArgs {
   BrLayer layer[kBrMaxLayers];
   BrBlock blk[kBrMaxBlocks];
   int nlayers, nblocks, nt, total_chunks;
+  int width, pad0;                               // the branch's real width (<= 32 nt: 32- and 64-wide branches run on three out tiles, zero-padded)
   const float* wsig; const float* bsig;          // density head: (1, width), (1)
   float* sigma;                                  // (P)
   float* Y; long ldy;                            // output rows of the LAST layer (null: not wanted, sigma_only)
@@ -184,23 +185,25 @@ __global__ void __launch_bounds__(256) branch_pack_kernel(const BrArgs a, BrArgs
     const int chunk = (int)(i / kChunkFloats), e = (int)(i % kChunkFloats);
     const int slot = e >> 8, lane = (e >> 2) & 63, j = e & 3;
     const int g4 = slot / nt, m = slot % nt, half = lane >> 5;
-    const long row = (long)(32 * m + (lane & 31)) * ly.ldw;
+    const int orow = 32 * m + (lane & 31);                  // output feature; rows / hidden columns past the real width: zero
+    const long row = (long)orow * ly.ldw;
     float v = 0.f;
-    if (chunk < ly.nblk) {                                  // a memory block: k-steps 0 .. 15 of its own chunk
+    if (orow >= a.width) {
+    } else if (chunk < ly.nblk) {                           // a memory block: k-steps 0 .. 15 of its own chunk
       const BrBlock b = a.blk[chunk];
       const int ks = 4 * g4 + j, col = 8 * (ks >> 2) + (ks & 3) + 4 * half;
       if (g4 < 4 && col < b.ncols) v = ly.W[row + b.wcol0 + col];
     } else {
       const int ks = (chunk - ly.nblk) * kg + 4 * g4 + j;
-      if (4 * g4 < kg && ks < ks_n) v = ly.W[row + ly.hid_col0 + hid_feat(ks, half)];
+      if (4 * g4 < kg && ks < ks_n && hid_feat(ks, half) < a.width) v = ly.W[row + ly.hid_col0 + hid_feat(ks, half)];
     }
     out[i] = v;
   }
   if (blockIdx.x == 0) {
     for (int e = threadIdx.x; e < nt * 32; e += 256) {
       const int m = e >> 5, half = (e >> 4) & 1, r = e & 15, f = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-      a.aux[l * kChainAuxFloats + e] = ly.b[f];
-      if (l == 0) a.aux[a.nlayers * kChainAuxFloats + e] = a.wsig[f];
+      a.aux[l * kChainAuxFloats + e] = f < a.width ? ly.b[f] : 0.f;
+      if (l == 0) a.aux[a.nlayers * kChainAuxFloats + e] = f < a.width ? a.wsig[f] : 0.f;
     }
     if (l == 0 && threadIdx.x == 0) a.aux[a.nlayers * kChainAuxFloats + nt * 32] = a.bsig[0];
     if (l == 0) {
@@ -234,6 +237,7 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
   for (int i = tid; i < kBrAuxFloats(nl); i += 256) aux_lds[i] = gaux[i];
   WeightStreamT<kCB> st;
   st.init((const char*)ap->blob, __builtin_amdgcn_readfirstlane(ap->total_chunks), (lds_char*)ring_mem, tid);
+  const int nt_real = __builtin_amdgcn_readfirstlane(ap->width) >> 5;
   float* const sigma_out = ap->sigma;
   float* const Y = ap->Y;
   const long ldy = ap->ldy;
@@ -295,7 +299,11 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
         if (half == 0 && p_raw < P) sigma_out[p_raw] = sgm;
       }
     }
-    if (Y) save_tiles<NT>(h, Y, ldy, sg);
+    if (Y) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t < nt_real) save_tile<NT>(h, t, Y, ldy, sg);      // (uniform: the padding tiles of a narrow branch have no columns)
+    }
   }
 }
 
@@ -306,8 +314,10 @@ static long branch_chunks(int width, int D, int nskips, int nblocks, bool with_f
   return (long)(1 + nskips) * nblocks + (long)(D - 1 + (with_final ? 1 : 0)) * chain_cpl(nt);
 }
 static int blocks_of(int cols) { return (cols + 31) / 32; }
+static int branch_width(int width) { return width < kChainMinWidth ? kChainMinWidth : width; }       // the width the kernel runs at
 int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c) {
-  if (width < kChainMinWidth || width > 256 || (width & 31) || D + 1 > kBrMaxLayers) return 0;
+  if (width < 32 || width > 256 || (width & 31) || D + 1 > kBrMaxLayers) return 0;
+  width = branch_width(width);
   const int nb = blocks_of(in_a) + (in_b > 0 ? blocks_of(in_b) : 0) + (in_c > 0 ? blocks_of(in_c) : 0);
   if (nb > kBrMaxBlocks) return 0;
   return branch_chunks(width, D, nskips, nb, true) * kChunkFloats + kBrAuxFloats(D + 1) + (int64_t)(sizeof(BrArgs) + 3) / 4 + 8;
@@ -319,7 +329,10 @@ int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, 
 // runs its GEMMs), 0 on success, < 0 on error.
 int launch_branch(int width, int D, const int32_t* skips, int nskips, const float* const* q, const BranchInput* in, int nin, long P,
                   float* sigma, float* fin, bool sigma_only, float* scratch, hipStream_t s) {
-  if (width < kChainMinWidth || width > 256 || (width & 31) || D + 1 > kBrMaxLayers || D < 1) return 1;
+  if (width < 32 || width > 256 || (width & 31) || D + 1 > kBrMaxLayers || D < 1) return 1;
+  const int width_real = width;
+  width = branch_width(width);                  // 32- and 64-wide branches: three out tiles, the surplus zero (layer_mac does not
+                                                // compile for one or two out tiles)
   BrArgs a;
   memset(&a, 0, sizeof(a));
   int nb = 0, cin = 0;
@@ -339,7 +352,7 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
     y.W = q[2 * l]; y.b = q[2 * l + 1];
     y.nblk = blk_layer ? nb : 0;
     y.hid_col0 = l == 0 ? -1 : (blk_layer ? cin : 0);
-    y.ldw = (blk_layer ? cin : 0) + (l == 0 ? 0 : width);
+    y.ldw = (blk_layer ? cin : 0) + (l == 0 ? 0 : width_real);
     y.flags = 1 | (l == D - 1 ? 2 : 0);
     y.chunk0 = chunk;
     chunk += y.nblk + (y.hid_col0 >= 0 ? chain_cpl(nt) : 0);
@@ -347,12 +360,13 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
   const float* const* t = q + 2 * D;            // final, dir, sigma, rgb
   if (!sigma_only) {
     BrLayer& y = a.layer[nl++];
-    y.W = t[0]; y.b = t[1]; y.nblk = 0; y.hid_col0 = 0; y.ldw = width; y.flags = 0; y.chunk0 = chunk;
+    y.W = t[0]; y.b = t[1]; y.nblk = 0; y.hid_col0 = 0; y.ldw = width_real; y.flags = 0; y.chunk0 = chunk;
     chunk += chain_cpl(nt);
   }
   a.nlayers = nl; a.nblocks = nb; a.nt = nt; a.total_chunks = chunk;
   a.wsig = t[4]; a.bsig = t[5];
-  a.sigma = sigma; a.Y = sigma_only ? nullptr : fin; a.ldy = width; a.P = P;
+  a.width = width_real;
+  a.sigma = sigma; a.Y = sigma_only ? nullptr : fin; a.ldy = width_real; a.P = P;
   a.blob = scratch;
   a.aux = scratch + (long)chunk * kChunkFloats;
   BrArgs* parked = (BrArgs*)(a.aux + kBrAuxFloats(nl) + ((4 - (kBrAuxFloats(nl) & 3)) & 3));

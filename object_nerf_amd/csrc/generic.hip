@@ -307,7 +307,7 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
     const bool chain_w = chain_on && W >= kChainMinWidth && W <= 256 && (W & 31) == 0;
     // the whole branch up to `final` in one persistent kernel when the shape allows it (chain_generic.hip: launch_branch)
     bool branch_done = false;
-    if (chain_w && chain_mode >= 2 && !c.rc) {
+    if (chain_mode >= 2 && W >= 32 && W <= 256 && (W & 31) == 0 && !c.rc) {      // (32 / 64 wide: zero-padded to three out tiles)
       BranchInput bin[3];
       for (int i = 0; i < nin; ++i) bin[i] = BranchInput{in[i].x, in[i].c};
       const int rc = launch_branch(W, D, skips, nsk, q, bin, nin, P, sig, fin, g->sigma_only != 0, chain_ws, c.s);

@@ -236,14 +236,16 @@ def test_layerwise_training_path_agrees_with_the_fused_training_kernels(monkeypa
 
 
 @pytest.mark.parametrize("W,D,skips,inst_W,inst_D,inst_skips", [(96, 4, [2], 96, 3, []), (160, 6, [3], 128, 4, [2]),
-                                                                 (224, 5, [], 192, 2, []), (256, 8, [4], 128, 4, [2])])
+                                                                 (224, 5, [], 192, 2, []), (256, 8, [4], 128, 4, [2]),
+                                                                 (128, 6, [3], 64, 3, [1]), (64, 4, [1, 3], 32, 2, [])])
 def test_runs_of_plain_layers_in_one_kernel_match_the_per_layer_gemms(W, D, skips, inst_W, inst_D, inst_skips, monkeypatch):
     """csrc/chain_generic.hip (round 6): every run of plain hidden layers of a width 32 NT in [96, 256] -- and the activation-free
     `final` layer -- is one persistent kernel (weights packed per call into the LDS-ring chunk layout, layers chained in registers)
     instead of a GEMM per layer; by default the WHOLE branch up to `final` is one kernel (the first and the skip layers contract
     32-column blocks of the embedding rows straight from memory, the density head runs on the VALU).  Widths with 3, 5, 7, 8 (scene) and 3, 4, 6 (object) out tiles, runs of 1 to 7 layers, 700 points
     (a ragged last tile), against the per-layer GEMMs of rounds 4-5 (OBJNERF_GENERIC_CHAIN=0) and against plain torch fp32 on the
-    same parameters (models/nerf_model.py:97-152): fp32-roundoff class."""
+    same parameters (models/nerf_model.py:97-152): fp32-roundoff class.  32- and 64-wide branches run zero-padded on three out tiles
+    (whole-branch form only; their runs of plain layers alone stay GEMMs)."""
     from object_nerf_amd import generic
     torch.manual_seed(W)
     m = A.ObjectNeRF(A.default_model_config(W=W, D=D, skips=skips, inst_W=inst_W, inst_D=inst_D, inst_skips=inst_skips,
@@ -262,8 +264,10 @@ def test_runs_of_plain_layers_in_one_kernel_match_the_per_layer_gemms(W, D, skip
     monkeypatch.setenv("OBJNERF_GENERIC_CHAIN", "0")
     b = run()                                     # a GEMM per layer
     monkeypatch.delenv("OBJNERF_GENERIC_CHAIN", raising=False)
-    assert any(not torch.equal(x, y) for x, y in zip(a, b)) and any(not torch.equal(x, y) for x, y in zip(a1, b)) \
-        and any(not torch.equal(x, y) for x, y in zip(a, a1)), "the switch did not select another path"
+    assert any(not torch.equal(x, y) for x, y in zip(a, b)) and any(not torch.equal(x, y) for x, y in zip(a, a1)), \
+        "the switch did not select another path"
+    if W >= 96:
+        assert any(not torch.equal(x, y) for x, y in zip(a1, b)), "the switch did not select another path"
     for x, y in zip(a1, b):
         assert H.normwise(x, y) < 1e-5, H.normwise(x, y)
     # plain torch on the same parameters
