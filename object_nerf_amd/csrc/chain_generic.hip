@@ -156,14 +156,18 @@ struct BrLayer {
   int hid_col0;                        // >= 0: ... and the previous layer's output, whose columns start here in W; -1: no hidden input
   int flags;                           // 1: LeakyReLU, 2: the density head reads this layer's output
   int chunk0;                          // first chunk of the layer in the stream
-  int pad;
+  int blk0;                            // its input blocks are blk[blk0 .. blk0 + nblk)
 };
 struct BrBlock { const float* x; long ld; int wcol0, col0, ncols, pad; };     // columns [col0, col0 + ncols) of x = W columns wcol0 ..
 struct BrArgs {
   BrLayer layer[kBrMaxLayers];
   BrBlock blk[kBrMaxBlocks];
   int nlayers, nblocks, nt, total_chunks;
-  int width, pad0;                               // the branch's real width (<= 32 nt: 32- and 64-wide branches run on three out tiles, zero-padded)
+  int width, has_dir;                            // the branch's real width (<= 32 nt: 32- and 64-wide branches run on three out tiles, zero-padded)
+  // has_dir: layer[nlayers] is the direction layer -- cat([final, emb_dir]) -> width / 2, LeakyReLU (nerf_model.py:116-118, 147-149) --
+  // on dir_tiles(nt) out tiles, followed by the 3-row colour head + sigmoid: the kernel then writes rgb instead of final's rows
+  const float* wrgb; const float* brgb;          // (3, width / 2), (3)
+  float* rgb;                                    // (P, 3)
   const float* wsig; const float* bsig;          // density head: (1, width), (1)
   float* sigma;                                  // (P)
   float* Y; long ldy;                            // output rows of the LAST layer (null: not wanted, sigma_only)
@@ -171,15 +175,22 @@ struct BrArgs {
   float* blob; float* aux;                       // packed stream / biases + head, in the workspace
 };
 static_assert(sizeof(BrArgs) <= 3584, "the branch description travels as a kernel argument");
-constexpr int kBrAuxFloats(int layers) { return (layers + 1) * kChainAuxFloats + 4; }
+// out tiles of the direction layer: width / 2 <= 96 columns on three tiles (zero-padded), more on four
+OBJ_HD constexpr int dir_tiles(int nt) { return nt <= 6 ? 3 : 4; }
+// aux: per layer 256 bias floats (the direction layer's too) | density head: 256 weights + bias | colour head: 3 x 128 weights + 3 biases
+constexpr int kBrAuxFloats(int layers) { return (layers + 1) * kChainAuxFloats + kChainAuxFloats + 4 + 3 * 128 + 4; }
 
 // grid (blocks over a layer's stream elements, layer): packs layer blockIdx.y's chunks; block (0, 0) also parks the description in
 // device memory for branch_kernel (indexing a by-value kernel argument with a run-time index would give that kernel a private copy
 // of the struct in scratch memory)
 __global__ void __launch_bounds__(256) branch_pack_kernel(const BrArgs a, BrArgs* __restrict__ parked) {
-  const int nt = a.nt, kg = chunk_ksteps(nt), ks_n = chain_ks(nt), l = blockIdx.y;
+  const int l = blockIdx.y;
+  const bool dirl = a.has_dir && l == a.nlayers;           // the direction layer: its own out-tile count and real width
+  const int nt = dirl ? dir_tiles(a.nt) : a.nt, kg = chunk_ksteps(nt), ks_n = chain_ks(a.nt);
+  const int width_out = dirl ? a.width / 2 : a.width;
   const BrLayer ly = a.layer[l];
-  const int nch = ly.nblk + (ly.hid_col0 >= 0 ? chain_cpl(nt) : 0);
+  const int hid_chunks = (ks_n + kg - 1) / kg;
+  const int nch = ly.nblk + (ly.hid_col0 >= 0 ? hid_chunks : 0);
   float* out = a.blob + (long)ly.chunk0 * kChunkFloats;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)nch * kChunkFloats; i += (long)gridDim.x * 256) {
     const int chunk = (int)(i / kChunkFloats), e = (int)(i % kChunkFloats);
@@ -188,9 +199,9 @@ __global__ void __launch_bounds__(256) branch_pack_kernel(const BrArgs a, BrArgs
     const int orow = 32 * m + (lane & 31);                  // output feature; rows / hidden columns past the real width: zero
     const long row = (long)orow * ly.ldw;
     float v = 0.f;
-    if (orow >= a.width) {
+    if (orow >= width_out) {
     } else if (chunk < ly.nblk) {                           // a memory block: k-steps 0 .. 15 of its own chunk
-      const BrBlock b = a.blk[chunk];
+      const BrBlock b = a.blk[ly.blk0 + chunk];
       const int ks = 4 * g4 + j, col = 8 * (ks >> 2) + (ks & 3) + 4 * half;
       if (g4 < 4 && col < b.ncols) v = ly.W[row + b.wcol0 + col];
     } else {
@@ -200,12 +211,17 @@ __global__ void __launch_bounds__(256) branch_pack_kernel(const BrArgs a, BrArgs
     out[i] = v;
   }
   if (blockIdx.x == 0) {
+    float* const sig_aux = a.aux + (a.nlayers + 1) * kChainAuxFloats;      // behind the layers' (and the direction layer's) biases
+    float* const rgb_aux = sig_aux + kChainAuxFloats + 4;
     for (int e = threadIdx.x; e < nt * 32; e += 256) {
       const int m = e >> 5, half = (e >> 4) & 1, r = e & 15, f = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-      a.aux[l * kChainAuxFloats + e] = f < a.width ? ly.b[f] : 0.f;
-      if (l == 0) a.aux[a.nlayers * kChainAuxFloats + e] = f < a.width ? a.wsig[f] : 0.f;
+      a.aux[l * kChainAuxFloats + e] = f < width_out ? ly.b[f] : 0.f;
+      if (l == 0) sig_aux[e] = f < a.width ? a.wsig[f] : 0.f;
+      if (dirl)
+        for (int c = 0; c < 3; ++c) rgb_aux[c * 128 + e] = f < width_out ? a.wrgb[(long)c * width_out + f] : 0.f;
     }
-    if (l == 0 && threadIdx.x == 0) a.aux[a.nlayers * kChainAuxFloats + nt * 32] = a.bsig[0];
+    if (l == 0 && threadIdx.x == 0) sig_aux[kChainAuxFloats] = a.bsig[0];
+    if (dirl && threadIdx.x < 3) rgb_aux[3 * 128 + threadIdx.x] = a.brgb[threadIdx.x];
     if (l == 0) {
       const unsigned* src = (const unsigned*)&a;
       unsigned* dst = (unsigned*)parked;
@@ -225,16 +241,20 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
   constexpr int kCB = kChunkBytes;
   constexpr int kAuxBytes = kBrAuxFloats(kBrMaxLayers) * 4;
   __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kCB + kAuxBytes + kStageBytes];
-  __shared__ int lay_nblk[kBrMaxLayers], lay_hid[kBrMaxLayers], lay_flags[kBrMaxLayers];
+  __shared__ int lay_nblk[kBrMaxLayers + 1], lay_hid[kBrMaxLayers + 1], lay_flags[kBrMaxLayers + 1], lay_blk0[kBrMaxLayers + 1];
   __shared__ BrBlock blks[kBrMaxBlocks];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, wave = tid >> 6;
   const int nl = __builtin_amdgcn_readfirstlane(ap->nlayers), nb = __builtin_amdgcn_readfirstlane(ap->nblocks);
   const long P = ap->P;
-  for (int i = tid; i < nl; i += 256) { lay_nblk[i] = ap->layer[i].nblk; lay_hid[i] = ap->layer[i].hid_col0; lay_flags[i] = ap->layer[i].flags; }
+  const int has_dir = __builtin_amdgcn_readfirstlane(ap->has_dir);
+  for (int i = tid; i < nl + has_dir; i += 256) {
+    lay_nblk[i] = ap->layer[i].nblk; lay_hid[i] = ap->layer[i].hid_col0; lay_flags[i] = ap->layer[i].flags; lay_blk0[i] = ap->layer[i].blk0;
+  }
   for (int i = tid; i < nb; i += 256) blks[i] = ap->blk[i];
   float* aux_lds = (float*)(ring_mem + kRingSlots * kCB);
   const float* gaux = ap->aux;
   for (int i = tid; i < kBrAuxFloats(nl); i += 256) aux_lds[i] = gaux[i];
+  float* const rgb_out = ap->rgb;
   WeightStreamT<kCB> st;
   st.init((const char*)ap->blob, __builtin_amdgcn_readfirstlane(ap->total_chunks), (lds_char*)ring_mem, tid);
   const int nt_real = __builtin_amdgcn_readfirstlane(ap->width) >> 5;
@@ -242,7 +262,8 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
   float* const Y = ap->Y;
   const long ldy = ap->ldy;
   __syncthreads();
-  const float* aux_sig = aux_lds + nl * kChainAuxFloats;
+  const float* aux_sig = aux_lds + (nl + 1) * kChainAuxFloats;
+  const float* aux_rgb = aux_sig + kChainAuxFloats + 4;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const Stage sg{(float*)(ring_mem + kRingSlots * kCB + kAuxBytes) + wave * kStageFloats, tile * 128 + wave * 32, P, lane};
     const long p_raw = sg.p0 + (lane & 31);
@@ -275,15 +296,16 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
       const float* b = aux_lds + l * kChainAuxFloats + half * 16;
 #pragma unroll
       for (int m = 0; m < NT; ++m) acc[m] = *(const f32x16*)(b + m * 32);
-      if (nblk > 0) {                                      // (uniform) the branch's input blocks, two register sets in turn
+      if (nblk > 0) {                                      // (uniform) the layer's input blocks, two register sets in turn
+        const int b0 = __builtin_amdgcn_readfirstlane(lay_blk0[l]);
         float r0[16], r1[16];
         int e = 0;
-        fetch(0, r0);
+        fetch(b0, r0);
         while (true) {
-          if (e + 1 < nblk) fetch(e + 1, r1);
+          if (e + 1 < nblk) fetch(b0 + e + 1, r1);
           { RegSrc16 s{r0}; layer_mac<NT, 16, RegSrc16>(acc, st, s); }
           if (++e >= nblk) break;
-          if (e + 1 < nblk) fetch(e + 1, r0);
+          if (e + 1 < nblk) fetch(b0 + e + 1, r0);
           { RegSrc16 s{r1}; layer_mac<NT, 16, RegSrc16>(acc, st, s); }
           if (++e >= nblk) break;
         }
@@ -295,11 +317,33 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
       if (flags & 1) finish<NT, true>(acc, h);
       else finish<NT, false>(acc, h);
       if (flags & 2) {                                     // density head on this layer's output (nerf_model.py:111, 141)
-        const float sgm = head_dot<NT>(h, aux_sig, half) + aux_sig[NT * 32];
+        const float sgm = head_dot<NT>(h, aux_sig, half) + aux_sig[kChainAuxFloats];
         if (half == 0 && p_raw < P) sigma_out[p_raw] = sgm;
       }
     }
-    if (Y) {
+    if (has_dir) {                                         // (uniform) direction layer on the final layer's output + colour head
+      constexpr int NTO = dir_tiles(NT);
+      f32x16 acc2[NTO], hd[NTO];
+      const float* b = aux_lds + nl * kChainAuxFloats + half * 16;
+#pragma unroll
+      for (int m = 0; m < NTO; ++m) acc2[m] = *(const f32x16*)(b + m * 32);
+      const int nblk = __builtin_amdgcn_readfirstlane(lay_nblk[nl]), b0 = __builtin_amdgcn_readfirstlane(lay_blk0[nl]);
+      for (int e = 0; e < nblk; ++e) {                     // the direction embedding: one block for Embedding(3, 4), more for wider ones
+        float r0[16];
+        fetch(b0 + e, r0);
+        RegSrc16 s{r0};
+        layer_mac<NTO, 16, RegSrc16>(acc2, st, s);
+      }
+      {
+        HidSrc<NT> s{h};
+        layer_mac<NTO, chain_ks(NT), HidSrc<NT>>(acc2, st, s);
+      }
+      finish<NTO, true>(acc2, hd);
+      float col[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] = sigmoidf(head_dot<NTO>(hd, aux_rgb + c * 128, half) + aux_rgb[3 * 128 + c]);
+      if (half == 0 && p_raw < P) { rgb_out[p_raw * 3] = col[0]; rgb_out[p_raw * 3 + 1] = col[1]; rgb_out[p_raw * 3 + 2] = col[2]; }
+    } else if (Y) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         if (t < nt_real) save_tile<NT>(h, t, Y, ldy, sg);      // (uniform: the padding tiles of a narrow branch have no columns)
@@ -313,22 +357,27 @@ static long branch_chunks(int width, int D, int nskips, int nblocks, bool with_f
   const int nt = width / 32;
   return (long)(1 + nskips) * nblocks + (long)(D - 1 + (with_final ? 1 : 0)) * chain_cpl(nt);
 }
+static int dir_hid_chunks(int nt) { const int kg = chunk_ksteps(dir_tiles(nt)); return (chain_ks(nt) + kg - 1) / kg; }
 static int blocks_of(int cols) { return (cols + 31) / 32; }
 static int branch_width(int width) { return width < kChainMinWidth ? kChainMinWidth : width; }       // the width the kernel runs at
-int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c) {
+int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c, int in_dir) {
   if (width < 32 || width > 256 || (width & 31) || D + 1 > kBrMaxLayers) return 0;
   width = branch_width(width);
   const int nb = blocks_of(in_a) + (in_b > 0 ? blocks_of(in_b) : 0) + (in_c > 0 ? blocks_of(in_c) : 0);
   if (nb > kBrMaxBlocks) return 0;
-  return branch_chunks(width, D, nskips, nb, true) * kChunkFloats + kBrAuxFloats(D + 1) + (int64_t)(sizeof(BrArgs) + 3) / 4 + 8;
+  // (the direction layer's part whenever launch_branch could take it: an upper bound of what any call of this shape packs)
+  const long chunks = branch_chunks(width, D, nskips, nb, true) + blocks_of(in_dir > 0 ? in_dir : 0) + dir_hid_chunks(width / 32);
+  return chunks * kChunkFloats + kBrAuxFloats(D + 1) + (int64_t)(sizeof(BrArgs) + 3) / 4 + 8;
 }
 
 // One branch: q = the branch's parameter pointers in objnerf_arch order (D layers' weight, bias; then final, dir, sigma, rgb),
 // in[] = its input tensors (row-major, `c` columns each, concatenated in this order by the reference).  Writes sigma (P) and, unless
 // sigma_only, the final layer's rows to fin (P x width).  Returns 1 when the shape is not one this kernel takes (the caller then
 // runs its GEMMs), 0 on success, < 0 on error.
+// emb_dir (P x in_dir) + rgb (P x 3) given: the direction layer and the colour head run in the kernel too and `fin` is not written.
 int launch_branch(int width, int D, const int32_t* skips, int nskips, const float* const* q, const BranchInput* in, int nin, long P,
-                  float* sigma, float* fin, bool sigma_only, float* scratch, hipStream_t s) {
+                  float* sigma, float* fin, bool sigma_only, const float* emb_dir, int in_dir, float* rgb, float* scratch,
+                  hipStream_t s) {
   if (width < 32 || width > 256 || (width & 31) || D + 1 > kBrMaxLayers || D < 1) return 1;
   const int width_real = width;
   width = branch_width(width);                  // 32- and 64-wide branches: three out tiles, the surplus zero (layer_mac does not
@@ -343,6 +392,7 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
     }
     cin += in[i].c;
   }
+  const bool with_dir = !sigma_only && emb_dir && rgb && in_dir > 0 && (width_real & 1) == 0 && nb + blocks_of(in_dir) <= kBrMaxBlocks;
   const int nt = width / 32;
   auto is_skip = [&](int l) { for (int i = 0; i < nskips; ++i) if (skips[i] == l) return true; return false; };
   int chunk = 0, nl = 0;
@@ -355,15 +405,25 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
     y.ldw = (blk_layer ? cin : 0) + (l == 0 ? 0 : width_real);
     y.flags = 1 | (l == D - 1 ? 2 : 0);
     y.chunk0 = chunk;
+    y.blk0 = 0;
     chunk += y.nblk + (y.hid_col0 >= 0 ? chain_cpl(nt) : 0);
   }
   const float* const* t = q + 2 * D;            // final, dir, sigma, rgb
   if (!sigma_only) {
     BrLayer& y = a.layer[nl++];
-    y.W = t[0]; y.b = t[1]; y.nblk = 0; y.hid_col0 = 0; y.ldw = width_real; y.flags = 0; y.chunk0 = chunk;
+    y.W = t[0]; y.b = t[1]; y.nblk = 0; y.hid_col0 = 0; y.ldw = width_real; y.flags = 0; y.chunk0 = chunk; y.blk0 = 0;
     chunk += chain_cpl(nt);
   }
-  a.nlayers = nl; a.nblocks = nb; a.nt = nt; a.total_chunks = chunk;
+  int nb_all = nb;
+  if (with_dir) {                               // layer[nl]: cat([final, emb_dir]) -> width / 2 (its hidden columns lead the weight)
+    BrLayer& y = a.layer[nl];
+    y.W = t[2]; y.b = t[3]; y.blk0 = nb; y.nblk = blocks_of(in_dir); y.hid_col0 = 0; y.ldw = width_real + in_dir; y.flags = 1; y.chunk0 = chunk;
+    for (int c0 = 0; c0 < in_dir; c0 += 32)
+      a.blk[nb_all++] = BrBlock{emb_dir, (long)in_dir, width_real + c0, c0, in_dir - c0 < 32 ? in_dir - c0 : 32, 0};
+    chunk += y.nblk + dir_hid_chunks(nt);
+    a.has_dir = 1; a.wrgb = t[6]; a.brgb = t[7]; a.rgb = rgb;
+  }
+  a.nlayers = nl; a.nblocks = nb_all; a.nt = nt; a.total_chunks = chunk;
   a.wsig = t[4]; a.bsig = t[5];
   a.width = width_real;
   a.sigma = sigma; a.Y = sigma_only ? nullptr : fin; a.ldy = width_real; a.P = P;
@@ -371,8 +431,9 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
   a.aux = scratch + (long)chunk * kChunkFloats;
   BrArgs* parked = (BrArgs*)(a.aux + kBrAuxFloats(nl) + ((4 - (kBrAuxFloats(nl) & 3)) & 3));
   if (P <= 0) return 0;
-  const int max_ch = nb + chain_cpl(nt);
-  hipLaunchKernelGGL(branch_pack_kernel, dim3((unsigned)((max_ch * kChunkFloats + 4095) / 4096), (unsigned)nl), dim3(256), 0, s, a, parked);
+  const int max_ch = nb + chain_cpl(nt) + dir_hid_chunks(nt);
+  hipLaunchKernelGGL(branch_pack_kernel, dim3((unsigned)((max_ch * kChunkFloats + 4095) / 4096), (unsigned)(nl + (with_dir ? 1 : 0))), dim3(256), 0, s,
+                     a, parked);
   const long ntiles = (P + 127) / 128;
   const dim3 grid(mlp_grid(ntiles));
   switch (nt) {
@@ -383,7 +444,8 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
     case 7: hipLaunchKernelGGL(branch_kernel<7>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
     default: hipLaunchKernelGGL(branch_kernel<8>, grid, dim3(256), 0, s, (const BrArgs*)parked, ntiles); break;
   }
-  return check_launch("branch");
+  const int rc = check_launch("branch");
+  return rc ? rc : (with_dir ? 2 : 0);          // 2: sigma AND rgb are written; 0: sigma and fin
 }
 
 }  // namespace objnerf

@@ -249,8 +249,8 @@ int64_t objnerf_mlp_generic_workspace_floats(const objnerf_arch* a, int64_t n_po
   int64_t chain = chain_scratch_floats(a->W, a->D) > chain_scratch_floats(a->inst_W, a->inst_D) ? chain_scratch_floats(a->W, a->D)
                                                                                                   : chain_scratch_floats(a->inst_W, a->inst_D);
   // ... or of a whole branch (first / skip layers as input blocks + plain layers + final)
-  const int64_t br_s = branch_scratch_floats(a->W, a->D, a->n_skips, a->in_xyz, 0, 0);
-  const int64_t br_o = branch_scratch_floats(a->inst_W, a->inst_D, a->n_inst_skips, a->in_xyz, a->obj_voxel_c, a->code_c);
+  const int64_t br_s = branch_scratch_floats(a->W, a->D, a->n_skips, a->in_xyz, 0, 0, a->in_dir);
+  const int64_t br_o = branch_scratch_floats(a->inst_W, a->inst_D, a->n_inst_skips, a->in_xyz, a->obj_voxel_c, a->code_c, a->in_dir);
   if (br_s > chain) chain = br_s;
   if (br_o > chain) chain = br_o;
   return n_points * (2 * wmax + wmax + wmax / 2) + chain + 4;
@@ -285,7 +285,8 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
   // Runs of plain hidden layers (not the first, not in `skips`) of a width that is a multiple of 32 from 96 to 256 go through ONE
   // persistent kernel each (chain_generic.hip, round 6): rows read once, weights from the LDS ring, the layers chained in registers.
   // OBJNERF_GENERIC_CHAIN=0: every layer its own GEMM as in rounds 4-5 (read on every call: the tests switch it inside a process).
-  const int chain_mode = [] { const char* e = getenv("OBJNERF_GENERIC_CHAIN"); return e ? atoi(e) : 2; }();      // 2: whole branches; 1: plain runs only
+  // 3: whole branches incl. the direction layer and the colour head; 2: up to `final`; 1: runs of plain layers only; 0: GEMMs
+  const int chain_mode = [] { const char* e = getenv("OBJNERF_GENERIC_CHAIN"); return e ? atoi(e) : 3; }();
   const bool chain_on = chain_mode != 0;
 
   // one branch: layers l = 0 .. D-1 (LeakyReLU; layer l in `skips` sees cat([input, h]), nerf_model.py:104-105, 137-138),
@@ -310,9 +311,11 @@ int objnerf_mlp_generic(const objnerf_mlp_generic_args* g, void* stream) {
     if (chain_mode >= 2 && W >= 32 && W <= 256 && (W & 31) == 0 && !c.rc) {      // (32 / 64 wide: zero-padded to three out tiles)
       BranchInput bin[3];
       for (int i = 0; i < nin; ++i) bin[i] = BranchInput{in[i].x, in[i].c};
-      const int rc = launch_branch(W, D, skips, nsk, q, bin, nin, P, sig, fin, g->sigma_only != 0, chain_ws, c.s);
+      const int rc = launch_branch(W, D, skips, nsk, q, bin, nin, P, sig, fin, g->sigma_only != 0, chain_mode >= 3 ? g->emb_dir : nullptr,
+                                   a->in_dir, rgb, chain_ws, c.s);
       if (rc < 0) c.rc = rc;
-      branch_done = rc == 0;
+      branch_done = rc == 0 || rc == 2;
+      if (rc == 2) return;                        // the direction layer and the colour head ran in the kernel as well
     }
     const float* h = nullptr;
     for (int l = 0; l < D && !branch_done; ++l) {

@@ -34,9 +34,11 @@ int launch_chain(int width, int L, const float* const* Ws, const float* const* b
 // any architecture: a whole branch (first / skip layers from 32-column blocks of the input tensors, plain layers chained, density
 // head, final layer) in one persistent kernel; returns 1 when the shape is outside what it takes (chain_generic.hip)
 struct BranchInput { const float* x; int c; };
-int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c);
+int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c, int in_dir);
+// returns 0: sigma and fin written; 2: sigma and rgb written (direction layer + colour head in the kernel); 1: shape not taken; < 0 error
 int launch_branch(int width, int D, const int32_t* skips, int nskips, const float* const* q, const BranchInput* in, int nin, long P,
-                  float* sigma, float* fin, bool sigma_only, float* scratch, hipStream_t s);
+                  float* sigma, float* fin, bool sigma_only, const float* emb_dir, int in_dir, float* rgb, float* scratch,
+                  hipStream_t s);
 // floats of the mask area behind the activation matrices of a training workspace (mlp_kernel.h: train_mask_floats)
 long train_mask_floats_host(long n_points);
 // persistent grid of the MLP kernel: one workgroup per CU

@@ -258,7 +258,12 @@ def test_runs_of_plain_layers_in_one_kernel_match_the_per_layer_gemms(W, D, skip
         with torch.no_grad():
             return generic.mlp(m, ex, ed, None, code, True, True)
     monkeypatch.delenv("OBJNERF_GENERIC_CHAIN", raising=False)
-    a = run()                                     # whole branches in one kernel each (first / skip layers from input blocks, density head)
+    a = run()                                     # whole branches in one kernel each, direction layer and colour head included
+    monkeypatch.setenv("OBJNERF_GENERIC_CHAIN", "2")
+    a2 = run()                                    # ... up to `final` (the direction layer and the colour head as GEMMs)
+    for x, y in zip(a, a2):
+        assert H.normwise(x, y) < 1e-5, H.normwise(x, y)
+    assert not torch.equal(a[1], a2[1]) and torch.equal(a[0], a2[0]), "the colour layers did not move / the density moved"
     monkeypatch.setenv("OBJNERF_GENERIC_CHAIN", "1")
     a1 = run()                                    # only the runs of plain layers
     monkeypatch.setenv("OBJNERF_GENERIC_CHAIN", "0")

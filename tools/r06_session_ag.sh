@@ -1,4 +1,4 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06ag; mkdir -p $O; cd $R; export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_arch.py -q -m gpu > $O/tests_arch.txt 2>&1; echo "arch tests rc=$?"; tail -25 $O/tests_arch.txt | cut -c1-300
 timeout 600 python tools/arch_bench.py $O/arch_bench.md > $O/arch_bench.log 2>&1; echo "arch rc=$?"; tail -6 $O/arch_bench.log | cut -c1-250
-OBJNERF_GENERIC_CHAIN=1 timeout 600 python tools/arch_bench.py $O/arch_bench_chain.md > $O/arch_bench_chain.log 2>&1; echo "arch(chain only) rc=$?"; tail -4 $O/arch_bench_chain.log | cut -c1-250
+OBJNERF_GENERIC_CHAIN=2 timeout 600 python tools/arch_bench.py $O/arch_bench_final.md > $O/arch_bench_final.log 2>&1; echo "arch(up to final) rc=$?"; tail -4 $O/arch_bench_final.log | cut -c1-250
