@@ -295,3 +295,25 @@ def test_runs_of_plain_layers_in_one_kernel_match_the_per_layer_gemms(W, D, skip
         assert got.shape == want.shape
         assert H.normwise(got, ref) < 1e-5, H.normwise(got, ref)
         assert H.normwise(got, want) < 2e-5, H.normwise(got, want)
+
+
+@pytest.mark.parametrize("n", [1, 33, 129])
+def test_branch_kernel_on_one_layer_networks_and_tiny_batches(n, monkeypatch):
+    """csrc/chain_generic.hip at its edges: D = inst_D = 1 (the first layer is also the one the density head reads; no plain layer, no
+    skip), batches of 1, 33 and 129 points (less than a wave, a wave + 1, a tile + 1), against a GEMM per layer."""
+    from object_nerf_amd import generic
+    torch.manual_seed(n)
+    m = A.ObjectNeRF(A.default_model_config(W=96, D=1, skips=[], inst_W=64, inst_D=1, inst_skips=[], use_voxel_embedding=False)).to(DEV)
+    ex, ed = torch.randn(n, m.in_channels_xyz, device=DEV), torch.randn(n, m.in_channels_dir, device=DEV)
+    code = torch.randn(n, 64, device=DEV)
+    with torch.no_grad():
+        monkeypatch.delenv("OBJNERF_GENERIC_CHAIN", raising=False)
+        a = generic.mlp(m, ex, ed, None, code, True, True)
+        so = generic.mlp(m, ex, None, None, code, True, True, sigma_only=True)
+        monkeypatch.setenv("OBJNERF_GENERIC_CHAIN", "0")
+        b = generic.mlp(m, ex, ed, None, code, True, True)
+        monkeypatch.delenv("OBJNERF_GENERIC_CHAIN", raising=False)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.isfinite(x).all()
+        assert H.normwise(x, y) < 1e-5, H.normwise(x, y)
+    assert torch.equal(so[0], a[0]) and torch.equal(so[2], a[2]) and so[1] is None and so[3] is None

@@ -1,0 +1,2 @@
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06ah; mkdir -p $O; cd $R; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_arch.py -q -m gpu > $O/tests_arch.txt 2>&1; echo "arch tests rc=$?"; tail -25 $O/tests_arch.txt | cut -c1-300
