@@ -423,7 +423,7 @@ int objnerf_mlp_train_backward(const objnerf_train_args* a, const float* d_sigma
   }
   // ---- the voxel-table scatter of those gradients (objnerf_train_args.scatter_*).  On a SIDE stream beside the weight-gradient
   // kernels it was measured slower (20.30 vs 20.05 ms per step, profiles/r04_train_ab.txt: its workgroups take compute units from
-  // MFMA-bound kernels that already run at the part's power limit), so it is simply enqueued here ----
+  // MFMA-bound kernels), so it is simply enqueued here ----
   clk.begin(PH_SCATTER);
   if (vox && a->scatter_xyz && a->scatter_table_grad && !c.rc)
     c.rc = launch_voxel_embed_bwd(&a->grid, a->scatter_xyz, P, d_emb_xyz, obj ? d_obj_voxel : nullptr, a->scatter_table_grad,
