@@ -1133,11 +1133,7 @@ __device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_l
     for (int j = 0; j < 4; ++j)
       if (4 * q + j < KS) {
 #pragma unroll
-#ifdef OBJ_RB_PROBE_NO_MFMA    // attribution probe: the stores and loads alone (one FMA per k-step keeps operands and reads alive)
-        for (int t = 0; t < NT; ++t) acc[t][j] = fmaf(a4[t][j], bop[4 * q + j], acc[t][j]);
-#else
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][j], bop[4 * q + j], acc[t], 0, 0, 0);
-#endif
       }
   }
   // The D layout of a tile is the 16-float piece [m][h][0..15] of the ray's vector: 64 bytes per lane, a ray's two halves 128
@@ -1148,9 +1144,6 @@ __device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_l
   // EVERY lane stores, no branch around the stores: a row past the end of the batch carries the LAST ray's inputs (fetch clamps its
   // slot) and re-writes that ray's row with the same bits.  A `valid` predicate made the stores a skippable block, the wait-count
   // pass then priced every wait for the next group's inputs by the path without them: vmcnt(0), a full drain per iteration.
-#ifdef OBJ_RB_PROBE_NO_STORE      // attribution probe (tools/ray_bias_probe.py): only a value-dependent, never-true store keeps the MFMAs alive
-  if (acc[0][0] == 1.2345e-31f) out_base[0] = acc[NT - 1][5];
-#else
   const int pt = lane & 31, rq = lane >> 3, k = lane & 7;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -1163,7 +1156,6 @@ __device__ __forceinline__ void rb_tiles(const float* a_lds, const float* bias_l
       *(f32x4u*)(out_base + (long)rayrow[i] * kRayBiasFloats + off[t] + 4 * k) = v;
     }
   }
-#endif
 }
 
 // Eight waves: the A slices (96 KB: one workgroup per CU) leave room for only ONE wave per SIMD with four -- nothing then overlaps a
@@ -1220,11 +1212,7 @@ __global__ void __launch_bounds__(512) ray_bias_kernel(const RayBiasArgs a, cons
       const float* cp = a.codes + o.ray * a.code_stride + 32 * h;
 #pragma unroll
       for (int c4 = 0; c4 < 8; ++c4) {
-#ifdef OBJ_RB_PROBE_NO_LOAD
-        const f32x4 v = {(float)c4, 1.f, (float)lane, 0.5f};
-#else
         const f32x4 v = *(const f32x4u*)(cp + 4 * c4);
-#endif
         o.x[4 * c4] = v[0]; o.x[4 * c4 + 1] = v[1]; o.x[4 * c4 + 2] = v[2]; o.x[4 * c4 + 3] = v[3];
       }
     }

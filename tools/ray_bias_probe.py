@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Times objnerf_ray_bias alone at the headline frame's ray count (307,200 rays, both branches) on the library OBJNERF_LIB names:
-the attribution probes of round 6 (csrc/ray_kernels.hip OBJ_RB_PROBE_NO_STORE / _NO_LOAD: stores or input loads compiled out) against
-the shipped kernel.  tools/ray_bias_probe.py [n_rays]"""
+the attribution probes of round 6 (libraries built from a temporary patch of csrc/ray_kernels.hip that compiled the kernel's stores,
+its input loads or its MFMAs out -- the patch is not kept, profiles/r06_ray_bias_probe.txt holds what it measured) against the
+shipped kernel.  tools/ray_bias_probe.py [n_rays]"""
 import ctypes as C
 import os
 import sys
