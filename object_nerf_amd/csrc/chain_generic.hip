@@ -138,7 +138,7 @@ int launch_chain(int width, int L, const float* const* Ws, const float* const* b
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // A whole branch of any architecture in one persistent kernel (round 6): layers 0 .. D-1 -- the first layer and the skip layers read
-// their `torch.cat([emb_xyz (, obj_voxel, obj_code) (, h)])` input (nerf_model.py:100-105, 128-138) as 32-column BLOCKS of the
+// their `torch.cat([emb_xyz (, obj_voxel, obj_code) (, h)])` input (nerf_model.py:100-105, 128-138) as 32- or 64-column BLOCKS of the
 // embedding rows straight from memory, the plain layers chain in registers as above -- then the 1-row density head on the VALU and the
 // activation-free `final` layer.  What is left to the GEMMs of generic.hip is the direction layer (W -> W / 2 on cat([final, dir]))
 // and the 3-row colour head.
@@ -175,6 +175,11 @@ struct BrArgs {
   float* blob; float* aux;                       // packed stream / biases + head, in the workspace
 };
 static_assert(sizeof(BrArgs) <= 3584, "the branch description travels as a kernel argument");
+// k-steps per input block: 16 (32 columns) fill a chunk for 8 out tiles; branches of up to 4 out tiles take 32 (64 columns) -- half
+// the chunk barriers per MFMA and chunks filled to 32 of their k-steps instead of 16 (the 128-wide object branch of the default
+// shape spends 60 % of its MFMAs in block layers: default shape 66.5 -> 67.9 M ray-samples/s); a block that holds at most 32 columns
+// runs its first 16 k-steps only
+OBJ_HD constexpr int blk_ks(int nt) { return nt <= 4 ? 32 : 16; }
 // out tiles of the direction layer: width / 2 <= 96 columns on three tiles (zero-padded), more on four
 OBJ_HD constexpr int dir_tiles(int nt) { return nt <= 6 ? 3 : 4; }
 // aux: per layer 256 bias floats (the direction layer's too) | density head: 256 weights + bias | colour head: 3 x 128 weights + 3 biases
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(256) branch_pack_kernel(const BrArgs a, BrArgs
     } else if (chunk < ly.nblk) {                           // a memory block: k-steps 0 .. 15 of its own chunk
       const BrBlock b = a.blk[ly.blk0 + chunk];
       const int ks = 4 * g4 + j, col = 8 * (ks >> 2) + (ks & 3) + 4 * half;
-      if (g4 < 4 && col < b.ncols) v = ly.W[row + b.wcol0 + col];
+      if (ks < blk_ks(a.nt) && col < b.ncols) v = ly.W[row + b.wcol0 + col];
     } else {
       const int ks = (chunk - ly.nblk) * kg + 4 * g4 + j;
       if (4 * g4 < kg && ks < ks_n && hid_feat(ks, half) < a.width) v = ly.W[row + ly.hid_col0 + hid_feat(ks, half)];
@@ -230,8 +235,9 @@ __global__ void __launch_bounds__(256) branch_pack_kernel(const BrArgs a, BrArgs
   }
 }
 
-struct RegSrc16 {
-  const float (&v)[16];
+template <int KS>
+struct RegSrc {
+  const float (&v)[KS];
   template <int I>
   __device__ __forceinline__ float get() { return v[I]; }
 };
@@ -273,12 +279,13 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
     for (int m = 0; m < NT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) h[m][r] = 0.f;
-    // this lane's 16 values of input block e: columns 8 g + 4 half .. + 3 of the block are k-steps 4 g .. 4 g + 3
-    auto fetch = [&](int e, float (&v)[16]) __attribute__((always_inline)) {
+    constexpr int BKS = blk_ks(NT);
+    // this lane's BKS values of input block e: columns 8 g + 4 half .. + 3 of the block are k-steps 4 g .. 4 g + 3
+    auto fetch = [&](int e, float (&v)[BKS]) __attribute__((always_inline)) {
       const float* x = blks[e].x + p * blks[e].ld + blks[e].col0 + 4 * half;
       const int ncols = blks[e].ncols;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < BKS / 4; ++g) {
         const int c = 8 * g + 4 * half;
         if (c + 4 <= ncols) {
           const f32x4 q = *(const f32x4u*)(x + 8 * g);
@@ -289,6 +296,13 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
         }
       }
     };
+    // one block's product; a 64-column block that holds at most 32 columns (a tensor's tail, a narrow tensor) runs its first 16
+    // k-steps only -- the rest of its chunk is zeros
+    auto mac = [&](int e, const float (&v)[BKS]) __attribute__((always_inline)) {
+      RegSrc<BKS> s{v};
+      if (BKS == 32 && __builtin_amdgcn_readfirstlane(blks[e].ncols) <= 32) layer_mac<NT, 16, RegSrc<BKS>>(acc, st, s);
+      else layer_mac<NT, BKS, RegSrc<BKS>>(acc, st, s);
+    };
 #pragma unroll 1
     for (int l = 0; l < nl; ++l) {
       const int nblk = __builtin_amdgcn_readfirstlane(lay_nblk[l]), hid = __builtin_amdgcn_readfirstlane(lay_hid[l]);
@@ -298,15 +312,15 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
       for (int m = 0; m < NT; ++m) acc[m] = *(const f32x16*)(b + m * 32);
       if (nblk > 0) {                                      // (uniform) the layer's input blocks, two register sets in turn
         const int b0 = __builtin_amdgcn_readfirstlane(lay_blk0[l]);
-        float r0[16], r1[16];
+        float r0[BKS], r1[BKS];
         int e = 0;
         fetch(b0, r0);
         while (true) {
           if (e + 1 < nblk) fetch(b0 + e + 1, r1);
-          { RegSrc16 s{r0}; layer_mac<NT, 16, RegSrc16>(acc, st, s); }
+          mac(b0 + e, r0);
           if (++e >= nblk) break;
           if (e + 1 < nblk) fetch(b0 + e + 1, r0);
-          { RegSrc16 s{r1}; layer_mac<NT, 16, RegSrc16>(acc, st, s); }
+          mac(b0 + e, r1);
           if (++e >= nblk) break;
         }
       }
@@ -329,10 +343,11 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
       for (int m = 0; m < NTO; ++m) acc2[m] = *(const f32x16*)(b + m * 32);
       const int nblk = __builtin_amdgcn_readfirstlane(lay_nblk[nl]), b0 = __builtin_amdgcn_readfirstlane(lay_blk0[nl]);
       for (int e = 0; e < nblk; ++e) {                     // the direction embedding: one block for Embedding(3, 4), more for wider ones
-        float r0[16];
+        float r0[BKS];
         fetch(b0 + e, r0);
-        RegSrc16 s{r0};
-        layer_mac<NTO, 16, RegSrc16>(acc2, st, s);
+        RegSrc<BKS> s{r0};
+        if (BKS == 32 && __builtin_amdgcn_readfirstlane(blks[b0 + e].ncols) <= 32) layer_mac<NTO, 16, RegSrc<BKS>>(acc2, st, s);
+        else layer_mac<NTO, BKS, RegSrc<BKS>>(acc2, st, s);
       }
       {
         HidSrc<NT> s{h};
@@ -358,15 +373,16 @@ static long branch_chunks(int width, int D, int nskips, int nblocks, bool with_f
   return (long)(1 + nskips) * nblocks + (long)(D - 1 + (with_final ? 1 : 0)) * chain_cpl(nt);
 }
 static int dir_hid_chunks(int nt) { const int kg = chunk_ksteps(dir_tiles(nt)); return (chain_ks(nt) + kg - 1) / kg; }
-static int blocks_of(int cols) { return (cols + 31) / 32; }
+static int blocks_of(int cols, int bw) { return (cols + bw - 1) / bw; }     // bw = 2 blk_ks(nt) columns per block
 static int branch_width(int width) { return width < kChainMinWidth ? kChainMinWidth : width; }       // the width the kernel runs at
 int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, int in_c, int in_dir) {
   if (width < 32 || width > 256 || (width & 31) || D + 1 > kBrMaxLayers) return 0;
   width = branch_width(width);
-  const int nb = blocks_of(in_a) + (in_b > 0 ? blocks_of(in_b) : 0) + (in_c > 0 ? blocks_of(in_c) : 0);
+  const int bw = 2 * blk_ks(width / 32);
+  const int nb = blocks_of(in_a, bw) + (in_b > 0 ? blocks_of(in_b, bw) : 0) + (in_c > 0 ? blocks_of(in_c, bw) : 0);
   if (nb > kBrMaxBlocks) return 0;
   // (the direction layer's part whenever launch_branch could take it: an upper bound of what any call of this shape packs)
-  const long chunks = branch_chunks(width, D, nskips, nb, true) + blocks_of(in_dir > 0 ? in_dir : 0) + dir_hid_chunks(width / 32);
+  const long chunks = branch_chunks(width, D, nskips, nb, true) + blocks_of(in_dir > 0 ? in_dir : 0, bw) + dir_hid_chunks(width / 32);
   return chunks * kChunkFloats + kBrAuxFloats(D + 1) + (int64_t)(sizeof(BrArgs) + 3) / 4 + 8;
 }
 
@@ -384,15 +400,16 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
                                                 // compile for one or two out tiles)
   BrArgs a;
   memset(&a, 0, sizeof(a));
+  const int bw = 2 * blk_ks(width / 32);        // columns per input block
   int nb = 0, cin = 0;
   for (int i = 0; i < nin; ++i) {
-    for (int c0 = 0; c0 < in[i].c; c0 += 32) {
+    for (int c0 = 0; c0 < in[i].c; c0 += bw) {
       if (nb >= kBrMaxBlocks) return 1;
-      a.blk[nb++] = BrBlock{in[i].x, (long)in[i].c, cin + c0, c0, in[i].c - c0 < 32 ? in[i].c - c0 : 32, 0};
+      a.blk[nb++] = BrBlock{in[i].x, (long)in[i].c, cin + c0, c0, in[i].c - c0 < bw ? in[i].c - c0 : bw, 0};
     }
     cin += in[i].c;
   }
-  const bool with_dir = !sigma_only && emb_dir && rgb && in_dir > 0 && (width_real & 1) == 0 && nb + blocks_of(in_dir) <= kBrMaxBlocks;
+  const bool with_dir = !sigma_only && emb_dir && rgb && in_dir > 0 && (width_real & 1) == 0 && nb + blocks_of(in_dir, bw) <= kBrMaxBlocks;
   const int nt = width / 32;
   auto is_skip = [&](int l) { for (int i = 0; i < nskips; ++i) if (skips[i] == l) return true; return false; };
   int chunk = 0, nl = 0;
@@ -417,9 +434,9 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
   int nb_all = nb;
   if (with_dir) {                               // layer[nl]: cat([final, emb_dir]) -> width / 2 (its hidden columns lead the weight)
     BrLayer& y = a.layer[nl];
-    y.W = t[2]; y.b = t[3]; y.blk0 = nb; y.nblk = blocks_of(in_dir); y.hid_col0 = 0; y.ldw = width_real + in_dir; y.flags = 1; y.chunk0 = chunk;
-    for (int c0 = 0; c0 < in_dir; c0 += 32)
-      a.blk[nb_all++] = BrBlock{emb_dir, (long)in_dir, width_real + c0, c0, in_dir - c0 < 32 ? in_dir - c0 : 32, 0};
+    y.W = t[2]; y.b = t[3]; y.blk0 = nb; y.nblk = blocks_of(in_dir, bw); y.hid_col0 = 0; y.ldw = width_real + in_dir; y.flags = 1; y.chunk0 = chunk;
+    for (int c0 = 0; c0 < in_dir; c0 += bw)
+      a.blk[nb_all++] = BrBlock{emb_dir, (long)in_dir, width_real + c0, c0, in_dir - c0 < bw ? in_dir - c0 : bw, 0};
     chunk += y.nblk + dir_hid_chunks(nt);
     a.has_dir = 1; a.wrgb = t[6]; a.brgb = t[7]; a.rgb = rgb;
   }

@@ -135,11 +135,12 @@ def test_other_architectures_are_built_like_the_reference_builds_them():
     assert l.objnerf_arch_num_param_ptrs(C.byref(a)) == 2 * (6 + 4) + 2 * (3 + 4)
     # two ping-pong hidden buffers | final | direction hidden per point, then (round 6) a constant: the packed weight stream of the
     # longest thing one persistent kernel may take -- a run of plain layers (6 x (2 chunks of 8,192 floats for a 128-wide layer + 256
-    # bias floats)) or the whole 128-wide scene branch (19 chunks + biases + heads + its description); the 64-wide object branch stays on the
+    # bias floats)) or the whole 128-wide scene branch (17 chunks + biases + heads + its description); the 64-wide object branch stays on the
     # GEMMs (csrc/chain_generic.hip: widths 96 .. 256)
     ws0, ws1 = (l.objnerf_mlp_generic_workspace_floats(C.byref(a), n) for n in (0, 1000))
-    # (16 chunks up to `final` + 1 direction-embedding block + 2 chunks of the direction layer's hidden columns)
-    assert ws1 - ws0 == 1000 * (2 * 128 + 128 + 64) and 19 * 8192 < ws0 < 19 * 8192 + 6144
+    # (a 128-wide branch takes its 51 input columns as ONE 64-column block: 2 block chunks + 12 up to `final` + 1 direction-embedding
+    # block + 2 chunks of the direction layer's hidden columns)
+    assert ws1 - ws0 == 1000 * (2 * 128 + 128 + 64) and 17 * 8192 < ws0 < 17 * 8192 + 6144
     a.W = 127
     assert l.objnerf_mlp_generic_workspace_floats(C.byref(a), 1000) < 0 and b"architecture" in l.objnerf_last_error()
     with pytest.raises(ValueError):
