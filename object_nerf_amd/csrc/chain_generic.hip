@@ -157,6 +157,7 @@ struct BrLayer {
   int flags;                           // 1: LeakyReLU, 2: the density head reads this layer's output
   int chunk0;                          // first chunk of the layer in the stream
   int blk0;                            // its input blocks are blk[blk0 .. blk0 + nblk)
+  float* save;                         // training: the layer's output rows (P x width) are also written here (null: not kept)
 };
 struct BrBlock { const float* x; long ld; int wcol0, col0, ncols, pad; };     // columns [col0, col0 + ncols) of x = W columns wcol0 ..
 struct BrArgs {
@@ -168,6 +169,7 @@ struct BrArgs {
   // on dir_tiles(nt) out tiles, followed by the 3-row colour head + sigmoid: the kernel then writes rgb instead of final's rows
   const float* wrgb; const float* brgb;          // (3, width / 2), (3)
   float* rgb;                                    // (P, 3)
+  float* save_dirh;                              // training: the direction layer's output rows (P x width / 2, width / 2 a multiple of 32)
   const float* wsig; const float* bsig;          // density head: (1, width), (1)
   float* sigma;                                  // (P)
   float* Y; long ldy;                            // output rows of the LAST layer (null: not wanted, sigma_only)
@@ -249,13 +251,16 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
   __shared__ __attribute__((aligned(16))) char ring_mem[kRingSlots * kCB + kAuxBytes + kStageBytes];
   __shared__ int lay_nblk[kBrMaxLayers + 1], lay_hid[kBrMaxLayers + 1], lay_flags[kBrMaxLayers + 1], lay_blk0[kBrMaxLayers + 1];
   __shared__ BrBlock blks[kBrMaxBlocks];
+  __shared__ float* lay_save[kBrMaxLayers + 1];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, wave = tid >> 6;
   const int nl = __builtin_amdgcn_readfirstlane(ap->nlayers), nb = __builtin_amdgcn_readfirstlane(ap->nblocks);
   const long P = ap->P;
   const int has_dir = __builtin_amdgcn_readfirstlane(ap->has_dir);
   for (int i = tid; i < nl + has_dir; i += 256) {
     lay_nblk[i] = ap->layer[i].nblk; lay_hid[i] = ap->layer[i].hid_col0; lay_flags[i] = ap->layer[i].flags; lay_blk0[i] = ap->layer[i].blk0;
+    lay_save[i] = ap->layer[i].save;
   }
+  float* const save_dirh = ap->save_dirh;
   for (int i = tid; i < nb; i += 256) blks[i] = ap->blk[i];
   float* aux_lds = (float*)(ring_mem + kRingSlots * kCB);
   const float* gaux = ap->aux;
@@ -330,6 +335,11 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
       }
       if (flags & 1) finish<NT, true>(acc, h);
       else finish<NT, false>(acc, h);
+      if (float* sv = lay_save[l]) {                       // (uniform) training: the layer's output is kept for the backward
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (t < nt_real) save_tile<NT>(h, t, sv, (long)(nt_real * 32), sg);
+      }
       if (flags & 2) {                                     // density head on this layer's output (nerf_model.py:111, 141)
         const float sgm = head_dot<NT>(h, aux_sig, half) + aux_sig[kChainAuxFloats];
         if (half == 0 && p_raw < P) sigma_out[p_raw] = sgm;
@@ -354,6 +364,11 @@ __global__ void __launch_bounds__(256, 1) branch_kernel(const BrArgs* __restrict
         layer_mac<NTO, chain_ks(NT), HidSrc<NT>>(acc2, st, s);
       }
       finish<NTO, true>(acc2, hd);
+      if (save_dirh) {                                     // (uniform; width / 2 is a multiple of 32 then)
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+          if (2 * t < nt_real) save_tile<NTO>(hd, t, save_dirh, (long)(nt_real * 16), sg);
+      }
       float col[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[c] = sigmoidf(head_dot<NTO>(hd, aux_rgb + c * 128, half) + aux_rgb[3 * 128 + c]);
@@ -393,7 +408,7 @@ int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, 
 // emb_dir (P x in_dir) + rgb (P x 3) given: the direction layer and the colour head run in the kernel too and `fin` is not written.
 int launch_branch(int width, int D, const int32_t* skips, int nskips, const float* const* q, const BranchInput* in, int nin, long P,
                   float* sigma, float* fin, bool sigma_only, const float* emb_dir, int in_dir, float* rgb, float* scratch,
-                  hipStream_t s) {
+                  hipStream_t s, float* const* saves, float* save_dirh) {
   if (width < 32 || width > 256 || (width & 31) || D + 1 > kBrMaxLayers || D < 1) return 1;
   const int width_real = width;
   width = branch_width(width);                  // 32- and 64-wide branches: three out tiles, the surplus zero (layer_mac does not
@@ -409,7 +424,9 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
     }
     cin += in[i].c;
   }
-  const bool with_dir = !sigma_only && emb_dir && rgb && in_dir > 0 && (width_real & 1) == 0 && nb + blocks_of(in_dir, bw) <= kBrMaxBlocks;
+  // (training keeps the direction layer's output: its rows are whole 32-column tiles only when width / 2 is a multiple of 32)
+  const bool with_dir = !sigma_only && emb_dir && rgb && in_dir > 0 && (width_real & 1) == 0 && nb + blocks_of(in_dir, bw) <= kBrMaxBlocks &&
+                        (!save_dirh || (width_real / 2) % 32 == 0);
   const int nt = width / 32;
   auto is_skip = [&](int l) { for (int i = 0; i < nskips; ++i) if (skips[i] == l) return true; return false; };
   int chunk = 0, nl = 0;
@@ -423,12 +440,14 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
     y.flags = 1 | (l == D - 1 ? 2 : 0);
     y.chunk0 = chunk;
     y.blk0 = 0;
+    y.save = saves ? saves[l] : nullptr;
     chunk += y.nblk + (y.hid_col0 >= 0 ? chain_cpl(nt) : 0);
   }
   const float* const* t = q + 2 * D;            // final, dir, sigma, rgb
   if (!sigma_only) {
     BrLayer& y = a.layer[nl++];
     y.W = t[0]; y.b = t[1]; y.nblk = 0; y.hid_col0 = 0; y.ldw = width_real; y.flags = 0; y.chunk0 = chunk; y.blk0 = 0;
+    y.save = (saves && with_dir) ? fin : nullptr;          // (without the direction layer `fin` is the kernel's output anyway)
     chunk += chain_cpl(nt);
   }
   int nb_all = nb;
@@ -438,7 +457,8 @@ int launch_branch(int width, int D, const int32_t* skips, int nskips, const floa
     for (int c0 = 0; c0 < in_dir; c0 += bw)
       a.blk[nb_all++] = BrBlock{emb_dir, (long)in_dir, width_real + c0, c0, in_dir - c0 < bw ? in_dir - c0 : bw, 0};
     chunk += y.nblk + dir_hid_chunks(nt);
-    a.has_dir = 1; a.wrgb = t[6]; a.brgb = t[7]; a.rgb = rgb;
+    a.has_dir = 1; a.wrgb = t[6]; a.brgb = t[7]; a.rgb = rgb; a.save_dirh = save_dirh;
+    y.save = nullptr;
   }
   a.nlayers = nl; a.nblocks = nb_all; a.nt = nt; a.total_chunks = chunk;
   a.wsig = t[4]; a.bsig = t[5];

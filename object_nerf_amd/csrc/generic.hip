@@ -248,7 +248,7 @@ int64_t objnerf_mlp_generic_workspace_floats(const objnerf_arch* a, int64_t n_po
   // two ping-pong hidden buffers | final | direction hidden | the packed weight stream of a run of plain layers (chain_generic.hip)
   int64_t chain = chain_scratch_floats(a->W, a->D) > chain_scratch_floats(a->inst_W, a->inst_D) ? chain_scratch_floats(a->W, a->D)
                                                                                                   : chain_scratch_floats(a->inst_W, a->inst_D);
-  // ... or of a whole branch (first / skip layers as input blocks + plain layers + final)
+  // ... or of a whole branch (first / skip layers as input blocks + plain layers + final + direction layer)
   const int64_t br_s = branch_scratch_floats(a->W, a->D, a->n_skips, a->in_xyz, 0, 0, a->in_dir);
   const int64_t br_o = branch_scratch_floats(a->inst_W, a->inst_D, a->n_inst_skips, a->in_xyz, a->obj_voxel_c, a->code_c, a->in_dir);
   if (br_s > chain) chain = br_s;
@@ -381,9 +381,15 @@ long gen_ws_floats(const objnerf_arch* a, long P) {
 }
 }  // namespace
 
+static int64_t gen_branch_scratch(const objnerf_arch* a) {
+  const int64_t br_s = branch_scratch_floats(a->W, a->D, a->n_skips, a->in_xyz, 0, 0, a->in_dir);
+  const int64_t br_o = branch_scratch_floats(a->inst_W, a->inst_D, a->n_inst_skips, a->in_xyz, a->obj_voxel_c, a->code_c, a->in_dir);
+  return (br_s > br_o ? br_s : br_o) + 4;
+}
 int64_t objnerf_mlp_generic_train_workspace_floats(const objnerf_arch* a, int64_t n_points) {
   if (check_arch(a) || n_points < 0) return -1;
-  return gen_ws_floats(a, n_points);
+  // the saved activations, then (round 6) the packed weight stream of a branch for the forward's persistent kernel (chain_generic.hip)
+  return gen_ws_floats(a, n_points) + gen_branch_scratch(a);
 }
 /* backward scratch: the gradients w.r.t. every layer's pre-activation output (same layout) + (P,3) x 2 for the rgb heads */
 int64_t objnerf_mlp_generic_train_scratch_floats(const objnerf_arch* a, int64_t n_points) {
@@ -405,10 +411,31 @@ int objnerf_mlp_generic_train_forward(const objnerf_mlp_generic_args* g, void* s
   const GenWs w{a, P, g->workspace};
   const float* const* p = g->h_params;
   struct Blk { const float* x; int c; };
+  // the forward's persistent branch kernel keeps every layer's rows as it goes (chain_generic.hip; OBJNERF_GENERIC_CHAIN < 2: GEMMs)
+  const int chain_mode = [] { const char* e = getenv("OBJNERF_GENERIC_CHAIN"); return e ? atoi(e) : 3; }();
+  float* chain_ws = g->workspace + gen_ws_floats(a, P);
+  chain_ws += (4 - ((chain_ws - g->workspace) & 3)) & 3;
   auto branch = [&](const float* const* q, int D, int W, const int32_t* skips, int nsk, const Blk* in, int nin, auto act_of, float* fin,
                     float* dirh, float* sig, float* rgb) {
     int cin = 0;
     for (int i = 0; i < nin; ++i) cin += in[i].c;
+    const float* const* t = q + 2 * D;
+    if (chain_mode >= 2 && D <= 64 && !c.rc) {
+      BranchInput bin[3];
+      for (int i = 0; i < nin; ++i) bin[i] = BranchInput{in[i].x, in[i].c};
+      float* saves[64];
+      for (int l = 0; l < D; ++l) saves[l] = act_of(l);
+      const int rc = launch_branch(W, D, skips, nsk, q, bin, nin, P, sig, fin, false, chain_mode >= 3 ? g->emb_dir : nullptr, a->in_dir, rgb,
+                                   chain_ws, c.s, saves, dirh);
+      if (rc < 0) { c.rc = rc; return; }
+      if (rc == 2) return;                       // every layer, both heads
+      if (rc == 0) {                             // up to `final`: the direction layer and the colour head as GEMMs
+        const CatBlk dblk[2] = {{fin, W, W, t[2]}, {g->emb_dir, a->in_dir, a->in_dir, t[2] + W}};
+        lin_cat(c, dblk, 2, W + a->in_dir, P, W / 2, dirh, W / 2, EPI_BIAS_LEAKY, t[3]);
+        lin(c, dirh, W / 2, t[6], W / 2, P, 3, W / 2, rgb, 3, 0, EPI_BIAS_SIGMOID, t[7]);
+        return;
+      }
+    }
     auto cat_layer = [&](const float* Wm, long ldw, const float* hid, float* y, const float* bias) {      // as in objnerf_mlp_generic
       CatBlk blk[5];
       int nb = 0, col = 0;
@@ -423,7 +450,6 @@ int objnerf_mlp_generic_train_forward(const objnerf_mlp_generic_args* g, void* s
       else lin(c, act_of(l - 1), W, q[2 * l], W, P, W, W, y, W, 0, EPI_BIAS_LEAKY, q[2 * l + 1]);
     }
     const float* h = act_of(D - 1);
-    const float* const* t = q + 2 * D;
     lin(c, h, W, t[4], W, P, 1, W, sig, 1, 0, EPI_BIAS, t[5]);
     lin(c, h, W, t[0], W, P, W, W, fin, W, 0, EPI_BIAS, t[1]);
     const CatBlk dblk[2] = {{fin, W, W, t[2]}, {g->emb_dir, a->in_dir, a->in_dir, t[2] + W}};

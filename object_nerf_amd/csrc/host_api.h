@@ -38,7 +38,9 @@ int64_t branch_scratch_floats(int width, int D, int nskips, int in_a, int in_b, 
 // returns 0: sigma and fin written; 2: sigma and rgb written (direction layer + colour head in the kernel); 1: shape not taken; < 0 error
 int launch_branch(int width, int D, const int32_t* skips, int nskips, const float* const* q, const BranchInput* in, int nin, long P,
                   float* sigma, float* fin, bool sigma_only, const float* emb_dir, int in_dir, float* rgb, float* scratch,
-                  hipStream_t s);
+                  hipStream_t s, float* const* saves = nullptr, float* save_dirh = nullptr);
+// (saves: training -- D pointers, layer l's output rows are also written to saves[l]; `fin` and save_dirh keep the final and the
+// direction layer's rows)
 // floats of the mask area behind the activation matrices of a training workspace (mlp_kernel.h: train_mask_floats)
 long train_mask_floats_host(long n_points);
 // persistent grid of the MLP kernel: one workgroup per CU
