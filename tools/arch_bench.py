@@ -44,6 +44,33 @@ def rate(sc, env):
                 os.environ["OBJNERF_PATH"] = old
 
 
+def train_ms(sc, n_rays=2048, steps=6):
+    """one training step of the reference's batch shape (2048 rays, 64 + 64, perturb / noise on) on a scene's architecture: forward +
+    backward (no optimizer), ms"""
+    rays_all = synth.camera_rays(320, 240).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    params = [p for m in (sc.models["coarse"], sc.models["fine"], sc.code_library, sc.embeddings["xyz"]) for p in m.parameters()]
+    target = torch.rand(n_rays, 3, device=DEV, generator=g)
+    ids = synth.per_ray_ids(n_rays).to(DEV)
+
+    def step():
+        for p in params:
+            p.grad = None
+        rays = rays_all[torch.randint(0, rays_all.shape[0], (n_rays,), device=DEV, generator=g)].contiguous()
+        codes = sc.code_library({"instance_ids": ids})["embedding_instance"]
+        r = A.render_rays(sc.models, sc.embeddings, rays, N_samples=64, N_importance=64, perturb=1.0, noise_std=1.0,
+                          embedding_instance=codes, frustum_bound_th=0.025)
+        mse = torch.nn.functional.mse_loss
+        sum(mse(r["rgb_%s" % t], target) + mse(r["rgb_instance_%s" % t], target) for t in ("coarse", "fine")).backward()
+    step(); step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def main(out=None):
     lines = ["| architecture | path | ms per 320x240 frame | M ray-samples/s |", "|---|---|---|---|"]
     sc = cases.scene_for(A, "voxel", device=DEV)
@@ -54,6 +81,11 @@ def main(out=None):
         sc = cases.scene_for(A, a, device=DEV)
         r, ms = rate(sc, None)
         lines.append("| %s %s | layer-wise | %.1f | %.1f |" % (a, cases.ARCH_SCENES[a][2], ms, r))
+    if os.environ.get("ARCH_BENCH_TRAIN", "1") != "0":
+        lines += ["", "| architecture | training step (2048 rays x (64 + 64), forward + backward), ms |", "|---|---|"]
+        for a in sorted(cases.ARCH_SCENES):
+            sc = cases.scene_for(A, a, device=DEV)
+            lines.append("| %s | %.2f |" % (a, train_ms(sc)))
     txt = "\n".join(lines)
     print(txt)
     if out:
